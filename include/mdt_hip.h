@@ -1,0 +1,239 @@
+/*
+ * mdt_hip.h -- C ABI of libmdt_hip.so: the MI355X (gfx950) native hot path of
+ * MIC-DKFZ/medicaldetectiontoolkit (2D/3D RoIAlign fwd/bwd, 2D/3D NMS, anchor
+ * generation, anchor<->GT matching, box decode/clip, weighted box clustering).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.  Every pointer is a
+ *    DEVICE pointer unless its name ends in _host.
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream).  All work
+ *    is enqueued on it; no call synchronises, allocates or frees.
+ *  - The caller owns every buffer, including `workspace` (size from the
+ *    matching *_workspace_bytes query; must be 16-byte aligned).
+ *  - Return value: MDT_OK (0) or a negative MDT_ERR_* code.  The library never
+ *    calls exit() (the reference does: crop_and_resize_kernel.cu:326-331).
+ *  - Tensor layouts are the reference's: feature maps (b, c, y, x[, z]) with the
+ *    last axis contiguous; boxes (y1, x1, y2, x2[, z1, z2]).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative
+ * to the reference checkout).
+ */
+#ifndef MDT_HIP_H
+#define MDT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDT_OK 0
+#define MDT_ERR_INVALID_ARGUMENT (-1)
+#define MDT_ERR_WORKSPACE_TOO_SMALL (-2)
+#define MDT_ERR_LAUNCH_FAILED (-3)
+#define MDT_ERR_UNSUPPORTED (-4)
+
+/* library / build identification; the string names the gfx target */
+const char *mdt_version(void);
+/* text for an MDT_ERR_* code */
+const char *mdt_error_string(int code);
+
+/* ------------------------------------------------------------------------- */
+/* RoIAlign ("crop and resize"), one bilinear/trilinear sample per bin        */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Replaces CropAndResizeLaucher (3D)
+ *   cuda_functions/roi_align_3D/roi_align/src/cuda/crop_and_resize_kernel.h:8-12
+ *   (kernel: crop_and_resize_kernel.cu:12-151) together with the output
+ *   zero-fill of crop_and_resize_gpu_forward (src/crop_and_resize_gpu.c:26-27):
+ *   every element of `crops` is written exactly once (rows whose box_ind is
+ *   outside [0,batch) are written as zeros), so the caller need not clear it.
+ * image [batch, depth, H, W, D] f32; boxes [num_boxes, 6] f32 normalised
+ * (y1,x1,y2,x2,z1,z2); box_ind [num_boxes] i32; crops [num_boxes, depth, ch, cw, cd].
+ * extrapolation_value is accepted and ignored, exactly like the reference kernel.
+ */
+int mdt_crop_and_resize_3d_forward(
+    const float *image, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
+    int crop_height, int crop_width, int crop_zdepth, int depth,
+    float extrapolation_value, float *crops, void *stream);
+
+/*
+ * Replaces CropAndResizeBackpropImageLaucher (3D)
+ *   crop_and_resize_kernel.h:14-18 (kernel: crop_and_resize_kernel.cu:154-304)
+ *   together with BOTH zero-fills of grads_image (crop_and_resize.py:40 and
+ *   crop_and_resize_gpu.c:61): grads_image is written exactly once, in gather
+ *   form, without atomics; the result is run-to-run deterministic and equals
+ *   the sequential (out_idx-ordered) fp32 accumulation bit for bit.
+ * grads [num_boxes, depth, ch, cw, cd]; grads_image [batch, depth, H, W, D].
+ * No workspace is needed.
+ */
+int mdt_crop_and_resize_3d_backward(
+    const float *grads, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
+    int crop_height, int crop_width, int crop_zdepth, int depth,
+    float *grads_image, void *stream);
+
+/* A/B variant of the above: vectorised zero-fill kernel followed by an fp32
+ * global-atomic scatter (the reference's algorithm, order-nondeterministic). */
+int mdt_crop_and_resize_3d_backward_atomic(
+    const float *grads, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
+    int crop_height, int crop_width, int crop_zdepth, int depth,
+    float *grads_image, void *stream);
+
+/* 2D twins: cuda_functions/roi_align_2D/roi_align/src/cuda/crop_and_resize_kernel.h
+ * (kernels crop_and_resize_kernel.cu:11-99, 102-194; glue crop_and_resize_gpu.c:7-67).
+ * image [batch, depth, H, W]; boxes [num_boxes, 4]; crops [num_boxes, depth, ch, cw]. */
+int mdt_crop_and_resize_2d_forward(
+    const float *image, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width,
+    int crop_height, int crop_width, int depth,
+    float extrapolation_value, float *crops, void *stream);
+
+int mdt_crop_and_resize_2d_backward(
+    const float *grads, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width,
+    int crop_height, int crop_width, int depth,
+    float *grads_image, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Non-maximum suppression                                                    */
+/* ------------------------------------------------------------------------- */
+
+#define MDT_NMS_RULE_GT 0 /* suppress when IoU >  thresh: GPU rule, nms_kernel.cu:71 */
+#define MDT_NMS_RULE_GE 1 /* suppress when IoU >= thresh: CPU rule, nms.c:64          */
+
+/*
+ * Pairwise suppression mask.  Replaces _nms
+ *   cuda_functions/nms_3D/src/cuda/nms_kernel.h:11-12 (kernel nms_kernel.cu:30-78;
+ *   IoU with the +1 pixel convention, nms_kernel.cu:16-28).
+ * dets_sorted [n, 7] = (y1,x1,y2,x2,z1,z2,score) (2D: [n,5]) already sorted by
+ * descending score; mask [n, ceil(n/64)] u64, bit j of word (i, c) set iff
+ * box 64c+j (> i) is suppressed by box i.  Only blocks on or above the diagonal
+ * are computed; words below it are written as 0 (the reference fills them but
+ * never reads them, nms_cuda.c:54).
+ */
+int mdt_nms_mask_3d(const float *dets_sorted, int n, float thresh, int rule,
+                    unsigned long long *mask, void *stream);
+int mdt_nms_mask_2d(const float *dets_sorted, int n, float thresh, int rule,
+                    unsigned long long *mask, void *stream);
+
+/*
+ * Device-resident NMS.  Replaces gpu_nms
+ *   cuda_functions/nms_3D/src/nms_cuda.h:1 (nms_cuda.c:17-67: mask launch, D2H
+ *   copy of the whole mask, host greedy scan) -- here mask build AND greedy
+ *   scan run on the device, nothing is copied to the host.
+ * keep [>= min(n, max_keep>0 ? max_keep : n)] i64 receives positions in the
+ * sorted list in ascending order; num_out [1] i32 (device) the count.
+ * max_keep <= 0: full scan (the reference's behaviour).  max_keep > 0: stop
+ * after that many boxes were kept -- identical to truncating the full result
+ * (models/mrcnn.py:348 keeps only the first proposal_count).
+ * workspace: mdt_nms_workspace_bytes(n) bytes.
+ */
+size_t mdt_nms_workspace_bytes(int n);
+int mdt_nms_3d(const float *dets_sorted, int n, float thresh, int rule, int max_keep,
+               long long *keep, int *num_out,
+               void *workspace, size_t workspace_bytes, void *stream);
+int mdt_nms_2d(const float *dets_sorted, int n, float thresh, int rule, int max_keep,
+               long long *keep, int *num_out,
+               void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Batched form used by the proposal layer (models/mrcnn.py:317-348 loops over
+ * batch elements and calls nms once per element): `batch` independent problems
+ * of n boxes each, dets_sorted [batch, n, 7|5], keep [batch, keep_stride] i64
+ * (rows padded with -1), num_out [batch] i32.
+ * workspace: batch * mdt_nms_workspace_bytes(n).
+ */
+int mdt_nms_3d_batched(const float *dets_sorted, int batch, int n, float thresh, int rule,
+                       int max_keep, long long *keep, int keep_stride, int *num_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int mdt_nms_2d_batched(const float *dets_sorted, int batch, int n, float thresh, int rule,
+                       int max_keep, long long *keep, int keep_stride, int *num_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Box decode + clip (fused)                                                  */
+/* ------------------------------------------------------------------------- */
+/*
+ * Replaces apply_box_deltas_{2D,3D} followed by clip_boxes_{2D,3D}
+ *   utils/model_utils.py:318-370, 374-398 as used in models/mrcnn.py:337-344:
+ *   out = clip(decode(anchors[order[i]], deltas[order[i]] * std_dev), window),
+ *   optionally with the score appended (out_stride 2*dim+1) so the result is
+ *   directly the `dets_sorted` input of mdt_nms_*.
+ * boxes [A, 2*dim] f32; deltas [A, 2*dim] f32; order [n] i64 or NULL (identity);
+ * scores [n] f32 or NULL (already gathered, i.e. scores[i] belongs to order[i]);
+ * std_dev_host [2*dim], window_host [2*dim] = (y1,x1,y2,x2[,z1,z2]) HOST floats;
+ * out [n, out_stride].
+ */
+int mdt_decode_clip_boxes(const float *boxes, const float *deltas, const long long *order,
+                          const float *scores, int n, int dim,
+                          const float *std_dev_host, const float *window_host,
+                          float *out, int out_stride, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Anchors                                                                    */
+/* ------------------------------------------------------------------------- */
+/*
+ * One pyramid level of generate_anchors_3D / generate_anchors
+ *   utils/model_utils.py:230-272, 190-226.  Anchor row index =
+ *   ((y*X + x)*Z + z)*K + k with K = n_ratios*n_scales, k = ratio_idx*n_scales +
+ *   scale_idx; heights = s/sqrt(r), widths = s*sqrt(r), depth = scales_z[k % n_scales]
+ *   (faithful to np.tile, :249); centres = arange(0,shape,anchor_stride)*feature_stride.
+ * All *_host arrays are HOST doubles.  out [n_anchors, 2*dim] f64 (device), rows
+ * (y1,x1,y2,x2[,z1,z2]); out_f32 (optional, may be NULL) receives the same rows
+ * rounded to f32 (models/mrcnn.py:846).
+ * dim = 2: shape_host = (Y,X), scales_z_host ignored.  dim = 3: shape_host = (Y,X,Z).
+ */
+int mdt_generate_anchors(int dim, const double *scales_xy_host, const double *scales_z_host,
+                         int n_scales, const double *ratios_host, int n_ratios,
+                         const int *shape_host, double feature_stride_xy,
+                         double feature_stride_z, int anchor_stride,
+                         double *out, float *out_f32, void *stream);
+
+/*
+ * Anchor <-> ground-truth matching, steps 1-3 of gt_anchor_matching
+ *   utils/model_utils.py:505-563 (IoU: compute_overlaps / compute_iou_{2D,3D},
+ *   :35-110, float64, no +1 convention).
+ * anchors [A, 2*dim] f64; gt_boxes [G, 2*dim] f64; gt_class_ids [G] i32 or NULL
+ * (all 1, the RPN case).  Outputs (device):
+ *   matches [A] i32     -1 negative (max IoU < neg_thresh), 0 neutral, >0 class id
+ *   iou_argmax [A] i32  index of the GT box with max IoU (first on ties, np.argmax)
+ *   iou_max [A] f64     may be NULL
+ *   gt_best_anchor [G] i32  argmax over anchors per GT (first on ties)
+ * The random positive subsampling and the delta targets of the few kept
+ * positives (:566-617) stay in the host mirror (they need numpy/torch RNG).
+ * workspace: mdt_anchor_match_workspace_bytes(A, G).
+ */
+size_t mdt_anchor_match_workspace_bytes(int n_anchors, int n_gt);
+int mdt_anchor_match(const double *anchors, int n_anchors, int dim,
+                     const double *gt_boxes, const int *gt_class_ids, int n_gt,
+                     double neg_thresh, double pos_thresh,
+                     int *matches, int *iou_argmax, double *iou_max, int *gt_best_anchor,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Weighted box clustering                                                    */
+/* ------------------------------------------------------------------------- */
+/*
+ * Replaces weighted_box_clustering  predictor.py:597-706 (float64).
+ * dets_sorted [n, 2*dim+3] f64 rows (coords, score, patch_center_factor,
+ * n_overlaps) sorted by descending score; patch_ids [n] i32 (the reference uses
+ * strings; any injective integer relabelling in [0, n_patch_ids) works).
+ * Outputs: out_scores [n] f64, out_coords [n, 2*dim] f64 hold the clusters whose
+ * averaged score > 0.01 (:697) in creation order; num_out [1] i32 (device).
+ * workspace: mdt_wbc_workspace_bytes(n, n_patch_ids).
+ */
+size_t mdt_wbc_workspace_bytes(int n, int n_patch_ids);
+int mdt_weighted_box_clustering(const double *dets_sorted, const int *patch_ids, int n, int dim,
+                                int n_patch_ids, double thresh, double n_ens,
+                                double *out_scores, double *out_coords, int *num_out,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDT_HIP_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of libmdt_hip.so (C ABI declared in include/mdt_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing or fails to
+load, every op raises ("fail loudly").
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdt_hip.so")
+
+MDT_OK = 0
+NMS_RULE_GT = 0  # GPU rule, IoU >  thresh (nms_kernel.cu:71)
+NMS_RULE_GE = 1  # CPU rule, IoU >= thresh (nms.c:64)
+
+_lib = None
+
+_SIGNATURES = {
+    "mdt_version": (c_char_p, []),
+    "mdt_error_string": (c_char_p, [c_int]),
+    "mdt_crop_and_resize_3d_forward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_float, c_void_p, c_void_p]),
+    "mdt_crop_and_resize_3d_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
+    "mdt_crop_and_resize_3d_backward_atomic": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
+    "mdt_crop_and_resize_2d_forward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p, c_void_p]),
+    "mdt_crop_and_resize_2d_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
+    "mdt_nms_mask_3d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "mdt_nms_mask_2d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "mdt_nms_workspace_bytes": (c_size_t, [c_int]),
+    "mdt_nms_3d": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_nms_2d": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_nms_3d_batched": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_nms_2d_batched": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_decode_clip_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mdt_generate_anchors": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p]),
+    "mdt_anchor_match_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mdt_anchor_match": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_wbc_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mdt_weighted_box_clustering": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises RuntimeError if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmdt_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C medicaldetectiontoolkit_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != MDT_OK:
+        raise RuntimeError("%s failed: %s (code %d)" % (what, lib().mdt_error_string(code).decode(), code))
+
+
+def current_stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: the MI355X HIP path is the only implementation "
+                           "(no CPU fallback in the product path)" % name)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)

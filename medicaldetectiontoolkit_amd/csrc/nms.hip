@@ -1,0 +1,296 @@
+// nms.hip -- 2D/3D greedy IoU-NMS, fully device resident, for gfx950.
+//
+// Semantics follow the reference (paths relative to the reference checkout):
+//   IoU (+1 pixel convention)  cuda_functions/nms_3D/src/cuda/nms_kernel.cu:16-28, nms_2D/...:16-24
+//   pairwise mask              cuda_functions/nms_3D/src/cuda/nms_kernel.cu:30-78
+//   greedy scan                cuda_functions/nms_3D/src/nms_cuda.c:47-61   (runs on the HOST there,
+//                              after a D2H copy of the whole mask, :33-34)
+// Design here:
+//   * mask kernel: one wavefront per 64x64 block of (row, col) box pairs, four
+//     blocks per workgroup.  The 64 lanes hold the 64 column boxes in registers;
+//     the row box is broadcast with v_readlane and one __ballot per row IS the
+//     u64 mask word.  Only blocks on/above the diagonal are computed.
+//   * scan kernel: one workgroup per problem.  Wave 0 resolves a 64-box block
+//     entirely in registers (ffs over the not-yet-removed bits, v_readlane of the
+//     diagonal words); all waves then OR the kept rows' remaining mask words
+//     into the `removed` bitmap held in LDS.  Blocks that are already fully
+//     removed cost no memory traffic; an optional max_keep stops the scan early
+//     (the RPN keeps only the first 75-500 boxes, models/mrcnn.py:348).
+//   Nothing is copied to the host and no memory is allocated.
+// Compiled with -ffp-contract=off so the IoU rounds like the uncontracted oracle
+// (the denominator Sa + Sb - interS would otherwise be contracted).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mdt_hip.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ float bcast(float v, int src_lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+// STRIDE == 7: 3D rows (c0,c1,c2,c3,c4,c5,score); STRIDE == 5: 2D rows (c0,c1,c2,c3,score)
+template <int STRIDE>
+struct Box {
+    float c[STRIDE - 1];
+};
+
+template <int STRIDE>
+__device__ __forceinline__ float box_iou(const Box<STRIDE> &a, const Box<STRIDE> &b)
+{
+    const float left = fmaxf(a.c[0], b.c[0]), right = fminf(a.c[2], b.c[2]);
+    const float top = fmaxf(a.c[1], b.c[1]), bottom = fminf(a.c[3], b.c[3]);
+    const float width = fmaxf(right - left + 1.0f, 0.f);
+    const float height = fmaxf(bottom - top + 1.0f, 0.f);
+    if (STRIDE == 7) {
+        const float front = fmaxf(a.c[4], b.c[4]), back = fminf(a.c[5], b.c[5]);
+        const float depth = fmaxf(back - front + 1.0f, 0.f);
+        const float interS = width * height * depth;
+        const float Sa = (a.c[2] - a.c[0] + 1.0f) * (a.c[3] - a.c[1] + 1.0f) * (a.c[5] - a.c[4] + 1.0f);
+        const float Sb = (b.c[2] - b.c[0] + 1.0f) * (b.c[3] - b.c[1] + 1.0f) * (b.c[5] - b.c[4] + 1.0f);
+        return interS / (Sa + Sb - interS);
+    } else {
+        const float interS = width * height;
+        const float Sa = (a.c[2] - a.c[0] + 1.0f) * (a.c[3] - a.c[1] + 1.0f);
+        const float Sb = (b.c[2] - b.c[0] + 1.0f) * (b.c[3] - b.c[1] + 1.0f);
+        return interS / (Sa + Sb - interS);
+    }
+}
+
+constexpr int MASK_WAVES = 4;
+
+// grid: (ceil(col_blocks / MASK_WAVES), col_blocks, batch); block: 64 * MASK_WAVES
+template <int STRIDE>
+__global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
+    const float *__restrict__ dets, int n, float thresh, int rule, int fill_lower,
+    u64 *__restrict__ mask)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int col_blocks = (n + 63) / 64;
+    const int col_start = blockIdx.x * MASK_WAVES + wave;
+    const int row_start = blockIdx.y;
+    if (col_start >= col_blocks) return;
+    dets += (long long)blockIdx.z * n * STRIDE;
+    mask += (long long)blockIdx.z * n * col_blocks;
+
+    const int row_idx = row_start * 64 + lane;
+    if (row_start > col_start) {
+        if (fill_lower && row_idx < n) mask[(long long)row_idx * col_blocks + col_start] = 0ULL;
+        return;
+    }
+    const int col_idx = col_start * 64 + lane;
+    const int row_size = min(n - row_start * 64, 64);
+
+    Box<STRIDE> colb, rowb;
+#pragma unroll
+    for (int q = 0; q < STRIDE - 1; ++q) {
+        colb.c[q] = (col_idx < n) ? dets[(long long)col_idx * STRIDE + q] : 0.0f;
+        rowb.c[q] = (row_idx < n) ? dets[(long long)row_idx * STRIDE + q] : 0.0f;
+    }
+
+    u64 word = 0ULL;
+    for (int i = 0; i < row_size; ++i) {
+        Box<STRIDE> a;
+#pragma unroll
+        for (int q = 0; q < STRIDE - 1; ++q) a.c[q] = bcast(rowb.c[q], i);
+        const float v = box_iou<STRIDE>(a, colb);  // a = current (row) box, b = column box
+        bool pred = (rule == MDT_NMS_RULE_GT) ? (v > thresh) : (v >= thresh);
+        pred = pred && (col_idx < n) && (col_idx > row_start * 64 + i);
+        const u64 bal = __ballot(pred);
+        if (lane == i) word = bal;
+    }
+    if (row_idx < n) mask[(long long)row_idx * col_blocks + col_start] = word;
+}
+
+constexpr int SCAN_THREADS = 1024;
+
+__device__ __forceinline__ u64 bcast64(u64 v, int src_lane)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffULL), src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src_lane);
+    return ((u64)hi << 32) | (u64)lo;
+}
+
+// grid: batch; block: SCAN_THREADS; dynamic LDS: col_blocks * 8 bytes
+__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
+    const u64 *__restrict__ mask, int n, int max_keep,
+    long long *__restrict__ keep, int keep_stride, int *__restrict__ num_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    u64 *remv = reinterpret_cast<u64 *>(smem_raw);
+    __shared__ u64 s_kept;
+    __shared__ int s_nkept;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int col_blocks = (n + 63) / 64;
+    mask += (long long)blockIdx.x * n * col_blocks;
+    keep += (long long)blockIdx.x * keep_stride;
+    const int limit = (max_keep > 0) ? min(max_keep, keep_stride) : keep_stride;
+
+    for (int j = tid; j < col_blocks; j += SCAN_THREADS) remv[j] = 0ULL;
+    if (tid == 0) { s_kept = 0ULL; s_nkept = 0; }
+    __syncthreads();
+
+    int nkept = 0;
+    for (int k = 0; k < col_blocks; ++k) {
+        const int rows_here = min(n - k * 64, 64);
+        const u64 valid = (rows_here == 64) ? ~0ULL : ((1ULL << rows_here) - 1ULL);
+        u64 r = remv[k];
+        if ((~r & valid) == 0ULL) continue;  // whole block already removed (uniform: remv is LDS-coherent after the barrier)
+
+        if (wave == 0) {
+            const int row = k * 64 + lane;
+            const u64 d = (row < n) ? mask[(long long)row * col_blocks + k] : 0ULL;
+            u64 kept = 0ULL;
+            u64 cand = ~r & valid;
+            while (cand) {
+                const int i = __ffsll((long long)cand) - 1;
+                kept |= 1ULL << i;
+                r |= bcast64(d, i);
+                const u64 above = (i == 63) ? 0ULL : (~0ULL << (i + 1));
+                cand = ~r & valid & above;
+            }
+            if ((kept >> lane) & 1ULL) {
+                const int pos = nkept + __popcll(kept & ((1ULL << lane) - 1ULL));
+                if (pos < limit) keep[pos] = (long long)row;
+            }
+            if (lane == 0) { s_kept = kept; s_nkept = nkept + __popcll(kept); }
+        }
+        __syncthreads();
+        const u64 kept = s_kept;
+        nkept = s_nkept;
+        if (max_keep > 0 && nkept >= max_keep) break;
+
+        // OR the kept rows' words of the later column blocks into remv
+        for (int j = k + 1 + tid; j < col_blocks; j += SCAN_THREADS) {
+            u64 acc = 0ULL;
+            u64 bits = kept;
+            while (bits) {
+                const int i = __ffsll((long long)bits) - 1;
+                bits &= bits - 1ULL;
+                acc |= mask[(long long)(k * 64 + i) * col_blocks + j];
+            }
+            remv[j] |= acc;
+        }
+        __syncthreads();
+    }
+
+    const int nout = min(nkept, limit);
+    if (tid == 0) num_out[blockIdx.x] = nout;
+    for (int j = nout + tid; j < keep_stride; j += SCAN_THREADS) keep[j] = -1LL;
+}
+
+inline int check_launch()
+{
+    return hipGetLastError() == hipSuccess ? MDT_OK : MDT_ERR_LAUNCH_FAILED;
+}
+
+template <int STRIDE>
+int launch_mask(const float *dets, int batch, int n, float thresh, int rule, int fill_lower,
+                u64 *mask, hipStream_t s)
+{
+    const int col_blocks = (n + 63) / 64;
+    if (col_blocks > 65535 || batch > 65535) return MDT_ERR_UNSUPPORTED;
+    dim3 grid((col_blocks + MASK_WAVES - 1) / MASK_WAVES, col_blocks, batch);
+    hipLaunchKernelGGL(nms_mask_kernel<STRIDE>, grid, dim3(64 * MASK_WAVES), 0, s,
+                       dets, n, thresh, rule, fill_lower, mask);
+    return check_launch();
+}
+
+template <int STRIDE>
+int nms_impl(const float *dets, int batch, int n, float thresh, int rule, int max_keep,
+             long long *keep, int keep_stride, int *num_out, void *ws, size_t ws_bytes, hipStream_t s)
+{
+    if (n < 0 || batch < 0 || (rule != MDT_NMS_RULE_GT && rule != MDT_NMS_RULE_GE) || keep_stride < 0)
+        return MDT_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return MDT_OK;
+    if (n == 0) {  // reference would launch a (0,0) grid unchecked (nms_kernel.cu:85-91); return num_out = 0
+        if (hipMemsetAsync(num_out, 0, sizeof(int) * batch, s) != hipSuccess) return MDT_ERR_LAUNCH_FAILED;
+        if (keep_stride > 0 &&
+            hipMemsetAsync(keep, 0xff, sizeof(long long) * (size_t)batch * keep_stride, s) != hipSuccess)
+            return MDT_ERR_LAUNCH_FAILED;
+        return MDT_OK;
+    }
+    const size_t need = (size_t)batch * mdt_nms_workspace_bytes(n);
+    if (ws == nullptr || ws_bytes < need) return MDT_ERR_WORKSPACE_TOO_SMALL;
+    const int col_blocks = (n + 63) / 64;
+    const size_t lds = (size_t)col_blocks * sizeof(u64);
+    if (lds > 128 * 1024) return MDT_ERR_UNSUPPORTED;  // n <= 1,048,576
+    u64 *mask = reinterpret_cast<u64 *>(ws);
+    int rc = launch_mask<STRIDE>(dets, batch, n, thresh, rule, 0, mask, s);
+    if (rc != MDT_OK) return rc;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nms_scan_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MDT_ERR_LAUNCH_FAILED;
+    }
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), lds, s,
+                       mask, n, max_keep, keep, keep_stride, num_out);
+    return check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mdt_nms_workspace_bytes(int n)
+{
+    if (n <= 0) return 16;
+    const size_t col_blocks = ((size_t)n + 63) / 64;
+    return ((size_t)n * col_blocks * sizeof(u64) + 255) & ~(size_t)255;
+}
+
+int mdt_nms_mask_3d(const float *dets_sorted, int n, float thresh, int rule, unsigned long long *mask, void *stream)
+{
+    if (n < 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return MDT_OK;
+    return launch_mask<7>(dets_sorted, 1, n, thresh, rule, 1, mask, (hipStream_t)stream);
+}
+
+int mdt_nms_mask_2d(const float *dets_sorted, int n, float thresh, int rule, unsigned long long *mask, void *stream)
+{
+    if (n < 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return MDT_OK;
+    return launch_mask<5>(dets_sorted, 1, n, thresh, rule, 1, mask, (hipStream_t)stream);
+}
+
+int mdt_nms_3d(const float *dets_sorted, int n, float thresh, int rule, int max_keep,
+               long long *keep, int *num_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int stride = (max_keep > 0 && max_keep < n) ? max_keep : n;
+    return nms_impl<7>(dets_sorted, 1, n, thresh, rule, max_keep, keep, stride, num_out,
+                       workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mdt_nms_2d(const float *dets_sorted, int n, float thresh, int rule, int max_keep,
+               long long *keep, int *num_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int stride = (max_keep > 0 && max_keep < n) ? max_keep : n;
+    return nms_impl<5>(dets_sorted, 1, n, thresh, rule, max_keep, keep, stride, num_out,
+                       workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mdt_nms_3d_batched(const float *dets_sorted, int batch, int n, float thresh, int rule, int max_keep,
+                       long long *keep, int keep_stride, int *num_out,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    return nms_impl<7>(dets_sorted, batch, n, thresh, rule, max_keep, keep, keep_stride, num_out,
+                       workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mdt_nms_2d_batched(const float *dets_sorted, int batch, int n, float thresh, int rule, int max_keep,
+                       long long *keep, int keep_stride, int *num_out,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    return nms_impl<5>(dets_sorted, batch, n, thresh, rule, max_keep, keep, keep_stride, num_out,
+                       workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+"""Shared implementation behind cuda_functions.roi_align_{2D,3D}.roi_align.crop_and_resize.
+
+The reference uses legacy instance-style autograd Functions (crop_and_resize.py:10-51),
+which torch >= 1.3 rejects; here `CropAndResizeFunction(ch, cw[, cd], extrap)` stays a
+callable object with the same constructor / call signature and dispatches to a
+new-style static Function.  Gradient flows to `image` only (crop_and_resize.py:51).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _prep(image, boxes, box_ind, dim):
+    _lib.require_cuda(image, "image")
+    # quirk 6: mask targets arrive as a (n,1,Y,X,Z,1) view -- tolerate trailing singletons
+    while image.dim() > dim + 2 and image.size(-1) == 1:
+        image = image.squeeze(-1)
+    if image.dim() != dim + 2:
+        raise ValueError("image must be [B, C, %s], got %s" % ("Y, X, Z" if dim == 3 else "Y, X", tuple(image.shape)))
+    if boxes.dim() != 2 or boxes.size(1) != 2 * dim:
+        raise ValueError("boxes must be [N, %d], got %s" % (2 * dim, tuple(boxes.shape)))
+    if box_ind.dim() != 1 or box_ind.size(0) != boxes.size(0):
+        raise ValueError("box_ind must be [N]")
+    # the reference's C glue never checks dtype / contiguity (crop_and_resize_gpu.c); do it here
+    image = image.contiguous()
+    if image.dtype != torch.float32:
+        image = image.float()
+    boxes = boxes.detach().to(device=image.device, dtype=torch.float32).contiguous()
+    box_ind = box_ind.detach().to(device=image.device, dtype=torch.int32).contiguous()
+    return image, boxes, box_ind
+
+
+def crop_forward(image, boxes, box_ind, crop, extrapolation_value=0.0):
+    dim = len(crop)
+    L = _lib.lib()
+    n = boxes.size(0)
+    B, C = image.size(0), image.size(1)
+    crops = torch.empty((n, C) + tuple(crop), dtype=torch.float32, device=image.device)
+    if n == 0 or C == 0:
+        return crops
+    with torch.cuda.device(image.device):
+        s = _lib.current_stream_ptr()
+        if dim == 3:
+            rc = L.mdt_crop_and_resize_3d_forward(
+                _lib.ptr(image), _lib.ptr(boxes), _lib.ptr(box_ind), n, B, image.size(2), image.size(3), image.size(4),
+                crop[0], crop[1], crop[2], C, ctypes.c_float(extrapolation_value), _lib.ptr(crops), s)
+        else:
+            rc = L.mdt_crop_and_resize_2d_forward(
+                _lib.ptr(image), _lib.ptr(boxes), _lib.ptr(box_ind), n, B, image.size(2), image.size(3),
+                crop[0], crop[1], C, ctypes.c_float(extrapolation_value), _lib.ptr(crops), s)
+    _lib.check(rc, "mdt_crop_and_resize_%dd_forward" % dim)
+    return crops
+
+
+def crop_backward(grads, boxes, box_ind, im_size, atomic=False):
+    """grads [N, C, *crop] -> grad_image of shape im_size; fully written by the kernel."""
+    dim = len(im_size) - 2
+    L = _lib.lib()
+    grads = grads.contiguous()
+    if grads.dtype != torch.float32:
+        grads = grads.float()
+    n = grads.size(0)
+    grad_image = torch.empty(tuple(im_size), dtype=torch.float32, device=grads.device)
+    if grad_image.numel() == 0:
+        return grad_image
+    with torch.cuda.device(grads.device):
+        s = _lib.current_stream_ptr()
+        if dim == 3:
+            fn = L.mdt_crop_and_resize_3d_backward_atomic if atomic else L.mdt_crop_and_resize_3d_backward
+            rc = fn(_lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(box_ind), n, im_size[0], im_size[2], im_size[3],
+                    im_size[4], grads.size(2), grads.size(3), grads.size(4), im_size[1], _lib.ptr(grad_image), s)
+        else:
+            rc = L.mdt_crop_and_resize_2d_backward(
+                _lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(box_ind), n, im_size[0], im_size[2], im_size[3],
+                grads.size(2), grads.size(3), im_size[1], _lib.ptr(grad_image), s)
+    _lib.check(rc, "mdt_crop_and_resize_%dd_backward" % dim)
+    return grad_image
+
+
+class _CropAndResize(Function):
+    @staticmethod
+    def forward(ctx, image, boxes, box_ind, crop, extrapolation_value):
+        orig_shape = image.shape
+        image_c, boxes_c, box_ind_c = _prep(image, boxes, box_ind, len(crop))
+        crops = crop_forward(image_c, boxes_c, box_ind_c, crop, extrapolation_value)
+        ctx.im_size = tuple(image_c.shape)
+        ctx.orig_shape = tuple(orig_shape)
+        ctx.in_dtype = image.dtype
+        ctx.save_for_backward(boxes_c, box_ind_c)
+        return crops
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        boxes, box_ind = ctx.saved_tensors
+        grad_image = crop_backward(grad_outputs, boxes, box_ind, ctx.im_size)
+        grad_image = grad_image.reshape(ctx.orig_shape)
+        if grad_image.dtype != ctx.in_dtype:
+            grad_image = grad_image.to(ctx.in_dtype)
+        return grad_image, None, None, None, None
+
+
+class CropAndResizeFunctionBase(object):
+    """Callable with the reference's constructor / call convention:
+    CropAndResizeFunction(ch, cw[, cd], extrapolation_value=0)(image, boxes, box_ind)."""
+    _dim = None
+
+    def __init__(self, *crop_and_extrap, **kw):
+        args = list(crop_and_extrap)
+        extrap = kw.pop("extrapolation_value", None)
+        if kw:
+            raise TypeError("unexpected arguments %s" % sorted(kw))
+        if len(args) == self._dim + 1:
+            extrap = args.pop()
+        if len(args) != self._dim:
+            raise TypeError("expected %d crop extents (+ optional extrapolation_value)" % self._dim)
+        self.crop = tuple(int(a) for a in args)
+        self.crop_height, self.crop_width = self.crop[0], self.crop[1]
+        if self._dim == 3:
+            self.crop_zdepth = self.crop[2]
+        self.extrapolation_value = 0.0 if extrap is None else float(extrap)
+
+    def __call__(self, image, boxes, box_ind):
+        return _CropAndResize.apply(image, boxes, box_ind, self.crop, self.extrapolation_value)
+
+    # legacy spelling used by some callers of the reference
+    def forward(self, image, boxes, box_ind):
+        return self(image, boxes, box_ind)

@@ -1,0 +1,43 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mdt_hip.h declares."""
+import ctypes
+import os
+import re
+
+from medicaldetectiontoolkit_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mdt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 15
+    L = _lib.lib()
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(names) == sorted(_lib.EXPORTED_SYMBOLS)
+    assert b"gfx950" in L.mdt_version()
+    assert L.mdt_error_string(-2) == b"workspace missing or too small"
+
+
+def test_workspace_queries_need_no_gpu():
+    L = _lib.lib()
+    assert L.mdt_nms_workspace_bytes(6000) >= 6000 * 94 * 8
+    assert L.mdt_nms_workspace_bytes(0) > 0
+    assert L.mdt_anchor_match_workspace_bytes(449280, 3) > 449280 * 8
+    assert L.mdt_wbc_workspace_bytes(45000, 1500) >= 45000 + 1500 * 4
+
+
+def test_dropin_import_paths():
+    import medicaldetectiontoolkit_amd as m
+    m.install_dropin()
+    from cuda_functions.nms_2D.pth_nms import nms_gpu as a  # noqa: F401  (models/mrcnn.py:24-27)
+    from cuda_functions.nms_3D.pth_nms import nms_gpu as b  # noqa: F401
+    from cuda_functions.roi_align_2D.roi_align.crop_and_resize import CropAndResizeFunction as c
+    from cuda_functions.roi_align_3D.roi_align.crop_and_resize import CropAndResizeFunction as d
+    assert c(7, 7, 0).crop == (7, 7) and d(7, 7, 3, 0).crop == (7, 7, 3)

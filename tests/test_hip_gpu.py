@@ -1,0 +1,280 @@
+"""GPU parity tests: the gfx950 HIP kernels (through the C ABI / the reference-shaped Python
+boundary) against the CPU oracle.  Bars (BASELINE.json north_star): NMS indices bit-exact;
+RoIAlign features within 1e-4 -- here the forward and the gather-form backward are required to be
+BIT-EXACT vs the (uncontracted, sequential) oracle; the atomic A/B variant within 1e-4."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from medicaldetectiontoolkit_amd import _lib
+from medicaldetectiontoolkit_amd.cuda_functions import _nms_impl, _roi_align_impl
+from medicaldetectiontoolkit_amd.cuda_functions.nms_2D.pth_nms import nms_cpu as nms_cpu_2D
+from medicaldetectiontoolkit_amd.cuda_functions.nms_2D.pth_nms import nms_gpu as nms_2D
+from medicaldetectiontoolkit_amd.cuda_functions.nms_3D.pth_nms import nms_cpu as nms_cpu_3D
+from medicaldetectiontoolkit_amd.cuda_functions.nms_3D.pth_nms import nms_gpu as nms_3D
+from medicaldetectiontoolkit_amd.cuda_functions.roi_align_2D.roi_align.crop_and_resize import \
+    CropAndResizeFunction as ra2D
+from medicaldetectiontoolkit_amd.cuda_functions.roi_align_3D.roi_align.crop_and_resize import \
+    CropAndResizeFunction as ra3D
+from oracle import oracle
+from tests.helpers import nms_boxes, random_boxes_2d, random_boxes_3d
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4  # north_star tolerance for RoIAlign features
+
+
+def _t(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+# ------------------------------------------------------------------ RoIAlign
+CASES_3D = [
+    # (B, C, Y, X, Z, N, crop, spill)
+    (2, 3, 12, 10, 16, 9, (7, 7, 3), True),
+    (8, 36, 32, 32, 128, 48, (7, 7, 3), False),     # P2 train-realistic
+    (8, 36, 32, 32, 128, 48, (14, 14, 5), False),
+    (8, 36, 16, 16, 64, 48, (14, 14, 5), True),     # P3
+    (8, 36, 8, 8, 32, 40, (7, 7, 3), True),         # P4
+    (8, 36, 4, 4, 16, 40, (14, 14, 5), True),       # P5
+    (3, 1, 32, 32, 32, 5, (28, 28, 10), False),     # mask-target shape (gt masks, C=1)
+    (2, 2, 6, 5, 7, 6, (3, 2, 2), True),            # odd extents -> scalar (VEC=1) path
+    (1, 2, 9, 9, 12, 4, (1, 1, 1), False),          # P == 1 rule
+    (2, 4, 16, 16, 16, 700, (7, 7, 3), True),       # > 256 RoIs: multi-chunk list
+]
+
+
+@pytest.mark.parametrize("case", CASES_3D)
+def test_roialign3d_forward_backward_bitexact(case, cuda):
+    B, C, Y, X, Z, N, crop, spill = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    image = rng.normal(size=(B, C, Y, X, Z)).astype(np.float32)
+    boxes = random_boxes_3d(rng, N, spill=spill)
+    box_ind = rng.integers(0, B, size=N).astype(np.int32)
+    if N > 4:
+        box_ind[1] = B + 3      # out of range -> row of zeros, no gradient
+        box_ind[2] = -1
+        boxes[3] = [0.5, 0.5, 0.5, 0.5, 0.5, 0.5]   # degenerate
+        boxes[4] = [0.9, 0.9, 0.1, 0.1, 0.8, 0.2]   # inverted
+    want = oracle.crop_and_resize_forward(image, boxes, box_ind, crop)
+
+    img_t = _t(image, cuda).requires_grad_(True)
+    got = ra3D(crop[0], crop[1], crop[2], 0)(img_t, _t(boxes, cuda), _t(box_ind, cuda))
+    assert got.shape == want.shape
+    assert np.array_equal(got.detach().cpu().numpy(), want), np.abs(got.detach().cpu().numpy() - want).max()
+
+    g = rng.normal(size=want.shape).astype(np.float32)
+    got.backward(_t(g, cuda))
+    want_g = oracle.crop_and_resize_backward(g, boxes, box_ind, image.shape)
+    got_g = img_t.grad.cpu().numpy()
+    assert np.array_equal(got_g, want_g), np.abs(got_g - want_g).max()
+
+    # atomic A/B variant: same values up to fp32 summation order
+    ga = _roi_align_impl.crop_backward(_t(g, cuda), _t(boxes, cuda), _t(box_ind, cuda), image.shape, atomic=True)
+    err = np.abs(ga.cpu().numpy() - want_g)
+    assert np.all(err <= TOL * np.maximum(1.0, np.abs(want_g)))
+
+
+CASES_2D = [
+    (2, 4, 20, 24, 11, (7, 7), True),
+    (4, 16, 72, 72, 60, (14, 14), False),
+    (2, 3, 9, 7, 8, (3, 5), True),     # odd width -> scalar path
+    (1, 1, 40, 40, 4, (28, 28), False),
+    (2, 2, 16, 16, 5, (1, 1), False),
+]
+
+
+@pytest.mark.parametrize("case", CASES_2D)
+def test_roialign2d_forward_backward_bitexact(case, cuda):
+    B, C, Y, X, N, crop, spill = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    image = rng.normal(size=(B, C, Y, X)).astype(np.float32)
+    boxes = random_boxes_2d(rng, N, patch=64.0, size=(4, 60), spill=spill)
+    box_ind = rng.integers(0, B, size=N).astype(np.int32)
+    if N > 3:
+        box_ind[1] = B
+    want = oracle.crop_and_resize_forward(image, boxes, box_ind, crop)
+    img_t = _t(image, cuda).requires_grad_(True)
+    got = ra2D(crop[0], crop[1], 0)(img_t, _t(boxes, cuda), _t(box_ind, cuda))
+    assert np.array_equal(got.detach().cpu().numpy(), want)
+    g = rng.normal(size=want.shape).astype(np.float32)
+    got.backward(_t(g, cuda))
+    want_g = oracle.crop_and_resize_backward(g, boxes, box_ind, image.shape)
+    assert np.array_equal(img_t.grad.cpu().numpy(), want_g)
+
+
+def test_roialign3d_backward_deterministic_and_full_size(cuda):
+    """BASELINE full size (P2, B=8, C=36, N=48, (14,14,5)): run-to-run bit equality, and the
+    size-independent adjoint property <crop(x), g> == <x, crop_bwd(g)>."""
+    rng = np.random.default_rng(7)
+    shape = (8, 36, 32, 32, 128)
+    boxes = _t(random_boxes_3d(rng, 48), cuda)
+    box_ind = _t(rng.integers(0, 8, size=48).astype(np.int32), cuda)
+    x = torch.randn(shape, device=cuda)
+    g = torch.randn((48, 36, 14, 14, 5), device=cuda)
+    a = _roi_align_impl.crop_backward(g, boxes, box_ind, shape)
+    b = _roi_align_impl.crop_backward(g, boxes, box_ind, shape)
+    assert torch.equal(a, b)
+    crops = _roi_align_impl.crop_forward(x, boxes, box_ind, (14, 14, 5))
+    lhs = (crops.double() * g.double()).sum().item()
+    rhs = (x.double() * a.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
+
+
+def test_roialign_empty_and_quirks(cuda):
+    img = torch.randn(2, 3, 8, 8, 8, device=cuda)
+    out = ra3D(7, 7, 3, 0)(img, torch.zeros(0, 6, device=cuda), torch.zeros(0, dtype=torch.int32, device=cuda))
+    assert out.shape == (0, 3, 7, 7, 3)
+    # quirk 6: 6-D view with a trailing singleton (mrcnn.py:558)
+    m = torch.rand(2, 1, 8, 8, 8, 1, device=cuda)
+    b = torch.tensor([[0.1, 0.1, 0.9, 0.9, 0.1, 0.9]] * 2, device=cuda)
+    o6 = ra3D(4, 4, 2, 0)(m, b, torch.arange(2, dtype=torch.int32, device=cuda))
+    o5 = ra3D(4, 4, 2, 0)(m.squeeze(-1), b, torch.arange(2, dtype=torch.int32, device=cuda))
+    assert torch.equal(o6, o5)
+    with pytest.raises(RuntimeError):
+        ra3D(7, 7, 3, 0)(img.cpu(), b.cpu(), torch.zeros(2, dtype=torch.int32))
+
+
+# ------------------------------------------------------------------ reference kernels on the same GPU
+def _ref_gpu(name):
+    p = os.path.join(os.path.dirname(oracle.__file__), "_ref", name)
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref/%s not built" % name)
+    return ctypes.CDLL(p)
+
+
+def test_roialign3d_vs_reference_cuda_kernel_on_gpu(cuda):
+    """oracle/_ref/libref_gpu_roialign3d.so = the reference's crop_and_resize_kernel.cu compiled for
+    gfx950 (hipcc contracts FMAs there like nvcc does) -> agreement within the 1e-4 bar."""
+    L = _ref_gpu("libref_gpu_roialign3d.so")
+    rng = np.random.default_rng(11)
+    B, C, Y, X, Z, N, crop = 4, 8, 16, 16, 32, 64, (7, 7, 3)
+    image = torch.randn(B, C, Y, X, Z, device=cuda)
+    boxes = _t(random_boxes_3d(rng, N, spill=True), cuda)
+    box_ind = _t(rng.integers(0, B, size=N).astype(np.int32), cuda)
+    ref = torch.zeros(N, C, *crop, device=cuda)
+    torch.cuda.synchronize()
+    vp = ctypes.c_void_p
+    L.CropAndResizeLaucher(vp(image.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X, Z,
+                           crop[0], crop[1], crop[2], C, ctypes.c_float(0), vp(ref.data_ptr()), vp(0))
+    torch.cuda.synchronize()
+    got = _roi_align_impl.crop_forward(image, boxes, box_ind, crop)
+    assert (got - ref).abs().max().item() <= TOL
+    g = torch.randn_like(ref)
+    ref_g = torch.zeros_like(image)
+    torch.cuda.synchronize()
+    L.CropAndResizeBackpropImageLaucher(vp(g.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X, Z,
+                                        crop[0], crop[1], crop[2], C, vp(ref_g.data_ptr()), vp(0))
+    torch.cuda.synchronize()
+    got_g = _roi_align_impl.crop_backward(g, boxes, box_ind, image.shape)
+    assert ((got_g - ref_g).abs() <= TOL * ref_g.abs().clamp(min=1.0)).all()
+
+
+def test_nms3d_mask_vs_reference_cuda_kernel_on_gpu(cuda):
+    L = _ref_gpu("libref_gpu_nms3d.so")
+    rng = np.random.default_rng(12)
+    n = 1000
+    dets = nms_boxes(rng, n)
+    ds = _t(dets[oracle.sort_order(dets[:, -1])], cuda)
+    cb = (n + 63) // 64
+    ref = torch.zeros(n, cb, dtype=torch.int64, device=cuda)
+    torch.cuda.synchronize()
+    vp = ctypes.c_void_p
+    L._nms(n, vp(ds.data_ptr()), vp(ref.data_ptr()), ctypes.c_float(0.7))
+    torch.cuda.synchronize()
+    mine = torch.zeros(n, cb, dtype=torch.int64, device=cuda)
+    rc = _lib.lib().mdt_nms_mask_3d(_lib.ptr(ds), n, ctypes.c_float(0.7), 0, _lib.ptr(mine), _lib.current_stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref, mine = ref.cpu().numpy(), mine.cpu().numpy()
+    rows = np.arange(n)[:, None] // 64
+    upper = np.arange(cb)[None, :] >= rows
+    # contraction may flip a pair whose IoU is within 1 ulp of the threshold: allow < 1e-5 of the bits
+    diff = np.unpackbits((ref[upper] ^ mine[upper]).view(np.uint8)).sum()
+    assert diff <= 1e-5 * upper.sum() * 64
+    assert np.all(mine[~upper] == 0)
+
+
+# ------------------------------------------------------------------ NMS
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 6000])
+def test_nms_indices_bitexact(dim, n, cuda):
+    nms = nms_3D if dim == 3 else nms_2D
+    nms_c = nms_cpu_3D if dim == 3 else nms_cpu_2D
+    for seed in range(2):
+        rng = np.random.default_rng(1000 * n + seed)
+        dets = nms_boxes(rng, n, dim=dim)
+        for thresh in (0.7, 1e-5):
+            got = nms(_t(dets, cuda), thresh)
+            assert got.dtype == torch.int64 and got.is_cuda
+            assert np.array_equal(got.cpu().numpy(), oracle.gpu_nms(dets, thresh, True))
+            gotc = nms_c(_t(dets, cuda), thresh)
+            assert np.array_equal(gotc.numpy(), oracle.cpu_nms(dets, thresh))
+
+
+def test_nms_mask_words_bitexact(cuda):
+    rng = np.random.default_rng(5)
+    for dim, n in ((3, 777), (2, 130)):
+        dets = nms_boxes(rng, n, dim=dim)
+        ds = dets[oracle.sort_order(dets[:, -1])]
+        want = oracle.nms_mask(ds, 0.5)
+        cb = (n + 63) // 64
+        mine = torch.full((n, cb), -1, dtype=torch.int64, device=cuda)
+        fn = _lib.lib().mdt_nms_mask_3d if dim == 3 else _lib.lib().mdt_nms_mask_2d
+        assert fn(_lib.ptr(_t(ds, cuda)), n, ctypes.c_float(0.5), 0, _lib.ptr(mine), _lib.current_stream_ptr()) == 0
+        mine = mine.cpu().numpy().view(np.uint64)
+        upper = np.arange(cb)[None, :] >= (np.arange(n)[:, None] // 64)
+        assert np.array_equal(mine[upper], want[upper])
+        assert np.all(mine[~upper] == 0)
+
+
+def test_nms_max_keep_equals_truncation_and_batched(cuda):
+    rng = np.random.default_rng(6)
+    B, n = 4, 1500
+    dets = np.stack([nms_boxes(rng, n) for _ in range(B)])
+    ds = np.stack([d[oracle.sort_order(d[:, -1])] for d in dets])
+    full = [oracle.gpu_nms(d, 0.7, True) for d in ds]   # ds already sorted -> positions
+    for b in range(B):
+        keep, num = _nms_impl.nms_sorted(_t(ds[b], cuda), 0.7, 3, max_keep=75)
+        k = int(num.item())
+        assert k == min(75, len(full[b]))
+        assert np.array_equal(keep[:k].cpu().numpy(), full[b][:k])
+    L = _lib.lib()
+    dsb = _t(ds, cuda)
+    keep = torch.empty(B, 75, dtype=torch.int64, device=cuda)
+    num = torch.empty(B, dtype=torch.int32, device=cuda)
+    wsb = B * L.mdt_nms_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    rc = L.mdt_nms_3d_batched(_lib.ptr(dsb), B, n, ctypes.c_float(0.7), 0, 75, _lib.ptr(keep), 75, _lib.ptr(num),
+                              _lib.ptr(ws), wsb, _lib.current_stream_ptr())
+    assert rc == 0
+    for b in range(B):
+        k = int(num[b].item())
+        assert k == min(75, len(full[b]))
+        assert np.array_equal(keep[b, :k].cpu().numpy(), full[b][:k])
+        assert (keep[b, k:] == -1).all()
+
+
+def test_nms_empty_and_errors(cuda):
+    assert nms_3D(torch.zeros(0, 7, device=cuda), 0.5).numel() == 0
+    with pytest.raises(ValueError):
+        nms_3D(torch.zeros(4, 5, device=cuda), 0.5)
+    with pytest.raises(RuntimeError):
+        nms_3D(torch.zeros(4, 7), 0.5)
+    L = _lib.lib()
+    d = torch.zeros(10, 7, device=cuda)
+    keep = torch.empty(10, dtype=torch.int64, device=cuda)
+    num = torch.empty(1, dtype=torch.int32, device=cuda)
+    rc = L.mdt_nms_3d(_lib.ptr(d), 10, ctypes.c_float(0.5), 0, 0, _lib.ptr(keep), _lib.ptr(num), None, 0, None)
+    assert rc == -2  # MDT_ERR_WORKSPACE_TOO_SMALL, no exit()
+
+
+def test_nms_worst_case_50000(cuda):
+    """Retina U-Net worst case: N = 50 000 at thresh 1e-5; properties instead of the
+    O(N^2) oracle: kept set is an independent set, every dropped box overlaps a better kept one."""
+    rng = np.random.default_rng(8)
+    dets = nms_boxes(rng, 50000)
+    got = nms_3D(_t(dets, cuda), 1e-5).cpu().numpy()
+    assert np.array_equal(got, oracle.gpu_nms(dets, 1e-5, True))

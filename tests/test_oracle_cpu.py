@@ -1,0 +1,154 @@
+"""CPU tests: pin the oracle (oracle/mdt_oracle.c) against independent statements of the same rule
+and against the reference's own nms.c compiled where it lies (oracle/_ref)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle
+from tests.helpers import nms_boxes, random_boxes_2d, random_boxes_3d
+
+
+def _grid_sample_crops(image, boxes, box_ind, crop):
+    """for pool extents > 1 the GPU kernel's rule == grid_sample(align_corners=False,
+    padding_mode='border') at the bin centres; grid last-dim order is (z, x, y) for (B,C,Y,X,Z)."""
+    img = torch.from_numpy(image).double()
+    dim = img.dim() - 2
+    b = torch.from_numpy(boxes).double()
+    out = []
+    for n in range(b.shape[0]):
+        axes = []
+        for a in range(dim):
+            a1, a2 = (b[n, a], b[n, a + 2]) if a < 2 else (b[n, 4], b[n, 5])
+            P = crop[a]
+            p = torch.arange(P, dtype=torch.float64)
+            centre = a1 + (p + 0.5) * (a2 - a1) / P       # normalised sampling position in [0,1]
+            axes.append(centre * 2 - 1)
+        if dim == 3:
+            gy, gx, gz = torch.meshgrid(axes[0], axes[1], axes[2], indexing="ij")
+            grid = torch.stack([gz, gx, gy], -1)[None]
+        else:
+            gy, gx = torch.meshgrid(axes[0], axes[1], indexing="ij")
+            grid = torch.stack([gx, gy], -1)[None]
+        src = img[int(box_ind[n])][None]
+        out.append(F.grid_sample(src, grid, mode="bilinear", padding_mode="border", align_corners=False)[0])
+    return torch.stack(out).numpy()
+
+
+@pytest.mark.parametrize("crop", [(7, 7, 3), (14, 14, 5), (4, 3, 2)])
+def test_oracle_roialign3d_matches_grid_sample(crop):
+    rng = np.random.default_rng(0)
+    image = rng.normal(size=(2, 3, 12, 10, 16)).astype(np.float32)
+    boxes = random_boxes_3d(rng, 9, patch=32.0, xy=(4, 24), z=(4, 24), spill=True)
+    box_ind = rng.integers(0, 2, size=9).astype(np.int32)
+    got = oracle.crop_and_resize_forward(image, boxes, box_ind, crop)
+    want = _grid_sample_crops(image, boxes, box_ind, crop)
+    assert np.abs(got - want).max() < 2e-5
+
+
+def test_oracle_roialign2d_matches_grid_sample():
+    rng = np.random.default_rng(1)
+    image = rng.normal(size=(2, 4, 20, 24)).astype(np.float32)
+    boxes = random_boxes_2d(rng, 11, patch=32.0, size=(4, 28), spill=True)
+    box_ind = rng.integers(0, 2, size=11).astype(np.int32)
+    got = oracle.crop_and_resize_forward(image, boxes, box_ind, (7, 7))
+    want = _grid_sample_crops(image, boxes, box_ind, (7, 7))
+    assert np.abs(got - want).max() < 2e-5
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_oracle_roialign_backward_is_adjoint_of_forward(dim):
+    """<crop(image), g> == <image, crop_bwd(g)> : the backward is the transpose of the (linear) forward."""
+    rng = np.random.default_rng(2)
+    if dim == 3:
+        shape, crop = (2, 2, 8, 9, 12), (5, 4, 3)
+        boxes = random_boxes_3d(rng, 6, patch=16.0, xy=(2, 14), z=(2, 14), spill=True)
+    else:
+        shape, crop = (2, 2, 10, 13), (5, 6)
+        boxes = random_boxes_2d(rng, 6, patch=16.0, size=(2, 14), spill=True)
+    image = rng.normal(size=shape).astype(np.float32)
+    box_ind = rng.integers(0, 2, size=6).astype(np.int32)
+    crops = oracle.crop_and_resize_forward(image, boxes, box_ind, crop)
+    g = rng.normal(size=crops.shape).astype(np.float32)
+    gi = oracle.crop_and_resize_backward(g, boxes, box_ind, shape)
+    lhs = float((crops.astype(np.float64) * g).sum())
+    rhs = float((image.astype(np.float64) * gi).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_oracle_roialign_edge_cases():
+    rng = np.random.default_rng(3)
+    image = rng.normal(size=(2, 2, 6, 6, 8)).astype(np.float32)
+    boxes = np.array([[0.2, 0.2, 0.8, 0.8, 0.1, 0.9],     # ok
+                      [0.2, 0.2, 0.8, 0.8, 0.1, 0.9],     # box_ind out of range -> zeros
+                      [0.5, 0.5, 0.5, 0.5, 0.5, 0.5],     # degenerate
+                      [-0.5, -0.5, 1.5, 1.5, -1, 2]], np.float32)  # spills: clamped
+    box_ind = np.array([0, 7, 1, -1], np.int32)
+    c = oracle.crop_and_resize_forward(image, boxes, box_ind, (3, 3, 2))
+    assert np.all(c[1] == 0) and np.all(c[3] == 0)
+    # degenerate box samples one point: every bin equal
+    assert np.allclose(c[2], c[2][:, :1, :1, :1])
+    # P == 1 rule: 0.5*(a1+a2)*L without the -0.5 (kernel.cu:66)
+    c1 = oracle.crop_and_resize_forward(image, boxes[:1], box_ind[:1], (1, 1, 1))
+    y, x, z = 0.5 * 6, 0.5 * 6, 0.5 * 8
+    assert np.allclose(c1[0, :, 0, 0, 0], image[0, :, int(y), int(x), int(z)])
+
+
+def _iou_ref(a, b, dim):
+    """numpy float32 statement of devIoU with the +1 convention."""
+    f = np.float32
+    ax = [(0, 2), (1, 3)] + ([(4, 5)] if dim == 3 else [])
+    inter, sa, sb = f(1), f(1), f(1)
+    for lo, hi in ax:
+        inter = f(inter * max(f(f(min(a[hi], b[hi]) - max(a[lo], b[lo])) + f(1)), f(0)))
+        sa = f(sa * f(f(a[hi] - a[lo]) + f(1)))
+        sb = f(sb * f(f(b[hi] - b[lo]) + f(1)))
+    return f(inter / f(f(sa + sb) - inter))
+
+
+def _greedy_py(dets, thresh, dim, strict):
+    order = oracle.sort_order(dets[:, -1])
+    keep, supp = [], np.zeros(len(dets), bool)
+    for ii, i in enumerate(order):
+        if supp[i]:
+            continue
+        keep.append(i)
+        for j in order[ii + 1:]:
+            v = _iou_ref(dets[i], dets[j], dim)
+            if (v > thresh) if strict else (v >= thresh):
+                supp[j] = True
+    return np.array(keep, dtype=np.int64)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("thresh", [0.7, 0.3, 1e-5])
+def test_oracle_nms_matches_pure_python(dim, thresh):
+    rng = np.random.default_rng(4)
+    dets = nms_boxes(rng, 150, dim=dim, patch=64.0)
+    assert np.array_equal(oracle.gpu_nms(dets, thresh, True), _greedy_py(dets, np.float32(thresh), dim, True))
+    assert np.array_equal(oracle.cpu_nms(dets, thresh), _greedy_py(dets, np.float32(thresh), dim, False))
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 300, 2000])
+def test_oracle_cpu_nms_equals_reference_nms_c(dim, n):
+    """oracle/_ref/libref_nms*.so is the reference's own nms.c (compiled by oracle/Makefile)."""
+    name = "libref_nms3d.so" if dim == 3 else "libref_nms2d.so"
+    if not oracle.ref_available(name):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(n)
+    dets = nms_boxes(rng, n, dim=dim)
+    for thresh in (0.7, 0.1, 1e-5):
+        assert np.array_equal(oracle.cpu_nms(dets, thresh), oracle.ref_cpu_nms(dets, thresh))
+
+
+def test_gpu_rule_vs_cpu_rule_differ_only_at_equality():
+    """GPU: IoU > t, CPU: IoU >= t.  Two identical boxes have IoU == 1."""
+    dets = np.array([[0, 0, 9, 9, 0, 9, 0.9], [0, 0, 9, 9, 0, 9, 0.8]], np.float32)
+    assert len(oracle.gpu_nms(dets, 1.0, True)) == 2
+    assert len(oracle.cpu_nms(dets, 1.0)) == 1
+    assert len(oracle.gpu_nms(dets, 1.0, False)) == 1
+
+
+def test_oracle_nms_empty():
+    assert oracle.gpu_nms(np.zeros((0, 7), np.float32), 0.5).shape == (0,)

@@ -1,0 +1,118 @@
+"""Per-kernel timing on the GPU box (SURVEY.md 8(d) micro-benchmarks).  Prints one JSON line per case.
+Usage: python tools/microbench.py [--iters 50]"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from medicaldetectiontoolkit_amd import _lib  # noqa: E402
+from medicaldetectiontoolkit_amd.cuda_functions import _nms_impl, _roi_align_impl  # noqa: E402
+from tests.helpers import nms_boxes, random_boxes_3d  # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def timeit(fn, iters, warmup=10):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)  # us
+    return t[len(t) // 2], t[0], sum(t) / len(t)
+
+
+def report(name, us, bytes_=None, **kw):
+    rec = {"case": name, "median_us": round(us[0], 2), "min_us": round(us[1], 2), "mean_us": round(us[2], 2)}
+    if bytes_:
+        rec["alg_MB"] = round(bytes_ / 1e6, 2)
+        rec["GBps"] = round(bytes_ / us[0] / 1e3, 1)
+        rec["frac_of_8TBps"] = round(bytes_ / (us[0] * 1e-6) / HBM_PEAK, 4)
+    rec.update(kw)
+    print(json.dumps(rec), flush=True)
+
+
+def ref_lib(name):
+    p = os.path.join(ROOT, "oracle", "_ref", name)
+    return ctypes.CDLL(p) if os.path.exists(p) else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    vp = ctypes.c_void_p
+    levels = {"P2": (32, 32, 128), "P3": (16, 16, 64), "P4": (8, 8, 32), "P5": (4, 4, 16)}
+    B, C = 8, 36
+    refra = ref_lib("libref_gpu_roialign3d.so")
+
+    for lvl, (Y, X, Z) in levels.items():
+        for N, crop in ((48, (14, 14, 5)), (48, (7, 7, 3)), (600, (7, 7, 3)), (240, (14, 14, 5)), (4096, (7, 7, 3))):
+            if lvl != "P2" and N > 48:
+                continue
+            shape = (B, C, Y, X, Z)
+            boxes = torch.from_numpy(random_boxes_3d(rng, N)).to(dev)
+            box_ind = torch.from_numpy(rng.integers(0, B, size=N).astype(np.int32)).to(dev)
+            image = torch.randn(shape, device=dev)
+            P = crop[0] * crop[1] * crop[2]
+            g = torch.randn((N, C) + crop, device=dev)
+            V = Y * X * Z
+            bwd_bytes = 4 * N * C * P + 4 * B * C * V + 28 * N
+            fwd_bytes = 4 * N * C * P + 28 * N  # + touched input voxels (reported separately)
+            tag = "%s_N%d_%s" % (lvl, N, "x".join(map(str, crop)))
+            report("roialign3d_bwd_gather_" + tag,
+                   timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape), args.iters), bwd_bytes)
+            report("roialign3d_bwd_atomic_" + tag,
+                   timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, atomic=True), args.iters), bwd_bytes)
+            report("roialign3d_fwd_" + tag,
+                   timeit(lambda: _roi_align_impl.crop_forward(image, boxes, box_ind, crop), args.iters), fwd_bytes)
+            if refra is not None:
+                out = torch.empty(shape, device=dev)
+
+                def ref_bwd():
+                    # the reference zero-fills twice (crop_and_resize.py:40, crop_and_resize_gpu.c:61)
+                    out.zero_()
+                    out.zero_()
+                    refra.CropAndResizeBackpropImageLaucher(
+                        vp(g.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X, Z,
+                        crop[0], crop[1], crop[2], C, vp(out.data_ptr()), vp(torch.cuda.current_stream().cuda_stream))
+                report("REF_cuda_kernel_roialign3d_bwd_" + tag, timeit(ref_bwd, args.iters), bwd_bytes)
+                crops = torch.empty((N, C) + crop, device=dev)
+
+                def ref_fwd():
+                    crops.zero_()
+                    refra.CropAndResizeLaucher(
+                        vp(image.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X, Z,
+                        crop[0], crop[1], crop[2], C, ctypes.c_float(0), vp(crops.data_ptr()),
+                        vp(torch.cuda.current_stream().cuda_stream))
+                report("REF_cuda_kernel_roialign3d_fwd_" + tag, timeit(ref_fwd, args.iters), fwd_bytes)
+
+    # fill-only ceiling for the P2 gradient map (what a perfect bwd could reach)
+    out = torch.empty((B, C, 32, 32, 128), device=dev)
+    report("torch_zero_fill_151MB", timeit(lambda: out.zero_(), args.iters), out.numel() * 4)
+
+    # NMS
+    for n, thresh in ((300, 1e-5), (6000, 0.7), (50000, 1e-5)):
+        dets = nms_boxes(rng, n)
+        ds = torch.from_numpy(dets[np.argsort(-dets[:, -1].astype(np.float64), kind="stable")]).to(dev)
+        cb = (n + 63) // 64
+        nb = 28 * n + 8 * n * cb + 8 * n
+        report("nms3d_full_N%d_t%g" % (n, thresh), timeit(lambda: _nms_impl.nms_sorted(ds, thresh, 3), args.iters), nb)
+        report("nms3d_keep75_N%d_t%g" % (n, thresh),
+               timeit(lambda: _nms_impl.nms_sorted(ds, thresh, 3, max_keep=75), args.iters), nb)
+
+
+if __name__ == "__main__":
+    main()
