@@ -64,20 +64,38 @@ int mdt_crop_and_resize_3d_forward(
  * Replaces CropAndResizeBackpropImageLaucher (3D)
  *   crop_and_resize_kernel.h:14-18 (kernel: crop_and_resize_kernel.cu:154-304)
  *   together with BOTH zero-fills of grads_image (crop_and_resize.py:40 and
- *   crop_and_resize_gpu.c:61): grads_image is written exactly once, in gather
- *   form, without atomics; the result is run-to-run deterministic and equals
- *   the sequential (out_idx-ordered) fp32 accumulation bit for bit.
+ *   crop_and_resize_gpu.c:61): grads_image is written exactly once, without atomics.
  * grads [num_boxes, depth, ch, cw, cd]; grads_image [batch, depth, H, W, D].
- * No workspace is needed.
+ *
+ * Default form (separable, two kernels): phase A pushes each (RoI, channel) gradient block
+ * through the three per-axis interpolation matrices in LDS and writes a compact block
+ * (<= 8*ch*cw*cd floats) to `workspace`; phase B streams grads_image out tile by tile, adding
+ * one value per overlapping RoI.  Deterministic run to run; sums are reassociated relative to
+ * the reference's flat 8-corner scatter, so values agree to fp32 rounding (bar: 1e-4).
+ * workspace: mdt_crop_and_resize_backward_workspace_bytes(3, num_boxes, depth, H, W, D, ch, cw, cd),
+ * 16-byte aligned (per-RoI headers + index tables + the compact blocks);
+ * pool extents too large for the LDS budget fall back to the _ordered kernel.
  */
+size_t mdt_crop_and_resize_backward_workspace_bytes(int dim, int num_boxes, int depth,
+                                                   int image_height, int image_width, int image_zdepth,
+                                                   int crop_height, int crop_width, int crop_zdepth);
 int mdt_crop_and_resize_3d_backward(
+    const float *grads, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
+    int crop_height, int crop_width, int crop_zdepth, int depth,
+    float *grads_image, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Exact-order form: gather kernel that adds, per voxel, the terms in exactly the order a
+ * sequential out_idx loop would (corner order of crop_and_resize_kernel.cu:256-301), so the
+ * result equals the fp32 CPU oracle bit for bit.  Any shape, no workspace, slower. */
+int mdt_crop_and_resize_3d_backward_ordered(
     const float *grads, const float *boxes, const int *box_ind,
     int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
     int crop_height, int crop_width, int crop_zdepth, int depth,
     float *grads_image, void *stream);
 
-/* A/B variant of the above: vectorised zero-fill kernel followed by an fp32
- * global-atomic scatter (the reference's algorithm, order-nondeterministic). */
+/* A/B variant: vectorised zero-fill kernel followed by an fp32 global-atomic scatter
+ * (the reference's algorithm, order-nondeterministic). */
 int mdt_crop_and_resize_3d_backward_atomic(
     const float *grads, const float *boxes, const int *box_ind,
     int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
@@ -94,6 +112,12 @@ int mdt_crop_and_resize_2d_forward(
     float extrapolation_value, float *crops, void *stream);
 
 int mdt_crop_and_resize_2d_backward(
+    const float *grads, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width,
+    int crop_height, int crop_width, int depth,
+    float *grads_image, void *workspace, size_t workspace_bytes, void *stream);
+
+int mdt_crop_and_resize_2d_backward_ordered(
     const float *grads, const float *boxes, const int *box_ind,
     int num_boxes, int batch, int image_height, int image_width,
     int crop_height, int crop_width, int depth,

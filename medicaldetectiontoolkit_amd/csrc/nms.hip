@@ -66,7 +66,7 @@ constexpr int MASK_WAVES = 4;
 // grid: (ceil(col_blocks / MASK_WAVES), col_blocks, batch); block: 64 * MASK_WAVES
 template <int STRIDE>
 __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
-    const float *__restrict__ dets, int n, float thresh, int rule, int fill_lower,
+    const float *__restrict__ dets, int n, float thresh, int rule, int fill_lower, int block_major,
     u64 *__restrict__ mask)
 {
     const int lane = threadIdx.x & 63;
@@ -76,7 +76,9 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
     const int row_start = blockIdx.y;
     if (col_start >= col_blocks) return;
     dets += (long long)blockIdx.z * n * STRIDE;
-    mask += (long long)blockIdx.z * n * col_blocks;
+    // block_major (internal workspace): word of row 64*R + l for column block Cb sits at
+    // ((R * col_blocks + Cb) * 64 + l): a wave reads/writes 512 contiguous bytes.
+    mask += (long long)blockIdx.z * (block_major ? (long long)col_blocks * col_blocks * 64 : (long long)n * col_blocks);
 
     const int row_idx = row_start * 64 + lane;
     if (row_start > col_start) {
@@ -104,10 +106,13 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
         const u64 bal = __ballot(pred);
         if (lane == i) word = bal;
     }
-    if (row_idx < n) mask[(long long)row_idx * col_blocks + col_start] = word;
+    if (block_major) mask[((long long)row_start * col_blocks + col_start) * 64 + lane] = (row_idx < n) ? word : 0ULL;
+    else if (row_idx < n) mask[(long long)row_idx * col_blocks + col_start] = word;
 }
 
 constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_WAVES = SCAN_THREADS / 64;
+constexpr int SCAN_PF = 6;   // column words prefetched per lane before the resolve (covers n <= 6208 in one round)
 
 __device__ __forceinline__ u64 bcast64(u64 v, int src_lane)
 {
@@ -116,7 +121,7 @@ __device__ __forceinline__ u64 bcast64(u64 v, int src_lane)
     return ((u64)hi << 32) | (u64)lo;
 }
 
-// grid: batch; block: SCAN_THREADS; dynamic LDS: col_blocks * 8 bytes
+// grid: batch; block: SCAN_THREADS; dynamic LDS: col_blocks * 8 bytes.  mask is block-major.
 __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
     const u64 *__restrict__ mask, int n, int max_keep,
     long long *__restrict__ keep, int keep_stride, int *__restrict__ num_out)
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int col_blocks = (n + 63) / 64;
-    mask += (long long)blockIdx.x * n * col_blocks;
+    mask += (long long)blockIdx.x * col_blocks * col_blocks * 64;
     keep += (long long)blockIdx.x * keep_stride;
     const int limit = (max_keep > 0) ? min(max_keep, keep_stride) : keep_stride;
 
@@ -143,11 +148,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
         const int rows_here = min(n - k * 64, 64);
         const u64 valid = (rows_here == 64) ? ~0ULL : ((1ULL << rows_here) - 1ULL);
         u64 r = remv[k];
-        if ((~r & valid) == 0ULL) continue;  // whole block already removed (uniform: remv is LDS-coherent after the barrier)
+        if ((~r & valid) == 0ULL) continue;  // block already fully removed (uniform: LDS value after a barrier)
+
+        // every wave prefetches "its" later column words of this row block; they do not depend on
+        // which rows end up kept, so the loads fly while wave 0 resolves the block.
+        const u64 *rowblk = mask + (long long)k * col_blocks * 64;
+        u64 pre[SCAN_PF];
+#pragma unroll
+        for (int q = 0; q < SCAN_PF; ++q) {
+            const int j = k + 1 + wave + SCAN_WAVES * q;
+            pre[q] = (j < col_blocks) ? rowblk[(long long)j * 64 + lane] : 0ULL;
+        }
 
         if (wave == 0) {
-            const int row = k * 64 + lane;
-            const u64 d = (row < n) ? mask[(long long)row * col_blocks + k] : 0ULL;
+            const u64 d = rowblk[(long long)k * 64 + lane];   // diagonal words (rows >= n hold 0)
             u64 kept = 0ULL;
             u64 cand = ~r & valid;
             while (cand) {
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
             }
             if ((kept >> lane) & 1ULL) {
                 const int pos = nkept + __popcll(kept & ((1ULL << lane) - 1ULL));
-                if (pos < limit) keep[pos] = (long long)row;
+                if (pos < limit) keep[pos] = (long long)(k * 64 + lane);
             }
             if (lane == 0) { s_kept = kept; s_nkept = nkept + __popcll(kept); }
         }
@@ -168,16 +182,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
         nkept = s_nkept;
         if (max_keep > 0 && nkept >= max_keep) break;
 
-        // OR the kept rows' words of the later column blocks into remv
-        for (int j = k + 1 + tid; j < col_blocks; j += SCAN_THREADS) {
-            u64 acc = 0ULL;
-            u64 bits = kept;
-            while (bits) {
-                const int i = __ffsll((long long)bits) - 1;
-                bits &= bits - 1ULL;
-                acc |= mask[(long long)(k * 64 + i) * col_blocks + j];
+        const bool mine = (kept >> lane) & 1ULL;
+#pragma unroll
+        for (int q = 0; q < SCAN_PF; ++q) {
+            const int j = k + 1 + wave + SCAN_WAVES * q;
+            if (mine && pre[q] != 0ULL) atomicOr(&remv[j], pre[q]);
+        }
+        // columns beyond the prefetch window (large n), 4 loads in flight per lane
+        for (int j0 = k + 1 + SCAN_WAVES * SCAN_PF + wave; j0 < col_blocks; j0 += 4 * SCAN_WAVES) {
+            u64 w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q * SCAN_WAVES;
+                w[q] = (mine && j < col_blocks) ? rowblk[(long long)j * 64 + lane] : 0ULL;
             }
-            remv[j] |= acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (w[q] != 0ULL) atomicOr(&remv[j0 + q * SCAN_WAVES], w[q]);
         }
         __syncthreads();
     }
@@ -193,14 +214,14 @@ inline int check_launch()
 }
 
 template <int STRIDE>
-int launch_mask(const float *dets, int batch, int n, float thresh, int rule, int fill_lower,
+int launch_mask(const float *dets, int batch, int n, float thresh, int rule, int fill_lower, int block_major,
                 u64 *mask, hipStream_t s)
 {
     const int col_blocks = (n + 63) / 64;
     if (col_blocks > 65535 || batch > 65535) return MDT_ERR_UNSUPPORTED;
     dim3 grid((col_blocks + MASK_WAVES - 1) / MASK_WAVES, col_blocks, batch);
     hipLaunchKernelGGL(nms_mask_kernel<STRIDE>, grid, dim3(64 * MASK_WAVES), 0, s,
-                       dets, n, thresh, rule, fill_lower, mask);
+                       dets, n, thresh, rule, fill_lower, block_major, mask);
     return check_launch();
 }
 
@@ -224,7 +245,7 @@ int nms_impl(const float *dets, int batch, int n, float thresh, int rule, int ma
     const size_t lds = (size_t)col_blocks * sizeof(u64);
     if (lds > 128 * 1024) return MDT_ERR_UNSUPPORTED;  // n <= 1,048,576
     u64 *mask = reinterpret_cast<u64 *>(ws);
-    int rc = launch_mask<STRIDE>(dets, batch, n, thresh, rule, 0, mask, s);
+    int rc = launch_mask<STRIDE>(dets, batch, n, thresh, rule, 0, 1, mask, s);
     if (rc != MDT_OK) return rc;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(nms_scan_kernel),
@@ -243,22 +264,22 @@ extern "C" {
 size_t mdt_nms_workspace_bytes(int n)
 {
     if (n <= 0) return 16;
-    const size_t col_blocks = ((size_t)n + 63) / 64;
-    return ((size_t)n * col_blocks * sizeof(u64) + 255) & ~(size_t)255;
+    const size_t col_blocks = ((size_t)n + 63) / 64;   // block-major mask: col_blocks^2 blocks of 64 words
+    return (col_blocks * col_blocks * 64 * sizeof(u64) + 255) & ~(size_t)255;
 }
 
 int mdt_nms_mask_3d(const float *dets_sorted, int n, float thresh, int rule, unsigned long long *mask, void *stream)
 {
     if (n < 0) return MDT_ERR_INVALID_ARGUMENT;
     if (n == 0) return MDT_OK;
-    return launch_mask<7>(dets_sorted, 1, n, thresh, rule, 1, mask, (hipStream_t)stream);
+    return launch_mask<7>(dets_sorted, 1, n, thresh, rule, 1, 0, mask, (hipStream_t)stream);
 }
 
 int mdt_nms_mask_2d(const float *dets_sorted, int n, float thresh, int rule, unsigned long long *mask, void *stream)
 {
     if (n < 0) return MDT_ERR_INVALID_ARGUMENT;
     if (n == 0) return MDT_OK;
-    return launch_mask<5>(dets_sorted, 1, n, thresh, rule, 1, mask, (hipStream_t)stream);
+    return launch_mask<5>(dets_sorted, 1, n, thresh, rule, 1, 0, mask, (hipStream_t)stream);
 }
 
 int mdt_nms_3d(const float *dets_sorted, int n, float thresh, int rule, int max_keep,

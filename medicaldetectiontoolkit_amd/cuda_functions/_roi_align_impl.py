@@ -55,8 +55,12 @@ def crop_forward(image, boxes, box_ind, crop, extrapolation_value=0.0):
     return crops
 
 
-def crop_backward(grads, boxes, box_ind, im_size, atomic=False):
-    """grads [N, C, *crop] -> grad_image of shape im_size; fully written by the kernel."""
+def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False):
+    """grads [N, C, *crop] -> grad_image of shape im_size; fully written by the kernel(s).
+    mode: "fast" (default, separable two-phase), "ordered" (bit-exact vs the sequential oracle),
+    "atomic" (reference algorithm, A/B only)."""
+    if atomic:
+        mode = "atomic"
     dim = len(im_size) - 2
     L = _lib.lib()
     grads = grads.contiguous()
@@ -66,17 +70,26 @@ def crop_backward(grads, boxes, box_ind, im_size, atomic=False):
     grad_image = torch.empty(tuple(im_size), dtype=torch.float32, device=grads.device)
     if grad_image.numel() == 0:
         return grad_image
+    crop = tuple(grads.shape[2:])
     with torch.cuda.device(grads.device):
         s = _lib.current_stream_ptr()
-        if dim == 3:
-            fn = L.mdt_crop_and_resize_3d_backward_atomic if atomic else L.mdt_crop_and_resize_3d_backward
-            rc = fn(_lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(box_ind), n, im_size[0], im_size[2], im_size[3],
-                    im_size[4], grads.size(2), grads.size(3), grads.size(4), im_size[1], _lib.ptr(grad_image), s)
+        head = [_lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(box_ind), n, im_size[0]] + list(im_size[2:]) + \
+            list(crop) + [im_size[1], _lib.ptr(grad_image)]
+        if mode == "fast":
+            wsb = L.mdt_crop_and_resize_backward_workspace_bytes(
+                dim, n, im_size[1], im_size[2], im_size[3], im_size[4] if dim == 3 else 1,
+                crop[0], crop[1], crop[2] if dim == 3 else 1)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=grads.device)
+            fn = L.mdt_crop_and_resize_3d_backward if dim == 3 else L.mdt_crop_and_resize_2d_backward
+            rc = fn(*(head + [_lib.ptr(ws), wsb, s]))
+        elif mode == "ordered":
+            fn = L.mdt_crop_and_resize_3d_backward_ordered if dim == 3 else L.mdt_crop_and_resize_2d_backward_ordered
+            rc = fn(*(head + [s]))
+        elif mode == "atomic" and dim == 3:
+            rc = L.mdt_crop_and_resize_3d_backward_atomic(*(head + [s]))
         else:
-            rc = L.mdt_crop_and_resize_2d_backward(
-                _lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(box_ind), n, im_size[0], im_size[2], im_size[3],
-                grads.size(2), grads.size(3), im_size[1], _lib.ptr(grad_image), s)
-    _lib.check(rc, "mdt_crop_and_resize_%dd_backward" % dim)
+            raise ValueError("unknown backward mode %r for dim %d" % (mode, dim))
+    _lib.check(rc, "mdt_crop_and_resize_%dd_backward(%s)" % (dim, mode))
     return grad_image
 
 

@@ -72,13 +72,16 @@ def main():
             bwd_bytes = 4 * N * C * P + 4 * B * C * V + 28 * N
             fwd_bytes = 4 * N * C * P + 28 * N  # + touched input voxels (reported separately)
             tag = "%s_N%d_%s" % (lvl, N, "x".join(map(str, crop)))
-            report("roialign3d_bwd_gather_" + tag,
+            report("roialign3d_bwd_fast_" + tag,
                    timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape), args.iters), bwd_bytes)
-            report("roialign3d_bwd_atomic_" + tag,
-                   timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, atomic=True), args.iters), bwd_bytes)
+            report("roialign3d_bwd_ordered_" + tag,
+                   timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="ordered"), args.iters), bwd_bytes)
+            if N <= 48:
+                report("roialign3d_bwd_atomic_" + tag,
+                       timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="atomic"), args.iters), bwd_bytes)
             report("roialign3d_fwd_" + tag,
                    timeit(lambda: _roi_align_impl.crop_forward(image, boxes, box_ind, crop), args.iters), fwd_bytes)
-            if refra is not None:
+            if refra is not None and N <= 600:
                 out = torch.empty(shape, device=dev)
 
                 def ref_bwd():

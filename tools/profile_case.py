@@ -1,0 +1,36 @@
+"""One case in a loop, for rocprofv3 --kernel-trace --stats.  Usage: profile_case.py <case> [iters]
+cases: bwd_fast | bwd_ordered | fwd | nms6000 | nms6000_keep75"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from medicaldetectiontoolkit_amd.cuda_functions import _nms_impl, _roi_align_impl  # noqa: E402
+from tests.helpers import nms_boxes, random_boxes_3d  # noqa: E402
+
+case = sys.argv[1]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+N = int(os.environ.get("MDT_N", 48))
+crop = tuple(int(v) for v in os.environ.get("MDT_CROP", "14,14,5").split(","))
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+shape = (8, 36, 32, 32, 128)
+boxes = torch.from_numpy(random_boxes_3d(rng, N)).to(dev)
+box_ind = torch.from_numpy(rng.integers(0, 8, size=N).astype(np.int32)).to(dev)
+g = torch.randn((N, 36) + crop, device=dev)
+image = torch.randn(shape, device=dev)
+dets = nms_boxes(rng, 6000)
+ds = torch.from_numpy(dets[np.argsort(-dets[:, -1].astype(np.float64), kind="stable")]).to(dev)
+fns = {
+    "bwd_fast": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape),
+    "bwd_ordered": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="ordered"),
+    "fwd": lambda: _roi_align_impl.crop_forward(image, boxes, box_ind, crop),
+    "nms6000": lambda: _nms_impl.nms_sorted(ds, 0.7, 3),
+    "nms6000_keep75": lambda: _nms_impl.nms_sorted(ds, 0.7, 3, max_keep=75),
+}
+for _ in range(iters):
+    fns[case]()
+torch.cuda.synchronize()
