@@ -1,0 +1,279 @@
+"""Device-resident mirror of the detection-op half of the reference's utils/model_utils.py.
+
+Same names, argument meaning and return conventions; the numpy / many-tiny-torch-op bodies are
+replaced by the gfx950 kernels behind include/mdt_hip.h.  Tensors live on the GPU; functions that
+the reference runs on the host with numpy (anchors, matching) return DEVICE tensors here (use
+.cpu().numpy() for the reference's exact return type).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def _dev(device):
+    return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+# --------------------------------------------------------------------------- anchors
+def generate_anchors_level(dim, scales_xy, scales_z, ratios, shape, feature_stride_xy, feature_stride_z,
+                           anchor_stride, device=None):
+    """One pyramid level: generate_anchors (utils/model_utils.py:190-226) / generate_anchors_3D (:230-272).
+    Returns (float64 [n, 2*dim], float32 [n, 2*dim]) device tensors."""
+    L = _lib.lib()
+    device = _dev(device)
+    sxy = np.ascontiguousarray(scales_xy, dtype=np.float64)
+    sz = np.ascontiguousarray(scales_z if scales_z is not None else np.zeros_like(sxy), dtype=np.float64)
+    if dim == 3 and len(sz) != len(sxy):
+        raise ValueError("scales_xy and scales_z must have the same length (np.tile at :249 assumes it)")
+    rt = np.ascontiguousarray(ratios, dtype=np.float64)
+    shp = np.ascontiguousarray(shape, dtype=np.int32)
+    pos = 1
+    for s in shp[:dim]:
+        pos *= (int(s) + anchor_stride - 1) // anchor_stride
+    n = pos * len(sxy) * len(rt)
+    out = torch.empty((n, 2 * dim), dtype=torch.float64, device=device)
+    out32 = torch.empty((n, 2 * dim), dtype=torch.float32, device=device)
+    if n == 0:
+        return out, out32
+    with torch.cuda.device(device):
+        rc = L.mdt_generate_anchors(dim, sxy.ctypes.data, sz.ctypes.data, len(sxy), rt.ctypes.data, len(rt),
+                                    shp.ctypes.data, ctypes.c_double(float(feature_stride_xy)),
+                                    ctypes.c_double(float(feature_stride_z)), int(anchor_stride),
+                                    _lib.ptr(out), _lib.ptr(out32), _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_generate_anchors")
+    return out, out32
+
+
+def generate_pyramid_anchors(logger, cf, device=None, return_f32=False):
+    """generate_pyramid_anchors (utils/model_utils.py:275-314): levels concatenated in cf.pyramid_levels order."""
+    outs, outs32 = [], []
+    for level in cf.pyramid_levels:
+        shape = cf.backbone_shapes[level]
+        dim = len(shape)
+        a, a32 = generate_anchors_level(
+            dim, cf.rpn_anchor_scales["xy"][level], cf.rpn_anchor_scales["z"][level] if dim == 3 else None,
+            cf.rpn_anchor_ratios, shape, cf.backbone_strides["xy"][level],
+            cf.backbone_strides["z"][level] if dim == 3 else 1, cf.rpn_anchor_stride, device)
+        outs.append(a)
+        outs32.append(a32)
+        if logger is not None:
+            logger.info("level {}: built anchors {}".format(level, tuple(a.shape)))
+    anchors = torch.cat(outs, 0)
+    if return_f32:
+        return anchors, torch.cat(outs32, 0)
+    return anchors
+
+
+# --------------------------------------------------------------------------- anchor <-> GT matching
+def anchor_match_labels(anchors, gt_boxes, gt_class_ids, neg_thresh, pos_thresh):
+    """Steps 1-3 of gt_anchor_matching (utils/model_utils.py:505-563) on the device.
+    anchors [A, 2*dim] f64, gt_boxes [G, 2*dim] f64, gt_class_ids [G] i32 or None.
+    Returns matches [A] i32, iou_argmax [A] i32, iou_max [A] f64, gt_best_anchor [G] i32."""
+    L = _lib.lib()
+    dev = anchors.device
+    A, dim = anchors.size(0), anchors.size(1) // 2
+    anchors = anchors.contiguous()
+    G = 0 if gt_boxes is None else gt_boxes.size(0)
+    matches = torch.empty(A, dtype=torch.int32, device=dev)
+    argmax = torch.empty(A, dtype=torch.int32, device=dev)
+    iou_max = torch.empty(A, dtype=torch.float64, device=dev)
+    gt_best = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
+    wsb = L.mdt_anchor_match_workspace_bytes(A, max(G, 1))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    gtb = gt_boxes.to(device=dev, dtype=torch.float64).contiguous() if G else None
+    cls = gt_class_ids.to(device=dev, dtype=torch.int32).contiguous() if (G and gt_class_ids is not None) else None
+    with torch.cuda.device(dev):
+        rc = L.mdt_anchor_match(_lib.ptr(anchors), A, dim, _lib.ptr(gtb), _lib.ptr(cls), G,
+                                ctypes.c_double(neg_thresh), ctypes.c_double(pos_thresh),
+                                _lib.ptr(matches), _lib.ptr(argmax), _lib.ptr(iou_max), _lib.ptr(gt_best),
+                                _lib.ptr(ws), wsb, _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_anchor_match")
+    return matches, argmax, iou_max, gt_best[:G]
+
+
+def anchor_delta_targets(anchors, gt_boxes, std_dev):
+    """Delta targets of matched (anchor, gt) rows, utils/model_utils.py:575-617 (float64)."""
+    dim = anchors.size(1) // 2
+    a, g = anchors.double(), gt_boxes.double()
+    a_h, a_w = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+    g_h, g_w = g[:, 2] - g[:, 0], g[:, 3] - g[:, 1]
+    a_cy, a_cx = a[:, 0] + 0.5 * a_h, a[:, 1] + 0.5 * a_w
+    g_cy, g_cx = g[:, 0] + 0.5 * g_h, g[:, 1] + 0.5 * g_w
+    cols = [(g_cy - a_cy) / a_h, (g_cx - a_cx) / a_w]
+    if dim == 3:
+        a_d, g_d = a[:, 5] - a[:, 4], g[:, 5] - g[:, 4]
+        a_cz, g_cz = a[:, 4] + 0.5 * a_d, g[:, 4] + 0.5 * g_d
+        cols += [(g_cz - a_cz) / a_d, torch.log(g_h / a_h), torch.log(g_w / a_w), torch.log(g_d / a_d)]
+    else:
+        cols += [torch.log(g_h / a_h), torch.log(g_w / a_w)]
+    std = torch.as_tensor(np.asarray(std_dev, dtype=np.float64), device=a.device)
+    return torch.stack(cols, 1) / std
+
+
+def gt_anchor_matching(cf, anchors, gt_boxes, gt_class_ids=None, generator=None):
+    """gt_anchor_matching (utils/model_utils.py:505-619).  anchors: [A, 2*dim] f64 DEVICE tensor.
+    Returns (anchor_class_matches [A] int32 device, anchor_delta_targets [rpn_train_anchors_per_image, 2*dim]
+    float64 device).  The random subsampling of surplus positives (:566-571, np.random.choice in the
+    reference) uses torch's device RNG."""
+    dev = anchors.device
+    dim = anchors.size(1) // 2
+    n_t = cf.rpn_train_anchors_per_image
+    targets = torch.zeros((n_t, 2 * dim), dtype=torch.float64, device=dev)
+    if gt_boxes is None or len(gt_boxes) == 0:
+        return torch.full((anchors.size(0),), -1, dtype=torch.int32, device=dev), targets
+    gt_t = torch.as_tensor(np.asarray(gt_boxes, dtype=np.float64) if not torch.is_tensor(gt_boxes) else gt_boxes,
+                           dtype=torch.float64, device=dev)
+    cls_t = None
+    if gt_class_ids is not None:
+        cls_t = torch.as_tensor(np.asarray(gt_class_ids) if not torch.is_tensor(gt_class_ids) else gt_class_ids,
+                                device=dev).to(torch.int32)
+    neg = 0.1 if dim == 2 else 0.01
+    matches, argmax, _, _ = anchor_match_labels(anchors, gt_t, cls_t, neg, float(cf.anchor_matching_iou))
+    ids = torch.nonzero(matches > 0)[:, 0]
+    extra = ids.numel() - (n_t // 2)
+    if extra > 0:
+        perm = torch.randperm(ids.numel(), device=dev, generator=generator)[:extra]
+        matches[ids[perm]] = 0
+        ids = torch.nonzero(matches > 0)[:, 0]
+    k = min(ids.numel(), n_t)
+    if k > 0:
+        ids = ids[:k]
+        targets[:k] = anchor_delta_targets(anchors[ids], gt_t[argmax[ids].long()], cf.rpn_bbox_std_dev)
+    return matches, targets
+
+
+# --------------------------------------------------------------------------- box decode + clip
+def decode_clip_boxes(boxes, deltas, std_dev, window, order=None, scores=None):
+    """Fused apply_box_deltas_{2D,3D}(boxes[order], deltas[order] * std_dev) -> clip_boxes_{2D,3D}(., window)
+    (utils/model_utils.py:318-398 as chained in models/mrcnn.py:320-345).  With `scores` (already gathered,
+    one per output row) the result is [n, 2*dim+1], directly the input of nms_*."""
+    L = _lib.lib()
+    dev = boxes.device
+    dim = boxes.size(1) // 2
+    boxes = boxes.contiguous().float()
+    deltas = deltas.contiguous().float()
+    n = boxes.size(0) if order is None else order.numel()
+    stride = 2 * dim + (1 if scores is not None else 0)
+    out = torch.empty((n, stride), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    std = np.ascontiguousarray(std_dev, dtype=np.float32)
+    win = np.ascontiguousarray(window, dtype=np.float32)
+    order_c = order.contiguous().long() if order is not None else None
+    scores_c = scores.contiguous().float() if scores is not None else None
+    with torch.cuda.device(dev):
+        rc = L.mdt_decode_clip_boxes(_lib.ptr(boxes), _lib.ptr(deltas), _lib.ptr(order_c), _lib.ptr(scores_c), n, dim,
+                                     std.ctypes.data, win.ctypes.data, _lib.ptr(out), stride, _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_decode_clip_boxes")
+    return out
+
+
+def apply_box_deltas_3D(boxes, deltas):
+    """apply_box_deltas_3D (utils/model_utils.py:343-370) without clipping."""
+    big = [-3.0e38, -3.0e38, 3.0e38, 3.0e38, -3.0e38, 3.0e38]
+    return decode_clip_boxes(boxes, deltas, [1.0] * 6, big)
+
+
+def apply_box_deltas_2D(boxes, deltas):
+    big = [-3.0e38, -3.0e38, 3.0e38, 3.0e38]
+    return decode_clip_boxes(boxes, deltas, [1.0] * 4, big)
+
+
+def clip_boxes(boxes, window):
+    """clip_boxes_{2D,3D} / clip_to_window (utils/model_utils.py:374-398, 623-637)."""
+    dim = boxes.size(1) // 2
+    w = [float(v) for v in window]
+    lo = torch.tensor([w[0], w[1], w[0], w[1]] + ([w[4], w[4]] if dim == 3 else []), device=boxes.device)
+    hi = torch.tensor([w[2], w[3], w[2], w[3]] + ([w[5], w[5]] if dim == 3 else []), device=boxes.device)
+    return torch.min(torch.max(boxes, lo), hi)
+
+
+def bbox_overlaps(boxes1, boxes2):
+    """bbox_overlaps_{2D,3D} (utils/model_utils.py:429-501): IoU [n1, n2], no +1 convention, fp32,
+    same operation order, one broadcasted expression instead of repeat/tile."""
+    dim = boxes1.size(1) // 2
+    b1, b2 = boxes1[:, None, :], boxes2[None, :, :]
+    y1 = torch.max(b1[..., 0], b2[..., 0])
+    x1 = torch.max(b1[..., 1], b2[..., 1])
+    y2 = torch.min(b1[..., 2], b2[..., 2])
+    x2 = torch.min(b1[..., 3], b2[..., 3])
+    inter = torch.clamp(x2 - x1, min=0) * torch.clamp(y2 - y1, min=0)
+    a1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    a2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    if dim == 3:
+        z1 = torch.max(b1[..., 4], b2[..., 4])
+        z2 = torch.min(b1[..., 5], b2[..., 5])
+        inter = inter * torch.clamp(z2 - z1, min=0)
+        a1 = a1 * (b1[..., 5] - b1[..., 4])
+        a2 = a2 * (b2[..., 5] - b2[..., 4])
+    return inter / (a1 + a2 - inter)
+
+
+bbox_overlaps_2D = bbox_overlaps
+bbox_overlaps_3D = bbox_overlaps
+
+
+def box_refinement(box, gt_box):
+    """box_refinement (utils/model_utils.py:114-143)."""
+    height, width = box[:, 2] - box[:, 0], box[:, 3] - box[:, 1]
+    center_y, center_x = box[:, 0] + 0.5 * height, box[:, 1] + 0.5 * width
+    gt_height, gt_width = gt_box[:, 2] - gt_box[:, 0], gt_box[:, 3] - gt_box[:, 1]
+    gt_center_y, gt_center_x = gt_box[:, 0] + 0.5 * gt_height, gt_box[:, 1] + 0.5 * gt_width
+    dy, dx = (gt_center_y - center_y) / height, (gt_center_x - center_x) / width
+    dh, dw = torch.log(gt_height / height), torch.log(gt_width / width)
+    if box.shape[1] > 4:
+        depth = box[:, 5] - box[:, 4]
+        center_z = box[:, 4] + 0.5 * depth
+        gt_depth = gt_box[:, 5] - gt_box[:, 4]
+        gt_center_z = gt_box[:, 4] + 0.5 * gt_depth
+        dz = (gt_center_z - center_z) / depth
+        dd = torch.log(gt_depth / depth)
+        return torch.stack([dy, dx, dz, dh, dw, dd], dim=1)
+    return torch.stack([dy, dx, dh, dw], dim=1)
+
+
+def shem(roi_probs_neg, negative_count, ohem_poolsize, generator=None):
+    """Stochastic hard example mining (utils/model_utils.py:674-691), device-only (no .cpu() round trip)."""
+    probs, order = roi_probs_neg[:, 1:].max(1)[0].sort(descending=True)
+    select = min(ohem_poolsize * int(negative_count), order.size(0))
+    pool_indices = order[:select]
+    rand_idx = torch.randperm(pool_indices.size(0), device=pool_indices.device, generator=generator)
+    return pool_indices[rand_idx[:negative_count]]
+
+
+def log2(x):
+    """utils/model_utils.py:658-663: log(x) / log(2) in the tensor's dtype."""
+    return torch.log(x) / torch.log(torch.tensor(2.0, dtype=x.dtype, device=x.device))
+
+
+class NDConvGenerator(object):
+    """2D/3D conv (+norm) (+relu) factory with the reference's Sequential layout, so state_dict keys match
+    (utils/model_utils.py:732-781).  The convolutions themselves run on MIOpen through torch."""
+
+    def __init__(self, dim):
+        self.dim = dim
+
+    def __call__(self, c_in, c_out, ks, pad=0, stride=1, norm=None, relu="relu"):
+        import torch.nn as nn
+        Conv = nn.Conv2d if self.dim == 2 else nn.Conv3d
+        conv = Conv(c_in, c_out, kernel_size=ks, padding=pad, stride=stride)
+        if norm is not None:
+            if norm == "instance_norm":
+                norm_layer = (nn.InstanceNorm2d if self.dim == 2 else nn.InstanceNorm3d)(c_out)
+            elif norm == "batch_norm":
+                norm_layer = (nn.BatchNorm2d if self.dim == 2 else nn.BatchNorm3d)(c_out)
+            else:
+                raise ValueError("norm type as specified in configs is not implemented... {}".format(norm))
+            conv = nn.Sequential(conv, norm_layer)
+        if relu is not None:
+            if relu == "relu":
+                relu_layer = nn.ReLU(inplace=True)
+            elif relu == "leaky_relu":
+                relu_layer = nn.LeakyReLU(inplace=True)
+            else:
+                raise ValueError("relu type as specified in configs is not implemented...")
+            conv = nn.Sequential(conv, relu_layer)
+        return conv

@@ -41,3 +41,18 @@ def test_dropin_import_paths():
     from cuda_functions.roi_align_2D.roi_align.crop_and_resize import CropAndResizeFunction as c
     from cuda_functions.roi_align_3D.roi_align.crop_and_resize import CropAndResizeFunction as d
     assert c(7, 7, 0).crop == (7, 7) and d(7, 7, 3, 0).crop == (7, 7, 3)
+
+
+def test_patch_tiler_matches_reference_golden():
+    """get_patch_crop_coords vs the reference's own output (tests/golden/make_golden.py)."""
+    import numpy as np
+    from medicaldetectiontoolkit_amd.utils.dataloader_utils import get_patch_crop_coords
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_python.npz"))
+    keys = [k for k in g.files if k.startswith("patch_")]
+    assert len(keys) >= 5
+    for k in keys:
+        shape, ps = k[6:].split("_")
+        shape = tuple(int(v) for v in shape.split("x"))
+        ps = [int(v) for v in ps.split("x")]
+        assert np.array_equal(get_patch_crop_coords(np.zeros(shape, np.uint8), ps), g[k]), k
+    assert g["patch_512x512x256_128x128x128"].shape == (75, 6)      # BASELINE config 5 work list
