@@ -53,6 +53,9 @@ def lib():
             raise RuntimeError(
                 "libmdt_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C medicaldetectiontoolkit_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        # torch bundles its own libamdhip64; import it FIRST so this library binds to the same HIP runtime
+        # (loading ours first pulls in /opt/rocm's copy and kernels then fail with "no ROCm-capable device")
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)

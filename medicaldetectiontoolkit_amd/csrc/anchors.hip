@@ -12,6 +12,8 @@
 // over the anchors plus a tiny second-stage reduction.
 
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <math.h>
 #include "mdt_hip.h"
 
@@ -190,7 +192,13 @@ __global__ __launch_bounds__(256) void match_pass2_kernel(
     }
 }
 
-inline int check_launch() { return hipGetLastError() == hipSuccess ? MDT_OK : MDT_ERR_LAUNCH_FAILED; }
+inline int check_launch()
+{
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MDT_OK;
+    if (getenv("MDT_VERBOSE")) fprintf(stderr, "libmdt_hip: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
+    return MDT_ERR_LAUNCH_FAILED;
+}
 
 inline int match_blocks(int A)
 {
@@ -209,6 +217,7 @@ int mdt_generate_anchors(int dim, const double *scales_xy_host, const double *sc
                          double feature_stride_xy, double feature_stride_z, int anchor_stride,
                          double *out, float *out_f32, void *stream)
 {
+    (void)hipGetLastError();   // drop stale error state of earlier runtime calls on this thread
     if ((dim != 2 && dim != 3) || n_scales <= 0 || n_ratios <= 0 || anchor_stride <= 0 || !scales_xy_host ||
         !ratios_host || !shape_host || (dim == 3 && !scales_z_host))
         return MDT_ERR_INVALID_ARGUMENT;
@@ -254,6 +263,7 @@ int mdt_anchor_match(const double *anchors, int n_anchors, int dim,
                      int *matches, int *iou_argmax, double *iou_max, int *gt_best_anchor,
                      void *workspace, size_t workspace_bytes, void *stream)
 {
+    (void)hipGetLastError();   // drop stale error state of earlier runtime calls on this thread
     if (n_anchors < 0 || n_gt < 0 || (dim != 2 && dim != 3) || !matches || !iou_argmax)
         return MDT_ERR_INVALID_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
@@ -275,14 +285,12 @@ int mdt_anchor_match(const double *anchors, int n_anchors, int dim,
     double *iou_max_buf = iou_max ? iou_max : reinterpret_cast<double *>(ws + off);
     const size_t lds = ((size_t)n_gt * (2 * dim + 1) + MATCH_THREADS / 64) * sizeof(double) + (MATCH_THREADS / 64) * sizeof(int);
     if (lds > 60 * 1024) return MDT_ERR_UNSUPPORTED;
-    if (dim == 3)
-        hipLaunchKernelGGL(match_pass1_kernel<3>, dim3(nb), dim3(MATCH_THREADS), lds, s, anchors, n_anchors, gt_boxes,
+    if (dim == 3) hipLaunchKernelGGL(match_pass1_kernel<3>, dim3(nb), dim3(MATCH_THREADS), lds, s, anchors, n_anchors, gt_boxes,
                            gt_class_ids, n_gt, neg_thresh, pos_thresh, matches, iou_argmax, iou_max_buf, part_val, part_idx);
-    else
-        hipLaunchKernelGGL(match_pass1_kernel<2>, dim3(nb), dim3(MATCH_THREADS), lds, s, anchors, n_anchors, gt_boxes,
+    else hipLaunchKernelGGL(match_pass1_kernel<2>, dim3(nb), dim3(MATCH_THREADS), lds, s, anchors, n_anchors, gt_boxes,
                            gt_class_ids, n_gt, neg_thresh, pos_thresh, matches, iou_argmax, iou_max_buf, part_val, part_idx);
     if (check_launch() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
-    hipLaunchKernelGGL(match_pass2_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, nb, n_gt, gt_class_ids,
+    (void)hipGetLastError(); hipLaunchKernelGGL(match_pass2_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, nb, n_gt, gt_class_ids,
                        pos_thresh, iou_max_buf, matches, gt_best_anchor);
     return check_launch();
 }

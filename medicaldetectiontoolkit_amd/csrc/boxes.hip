@@ -83,6 +83,7 @@ extern "C" int mdt_decode_clip_boxes(const float *boxes, const float *deltas, co
                                      const float *std_dev_host, const float *window_host,
                                      float *out, int out_stride, void *stream)
 {
+    (void)hipGetLastError();   // drop stale error state of earlier runtime calls on this thread
     if (n < 0 || (dim != 2 && dim != 3) || out_stride < 2 * dim || !std_dev_host || !window_host)
         return MDT_ERR_INVALID_ARGUMENT;
     if (n == 0) return MDT_OK;
@@ -93,9 +94,7 @@ extern "C" int mdt_decode_clip_boxes(const float *boxes, const float *deltas, co
     }
     const int blocks = (n + 255) / 256;
     hipStream_t s = (hipStream_t)stream;
-    if (dim == 3)
-        hipLaunchKernelGGL(decode_clip_kernel<3>, dim3(blocks), dim3(256), 0, s, boxes, deltas, order, scores, n, prm, out, out_stride);
-    else
-        hipLaunchKernelGGL(decode_clip_kernel<2>, dim3(blocks), dim3(256), 0, s, boxes, deltas, order, scores, n, prm, out, out_stride);
+    if (dim == 3) hipLaunchKernelGGL(decode_clip_kernel<3>, dim3(blocks), dim3(256), 0, s, boxes, deltas, order, scores, n, prm, out, out_stride);
+    else hipLaunchKernelGGL(decode_clip_kernel<2>, dim3(blocks), dim3(256), 0, s, boxes, deltas, order, scores, n, prm, out, out_stride);
     return hipGetLastError() == hipSuccess ? MDT_OK : MDT_ERR_LAUNCH_FAILED;
 }

@@ -21,6 +21,8 @@
 // (the denominator Sa + Sb - interS would otherwise be contracted).
 
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "mdt_hip.h"
 
@@ -210,7 +212,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
 
 inline int check_launch()
 {
-    return hipGetLastError() == hipSuccess ? MDT_OK : MDT_ERR_LAUNCH_FAILED;
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MDT_OK;
+    if (getenv("MDT_VERBOSE")) fprintf(stderr, "libmdt_hip: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
+    return MDT_ERR_LAUNCH_FAILED;
 }
 
 template <int STRIDE>
@@ -220,7 +225,7 @@ int launch_mask(const float *dets, int batch, int n, float thresh, int rule, int
     const int col_blocks = (n + 63) / 64;
     if (col_blocks > 65535 || batch > 65535) return MDT_ERR_UNSUPPORTED;
     dim3 grid((col_blocks + MASK_WAVES - 1) / MASK_WAVES, col_blocks, batch);
-    hipLaunchKernelGGL(nms_mask_kernel<STRIDE>, grid, dim3(64 * MASK_WAVES), 0, s,
+    (void)hipGetLastError(); hipLaunchKernelGGL(nms_mask_kernel<STRIDE>, grid, dim3(64 * MASK_WAVES), 0, s,
                        dets, n, thresh, rule, fill_lower, block_major, mask);
     return check_launch();
 }
@@ -252,7 +257,7 @@ int nms_impl(const float *dets, int batch, int n, float thresh, int rule, int ma
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MDT_ERR_LAUNCH_FAILED;
     }
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), lds, s,
+    (void)hipGetLastError(); hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), lds, s,
                        mask, n, max_keep, keep, keep_stride, num_out);
     return check_launch();
 }

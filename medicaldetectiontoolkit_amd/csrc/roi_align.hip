@@ -25,6 +25,8 @@
 //   bwd: 4*B*C*V (grad_image written once) + 4*N*C*P (grads read once) + 28*N.
 
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "mdt_hip.h"
@@ -966,7 +968,10 @@ __global__ __launch_bounds__(256) void crop_bwd3d_atomic_kernel(
 
 inline int check_launch()
 {
-    return hipGetLastError() == hipSuccess ? MDT_OK : MDT_ERR_LAUNCH_FAILED;
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MDT_OK;
+    if (getenv("MDT_VERBOSE")) fprintf(stderr, "libmdt_hip: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
+    return MDT_ERR_LAUNCH_FAILED;
 }
 
 template <int DIM>
@@ -983,7 +988,7 @@ int launch_fwd(const float *image, const float *boxes, const int *box_ind, int N
     const long long slabs = (per_roi + FWD_SLAB - 1) / FWD_SLAB;
     if (slabs > 65535) return MDT_ERR_UNSUPPORTED;
     dim3 grid((unsigned)N, (unsigned)slabs);
-    hipLaunchKernelGGL(crop_fwd_kernel<DIM>, grid, dim3(FWD_THREADS), lds, s,
+    (void)hipGetLastError(); hipLaunchKernelGGL(crop_fwd_kernel<DIM>, grid, dim3(FWD_THREADS), lds, s,
                        image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, crops);
     return check_launch();
 }
@@ -992,6 +997,7 @@ template <int DIM>
 int launch_bwd(const float *grads, const float *boxes, const int *box_ind, int N, int B,
                int H, int W, int D, int ph, int pw, int pd, int C, float *out, hipStream_t s)
 {
+    (void)hipGetLastError();   // drop stale error state of earlier runtime calls on this thread
     if (N < 0 || B <= 0 || H <= 0 || W <= 0 || D <= 0 || ph <= 0 || pw <= 0 || pd <= 0 || C <= 0)
         return MDT_ERR_INVALID_ARGUMENT;
     const long long vol = (long long)H * W * D;
@@ -1024,10 +1030,8 @@ int launch_bwd(const float *grads, const float *boxes, const int *box_ind, int N
     p.tb = tb;
     long long grid = p.tiles_total < 2048 ? p.tiles_total : 2048;
     if (grid <= 0) return MDT_OK;
-    if (vec == 4)
-        hipLaunchKernelGGL((crop_bwd_gather_kernel<DIM, 4>), dim3((unsigned)grid), dim3(BWD_THREADS), lds, s, p);
-    else
-        hipLaunchKernelGGL((crop_bwd_gather_kernel<DIM, 1>), dim3((unsigned)grid), dim3(BWD_THREADS), lds, s, p);
+    if (vec == 4) hipLaunchKernelGGL((crop_bwd_gather_kernel<DIM, 4>), dim3((unsigned)grid), dim3(BWD_THREADS), lds, s, p);
+    else hipLaunchKernelGGL((crop_bwd_gather_kernel<DIM, 1>), dim3((unsigned)grid), dim3(BWD_THREADS), lds, s, p);
     return check_launch();
 }
 
@@ -1118,12 +1122,12 @@ int launch_bwd_fast(const float *grads, const float *boxes, const int *box_ind, 
     long long n_zero = (n_total / 4 + EXP_THREADS - 1) / EXP_THREADS;
     if (n_zero > 4096) n_zero = 4096;
     if (n_zero < 1) n_zero = 1;
-    hipLaunchKernelGGL(crop_bwd_expand_zero_kernel<DIM>, dim3((unsigned)(n_expand + n_zero)), dim3(EXP_THREADS), ldsA, s,
+    (void)hipGetLastError(); hipLaunchKernelGGL(crop_bwd_expand_zero_kernel<DIM>, dim3((unsigned)(n_expand + n_zero)), dim3(EXP_THREADS), ldsA, s,
                        p, n_expand, gy, n_vec4, tail_begin, n_total);
     if (check_launch() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
     if (N == 0) return MDT_OK;
     // kernel 2: patch the touched voxels, one workgroup per (RoI, channel group)
-    hipLaunchKernelGGL(crop_bwd_patch_kernel<DIM>, dim3((unsigned)n_expand), dim3(PATCH_THREADS), ldsB, s, p, gy);
+    (void)hipGetLastError(); hipLaunchKernelGGL(crop_bwd_patch_kernel<DIM>, dim3((unsigned)n_expand), dim3(PATCH_THREADS), ldsB, s, p, gy);
     return check_launch();
 }
 
@@ -1223,14 +1227,14 @@ int mdt_crop_and_resize_3d_backward_atomic(const float *grads, const float *boxe
         long long blocks = (n4 + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+        (void)hipGetLastError(); hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            reinterpret_cast<v4f *>(grads_image), n4, grads_image + n4 * 4, ntail);
     }
     const long long total = (long long)num_boxes * depth * ch * cw * cd;
     if (total > 0) {
         long long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(crop_bwd3d_atomic_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+        (void)hipGetLastError(); hipLaunchKernelGGL(crop_bwd3d_atomic_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            grads, boxes, box_ind, total, batch, H, W, D, ch, cw, cd, depth, grads_image);
     }
     return check_launch();

@@ -168,6 +168,7 @@ int mdt_weighted_box_clustering(const double *dets_sorted, const int *patch_ids,
                                 double *out_scores, double *out_coords, int *num_out,
                                 void *workspace, size_t workspace_bytes, void *stream)
 {
+    (void)hipGetLastError();   // drop stale error state of earlier runtime calls on this thread
     if (n < 0 || (dim != 2 && dim != 3) || n_patch_ids < 0 || !num_out) return MDT_ERR_INVALID_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
@@ -176,11 +177,9 @@ int mdt_weighted_box_clustering(const double *dets_sorted, const int *patch_ids,
     if (!workspace || workspace_bytes < mdt_wbc_workspace_bytes(n, n_patch_ids)) return MDT_ERR_WORKSPACE_TOO_SMALL;
     unsigned char *alive = reinterpret_cast<unsigned char *>(workspace);
     int *stamp = reinterpret_cast<int *>(alive + (((size_t)n + 15) & ~(size_t)15));
-    if (dim == 3)
-        hipLaunchKernelGGL(wbc_kernel<3>, dim3(1), dim3(WBC_THREADS), 0, s, dets_sorted, patch_ids, n, n_patch_ids,
+    if (dim == 3) hipLaunchKernelGGL(wbc_kernel<3>, dim3(1), dim3(WBC_THREADS), 0, s, dets_sorted, patch_ids, n, n_patch_ids,
                            thresh, n_ens, out_scores, out_coords, num_out, alive, stamp);
-    else
-        hipLaunchKernelGGL(wbc_kernel<2>, dim3(1), dim3(WBC_THREADS), 0, s, dets_sorted, patch_ids, n, n_patch_ids,
+    else hipLaunchKernelGGL(wbc_kernel<2>, dim3(1), dim3(WBC_THREADS), 0, s, dets_sorted, patch_ids, n, n_patch_ids,
                            thresh, n_ens, out_scores, out_coords, num_out, alive, stamp);
     return hipGetLastError() == hipSuccess ? MDT_OK : MDT_ERR_LAUNCH_FAILED;
 }

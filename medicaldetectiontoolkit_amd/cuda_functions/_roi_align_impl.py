@@ -13,6 +13,11 @@ from torch.autograd import Function
 from .. import _lib
 
 
+# bench.py hook: when PROFILE is a list, every backward call appends (start_event, end_event, meta); the events are
+# recorded on the stream the kernels are launched on (torch's current stream).  None = off (no overhead).
+PROFILE = None
+
+
 def _prep(image, boxes, box_ind, dim):
     _lib.require_cuda(image, "image")
     # quirk 6: mask targets arrive as a (n,1,Y,X,Z,1) view -- tolerate trailing singletons
@@ -71,6 +76,11 @@ def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False):
     if grad_image.numel() == 0:
         return grad_image
     crop = tuple(grads.shape[2:])
+    prof = PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_valid = ((box_ind >= 0) & (box_ind < im_size[0])).sum()      # device scalar, read after the timed region
+        ev0.record()
     with torch.cuda.device(grads.device):
         s = _lib.current_stream_ptr()
         head = [_lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(box_ind), n, im_size[0]] + list(im_size[2:]) + \
@@ -89,6 +99,9 @@ def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False):
             rc = L.mdt_crop_and_resize_3d_backward_atomic(*(head + [s]))
         else:
             raise ValueError("unknown backward mode %r for dim %d" % (mode, dim))
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, {"im_size": tuple(im_size), "crop": crop, "n_rows": n, "n_valid": n_valid, "mode": mode}))
     _lib.check(rc, "mdt_crop_and_resize_%dd_backward(%s)" % (dim, mode))
     return grad_image
 

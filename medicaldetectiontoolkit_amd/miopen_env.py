@@ -1,0 +1,20 @@
+"""The 3D conv backbone rides MIOpen (north star).  Its solver search ("find") for this model's odd channel
+counts takes ~2 minutes per fresh process, and without it the immediate-mode heuristics fall back to naive
+kernels (42x slower).  setup() points MIOpen's user find-db and compiled-kernel cache at a directory inside
+the repository so that the result of one search travels with the tree (e.g. onto a fresh GPU box)."""
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CACHE_DIR = os.path.join(HERE, "miopen_cache")
+
+
+def setup(cache_dir=None):
+    d = cache_dir or os.environ.get("MDT_MIOPEN_CACHE", CACHE_DIR)
+    try:
+        os.makedirs(os.path.join(d, "db"), exist_ok=True)
+        os.makedirs(os.path.join(d, "kernels"), exist_ok=True)
+    except OSError:
+        return None
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(d, "db"))
+    os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(d, "kernels"))
+    return d

@@ -1,0 +1,122 @@
+"""FPN / ResNet backbone, 2D and 3D.  Architecture and state_dict keys follow the reference's
+models/backbone.py (FPN :22-179, ResBlock :183-206, Interpolate :209-217) so its checkpoints load;
+the convolutions run on MIOpen through torch (the north star leaves the conv path on MIOpen).
+"""
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ResBlock(nn.Module):
+    def __init__(self, start_filts, planes, conv, stride=1, downsample=None, norm=None, relu="relu"):
+        super(ResBlock, self).__init__()
+        self.conv1 = conv(start_filts, planes, ks=1, stride=stride, norm=norm, relu=relu)
+        self.conv2 = conv(planes, planes, ks=3, pad=1, norm=norm, relu=relu)
+        self.conv3 = conv(planes, planes * 4, ks=1, norm=norm, relu=None)
+        self.relu = nn.ReLU(inplace=True) if relu == "relu" else nn.LeakyReLU(inplace=True)
+        if downsample is not None:
+            self.downsample = conv(downsample[0], downsample[0] * downsample[1], ks=1, stride=downsample[2], norm=norm, relu=None)
+        else:
+            self.downsample = None
+        self.stride = stride
+
+    def forward(self, x):
+        residual = x
+        out = self.conv3(self.conv2(self.conv1(x)))
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        out = out + residual
+        return self.relu(out)
+
+
+class Interpolate(nn.Module):
+    def __init__(self, scale_factor, mode):
+        super(Interpolate, self).__init__()
+        self.scale_factor = scale_factor
+        self.mode = mode
+
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=self.scale_factor, mode=self.mode, align_corners=False)
+
+
+class FPN(nn.Module):
+    def __init__(self, cf, conv, operate_stride1=False):
+        super(FPN, self).__init__()
+        sf = cf.start_filts
+        self.start_filts = sf
+        self.n_blocks = [3, 4, {"resnet50": 6, "resnet101": 23}[cf.res_architecture], 3]
+        self.block_expansion = 4
+        self.operate_stride1 = operate_stride1
+        self.sixth_pooling = cf.sixth_pooling
+        self.dim = conv.dim
+        s1 = (2, 2, 1) if conv.dim == 3 else 2
+        if operate_stride1:
+            self.C0 = nn.Sequential(conv(cf.n_channels, sf, ks=3, pad=1, norm=cf.norm, relu=cf.relu),
+                                    conv(sf, sf, ks=3, pad=1, norm=cf.norm, relu=cf.relu))
+            self.C1 = conv(sf, sf, ks=7, stride=s1, pad=3, norm=cf.norm, relu=cf.relu)
+        else:
+            self.C1 = conv(cf.n_channels, sf, ks=7, stride=s1, pad=3, norm=cf.norm, relu=cf.relu)
+        sfe = sf * self.block_expansion
+
+        def stage(c_in, planes, n, stride, first_ds):
+            layers = [ResBlock(c_in, planes, conv=conv, stride=stride, norm=cf.norm, relu=cf.relu, downsample=first_ds)]
+            for _ in range(1, n):
+                layers.append(ResBlock(planes * 4, planes, conv=conv, norm=cf.norm, relu=cf.relu))
+            return layers
+
+        pool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1) if conv.dim == 2 else \
+            nn.MaxPool3d(kernel_size=3, stride=(2, 2, 1), padding=1)
+        self.C2 = nn.Sequential(pool, *stage(sf, sf, self.n_blocks[0], 1, (sf, self.block_expansion, 1)))
+        self.C3 = nn.Sequential(*stage(sfe, sf * 2, self.n_blocks[1], 2, (sfe, 2, 2)))
+        self.C4 = nn.Sequential(*stage(sfe * 2, sf * 4, self.n_blocks[2], 2, (sfe * 2, 2, 2)))
+        self.C5 = nn.Sequential(*stage(sfe * 4, sf * 8, self.n_blocks[3], 2, (sfe * 4, 2, 2)))
+        if self.sixth_pooling:
+            self.C6 = nn.Sequential(*stage(sfe * 8, sf * 16, self.n_blocks[3], 2, (sfe * 8, 2, 2)))
+        if conv.dim == 2:
+            self.P1_upsample = Interpolate(scale_factor=2, mode="bilinear")
+            self.P2_upsample = Interpolate(scale_factor=2, mode="bilinear")
+        else:
+            self.P1_upsample = Interpolate(scale_factor=(2, 2, 1), mode="trilinear")
+            self.P2_upsample = Interpolate(scale_factor=(2, 2, 1), mode="trilinear")
+        oc = cf.end_filts
+        self.out_channels = oc
+        self.P5_conv1 = conv(sf * 32 + cf.n_latent_dims, oc, ks=1, stride=1, relu=None)
+        self.P4_conv1 = conv(sf * 16, oc, ks=1, stride=1, relu=None)
+        self.P3_conv1 = conv(sf * 8, oc, ks=1, stride=1, relu=None)
+        self.P2_conv1 = conv(sf * 4, oc, ks=1, stride=1, relu=None)
+        self.P1_conv1 = conv(sf, oc, ks=1, stride=1, relu=None)       # constructed unconditionally, like :112
+        if operate_stride1:
+            self.P0_conv1 = conv(sf, oc, ks=1, stride=1, relu=None)
+            self.P0_conv2 = conv(oc, oc, ks=3, stride=1, pad=1, relu=None)
+        self.P1_conv2 = conv(oc, oc, ks=3, stride=1, pad=1, relu=None)  # never used (:175 is commented out there)
+        self.P2_conv2 = conv(oc, oc, ks=3, stride=1, pad=1, relu=None)
+        self.P3_conv2 = conv(oc, oc, ks=3, stride=1, pad=1, relu=None)
+        self.P4_conv2 = conv(oc, oc, ks=3, stride=1, pad=1, relu=None)
+        self.P5_conv2 = conv(oc, oc, ks=3, stride=1, pad=1, relu=None)
+        if self.sixth_pooling:
+            self.P6_conv1 = conv(sf * 64, oc, ks=1, stride=1, relu=None)
+            self.P6_conv2 = conv(oc, oc, ks=3, stride=1, pad=1, relu=None)
+
+    def forward(self, x):
+        c0_out = self.C0(x) if self.operate_stride1 else x
+        c1_out = self.C1(c0_out)
+        c2_out = self.C2(c1_out)
+        c3_out = self.C3(c2_out)
+        c4_out = self.C4(c3_out)
+        c5_out = self.C5(c4_out)
+        if self.sixth_pooling:
+            c6_out = self.C6(c5_out)
+            p6_pre_out = self.P6_conv1(c6_out)
+            p5_pre_out = self.P5_conv1(c5_out) + F.interpolate(p6_pre_out, scale_factor=2)
+        else:
+            p5_pre_out = self.P5_conv1(c5_out)
+        p4_pre_out = self.P4_conv1(c4_out) + F.interpolate(p5_pre_out, scale_factor=2)
+        p3_pre_out = self.P3_conv1(c3_out) + F.interpolate(p4_pre_out, scale_factor=2)
+        p2_pre_out = self.P2_conv1(c2_out) + F.interpolate(p3_pre_out, scale_factor=2)
+        out_list = [self.P2_conv2(p2_pre_out), self.P3_conv2(p3_pre_out), self.P4_conv2(p4_pre_out), self.P5_conv2(p5_pre_out)]
+        if self.sixth_pooling:
+            out_list.append(self.P6_conv2(p6_pre_out))
+        if self.operate_stride1:
+            p1_pre_out = self.P1_conv1(c1_out) + self.P2_upsample(p2_pre_out)
+            p0_pre_out = self.P0_conv1(c0_out) + self.P1_upsample(p1_pre_out)
+            out_list = [self.P0_conv2(p0_pre_out)] + out_list
+        return out_list

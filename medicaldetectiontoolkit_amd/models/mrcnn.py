@@ -1,0 +1,604 @@
+"""Mask R-CNN (2D / 3D) on the gfx950 hot-path kernels.
+
+Mirror of the reference's models/mrcnn.py: same module names / state_dict keys (fpn, rpn, classifier,
+mask), same `net(cf, logger)` with train_forward / test_forward / forward returning the same
+results_dict.  What changed is the glue between the kernels:
+  * proposal_layer (mrcnn.py:297-369): top-k, fused decode+clip+score kernel, ONE batched
+    device-resident NMS over the batch with early stop at proposal_count; no D2H, no per-element sync.
+  * pyramid_roi_align (:373-457): level routing through box_ind (rows of other levels are written as
+    zeros by the kernel and summed away) -- no nonzero(), no gather/sort-back.
+  * detection_target_layer (:461-613), refine_detections (:620-714) and the RPN losses (:176-240) are
+    expressed on fixed-size, masked tensors (random keys + top-k for the random sub-sampling, SHEM via
+    sorted pools), so a training step has no host synchronisation before the final loss read-out.
+Random sub-sampling uses torch's device RNG instead of numpy / CPU randperm, so individual samples
+differ from the reference while the sampling distribution is the same.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from ..cuda_functions import _nms_impl
+from ..cuda_functions.roi_align_2D.roi_align.crop_and_resize import CropAndResizeFunction as ra2D
+from ..cuda_functions.roi_align_3D.roi_align.crop_and_resize import CropAndResizeFunction as ra3D
+from ..utils import model_utils as mutils
+from . import backbone as backbone_module
+
+
+############################################################
+# Networks on top of backbone (state_dict-compatible with the reference)
+############################################################
+class RPN(nn.Module):
+    """Region Proposal Network (mrcnn.py:40-86)."""
+
+    def __init__(self, cf, conv):
+        super(RPN, self).__init__()
+        self.dim = conv.dim
+        self.conv_shared = conv(cf.end_filts, cf.n_rpn_features, ks=3, stride=cf.rpn_anchor_stride, pad=1, relu=cf.relu)
+        self.conv_class = conv(cf.n_rpn_features, 2 * len(cf.rpn_anchor_ratios), ks=1, stride=1, relu=None)
+        self.conv_bbox = conv(cf.n_rpn_features, 2 * self.dim * len(cf.rpn_anchor_ratios), ks=1, stride=1, relu=None)
+
+    def forward(self, x):
+        x = self.conv_shared(x)
+        axes = (0, 2, 3, 1) if self.dim == 2 else (0, 2, 3, 4, 1)
+        rpn_class_logits = self.conv_class(x).permute(*axes).contiguous().view(x.size(0), -1, 2)
+        rpn_probs = F.softmax(rpn_class_logits, dim=2)
+        rpn_bbox = self.conv_bbox(x).permute(*axes).contiguous().view(x.size(0), -1, self.dim * 2)
+        return [rpn_class_logits, rpn_probs, rpn_bbox]
+
+
+class Classifier(nn.Module):
+    """Classification + box-refinement head (mrcnn.py:89-127)."""
+
+    def __init__(self, cf, conv):
+        super(Classifier, self).__init__()
+        self.dim = conv.dim
+        self.in_channels = cf.end_filts
+        self.pool_size = cf.pool_size
+        self.pyramid_levels = cf.pyramid_levels
+        norm = cf.norm if cf.norm != "instance_norm" else None
+        self.conv1 = conv(cf.end_filts, cf.end_filts * 4, ks=self.pool_size, stride=1, norm=norm, relu=cf.relu)
+        self.conv2 = conv(cf.end_filts * 4, cf.end_filts * 4, ks=1, stride=1, norm=norm, relu=cf.relu)
+        self.linear_class = nn.Linear(cf.end_filts * 4, cf.head_classes)
+        self.linear_bbox = nn.Linear(cf.end_filts * 4, cf.head_classes * 2 * self.dim)
+
+    def forward(self, x, rois):
+        x = pyramid_roi_align(x, rois, self.pool_size, self.pyramid_levels, self.dim)
+        x = self.conv2(self.conv1(x))
+        x = x.view(-1, self.in_channels * 4)
+        mrcnn_class_logits = self.linear_class(x)
+        mrcnn_bbox = self.linear_bbox(x)
+        return [mrcnn_class_logits, mrcnn_bbox.view(mrcnn_bbox.size(0), -1, self.dim * 2)]
+
+
+class Mask(nn.Module):
+    """Mask head (mrcnn.py:130-169)."""
+
+    def __init__(self, cf, conv):
+        super(Mask, self).__init__()
+        self.pool_size = cf.mask_pool_size
+        self.pyramid_levels = cf.pyramid_levels
+        self.dim = conv.dim
+        self.conv1 = conv(cf.end_filts, cf.end_filts, ks=3, stride=1, pad=1, norm=cf.norm, relu=cf.relu)
+        self.conv2 = conv(cf.end_filts, cf.end_filts, ks=3, stride=1, pad=1, norm=cf.norm, relu=cf.relu)
+        self.conv3 = conv(cf.end_filts, cf.end_filts, ks=3, stride=1, pad=1, norm=cf.norm, relu=cf.relu)
+        self.conv4 = conv(cf.end_filts, cf.end_filts, ks=3, stride=1, pad=1, norm=cf.norm, relu=cf.relu)
+        Deconv = nn.ConvTranspose2d if conv.dim == 2 else nn.ConvTranspose3d
+        self.deconv = Deconv(cf.end_filts, cf.end_filts, kernel_size=2, stride=2)
+        self.relu = nn.ReLU(inplace=True) if cf.relu == "relu" else nn.LeakyReLU(inplace=True)
+        self.conv5 = conv(cf.end_filts, cf.head_classes, ks=1, stride=1, relu=None)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x, rois):
+        x = pyramid_roi_align(x, rois, self.pool_size, self.pyramid_levels, self.dim)
+        x = self.conv4(self.conv3(self.conv2(self.conv1(x))))
+        x = self.relu(self.deconv(x))
+        return self.sigmoid(self.conv5(x))
+
+
+############################################################
+#  Helper layers
+############################################################
+def _masked_mean(values, mask):
+    """mean of `values` over entries where mask is True; 0 if none (mirrors the `0 not in ...size()` guards)."""
+    m = mask.to(values.dtype)
+    while m.dim() < values.dim():
+        m = m.unsqueeze(-1)
+    m = m.expand_as(values)
+    return (values * m).sum() / m.sum().clamp(min=1.0)
+
+
+def proposal_layer(rpn_pred_probs, rpn_pred_deltas, proposal_count, anchors, cf):
+    """mrcnn.py:297-369.  anchors: [A, 2*dim] fp32 device.  Returns
+    batch_normalized_boxes [B, proposal_count, 2*dim] and batch_out_proposals [B, proposal_count, 2*dim+1]
+    (pixel boxes + RPN fg score; zero rows pad missing proposals) -- both DEVICE tensors."""
+    L = _lib.lib()
+    B, A = rpn_pred_probs.shape[0], rpn_pred_probs.shape[1]
+    dim = rpn_pred_deltas.shape[-1] // 2
+    dev = rpn_pred_probs.device
+    pre_nms_limit = min(cf.pre_nms_limit, A)
+    # top pre_nms_limit anchors by fg score, best first (:328-333)
+    scores, order = torch.topk(rpn_pred_probs[:, :, 1].detach(), pre_nms_limit, dim=1, sorted=True)
+    deltas = rpn_pred_deltas.detach()
+    dets = torch.empty((B, pre_nms_limit, 2 * dim + 1), dtype=torch.float32, device=dev)
+    for b in range(B):   # fused gather + decode + clip + score append (:337-344); launches only, no sync
+        dets[b] = mutils.decode_clip_boxes(anchors, deltas[b], cf.rpn_bbox_std_dev, cf.window, order=order[b], scores=scores[b])
+    keep = torch.empty((B, proposal_count), dtype=torch.int64, device=dev)
+    num = torch.empty(B, dtype=torch.int32, device=dev)
+    wsb = B * L.mdt_nms_workspace_bytes(pre_nms_limit)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    fn = L.mdt_nms_3d_batched if dim == 3 else L.mdt_nms_2d_batched
+    import ctypes
+    with torch.cuda.device(dev):
+        rc = fn(_lib.ptr(dets), B, pre_nms_limit, ctypes.c_float(cf.rpn_nms_threshold), _lib.NMS_RULE_GT, proposal_count,
+                _lib.ptr(keep), proposal_count, _lib.ptr(num), _lib.ptr(ws), wsb, _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_nms_batched")
+    valid = keep >= 0                                            # rows beyond num_out are -1: zero-padded (:352-358)
+    gathered = torch.gather(dets, 1, keep.clamp(min=0).unsqueeze(-1).expand(-1, -1, 2 * dim + 1))
+    batch_out_proposals = gathered * valid.unsqueeze(-1).to(gathered.dtype)
+    norm = torch.as_tensor(np.asarray(cf.scale, dtype=np.float32), device=dev)
+    batch_normalized_boxes = batch_out_proposals[:, :, :2 * dim] / norm
+    return batch_normalized_boxes, batch_out_proposals
+
+
+def pyramid_roi_align(feature_maps, rois, pool_size, pyramid_levels, dim):
+    """mrcnn.py:373-457.  rois [n, 2*dim + 1] (normalised box, batch_ix; batch_ix < 0 marks a padding row).
+    Level rule :403 (h*w of the normalised box only).  Each level is pooled over ALL rois with
+    box_ind = batch_ix where the roi belongs to the level and -1 elsewhere: the kernel writes zero rows for
+    -1, so the per-level outputs simply add up -- no nonzero()/gather/sort-back and no host sync."""
+    boxes = rois[:, :dim * 2].detach()
+    batch_ixs = rois[:, dim * 2]
+    h = boxes[:, 2] - boxes[:, 0]
+    w = boxes[:, 3] - boxes[:, 1]
+    roi_level = (4 + mutils.log2(torch.sqrt(h * w))).round().int().clamp(pyramid_levels[0], pyramid_levels[-1])
+    if len(pyramid_levels) == 5:
+        roi_level = torch.where(h * w > 0.65, torch.full_like(roi_level, 5), roi_level)
+    ind_all = batch_ixs.to(torch.int32)
+    boxes = boxes.contiguous()
+    pooled = None
+    for level_ix, level in enumerate(pyramid_levels):
+        ind = torch.where(roi_level == level, ind_all, torch.full_like(ind_all, -1))
+        if len(pool_size) == 2:
+            p = ra2D(pool_size[0], pool_size[1], 0)(feature_maps[level_ix], boxes, ind)
+        else:
+            p = ra3D(pool_size[0], pool_size[1], pool_size[2], 0)(feature_maps[level_ix], boxes, ind)
+        pooled = p if pooled is None else pooled + p
+    return pooled
+
+
+def _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev):
+    """lists over batch elements -> padded device tensors [B, Gmax, ...] + validity mask + global gt index."""
+    B = len(batch_gt_boxes)
+    counts = [0 if (g is None or len(g) == 0 or not np.any(np.asarray(c) > 0)) else len(g)
+              for g, c in zip(batch_gt_boxes, batch_gt_class_ids)]
+    gmax = max(1, max(counts))
+    boxes = np.zeros((B, gmax, 2 * dim), dtype=np.float32)
+    cls = np.zeros((B, gmax), dtype=np.int64)
+    valid = np.zeros((B, gmax), dtype=bool)
+    gidx = np.full((B, gmax), -1, dtype=np.int32)
+    run = 0
+    for b in range(B):
+        n_all = 0 if batch_gt_boxes[b] is None else len(batch_gt_boxes[b])
+        if counts[b] > 0:
+            boxes[b, :counts[b]] = np.asarray(batch_gt_boxes[b], dtype=np.float32)
+            cls[b, :counts[b]] = np.asarray(batch_gt_class_ids[b])
+            valid[b, :counts[b]] = True
+            gidx[b, :counts[b]] = run + np.arange(counts[b])
+        run += n_all
+    t = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
+    return t(boxes) / scale, t(cls), t(valid), t(gidx), counts
+
+
+def detection_target_layer(batch_proposals, batch_mrcnn_class_scores, batch_gt_class_ids, batch_gt_boxes,
+                           batch_gt_masks, cf, B, generator=None):
+    """mrcnn.py:461-613 on fixed-size masked tensors.
+    batch_proposals [B*pc, 2*dim+1]; batch_gt_masks: device float/uint8 tensor [sum_G, 1, Y, X, (Z)] with the GT
+    masks of all batch elements stacked in order (the reference gathers per-RoI copies, :551).
+    Returns sample_indices [B*S], valid [B*S], target_class_ids [B*S], target_deltas [B*S, 2*dim],
+    target_masks [B*S, *mask_shape] with S = train_rois_per_image slots per element (positives then negatives)."""
+    dev = batch_proposals.device
+    dim = cf.dim
+    pc = batch_proposals.shape[0] // B
+    scale = torch.as_tensor(np.asarray(cf.scale, dtype=np.float32), device=dev)
+    gt_boxes, gt_cls, gt_valid, gt_gidx, counts = _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev)
+    proposals = batch_proposals[:, :2 * dim].detach().view(B, pc, 2 * dim)
+    has_gt = gt_valid.any(1)                                                          # [B]
+
+    overlaps = torch.stack([mutils.bbox_overlaps(proposals[b], gt_boxes[b]) for b in range(B)])   # [B, pc, Gmax]
+    overlaps = torch.where(gt_valid[:, None, :], overlaps, torch.full_like(overlaps, -1.0))
+    roi_iou_max, roi_gt_assign = overlaps.max(dim=2)                                  # [B, pc]
+    pos_thr, neg_thr = (0.5, 0.1) if dim == 2 else (0.3, 0.01)
+    positive = (roi_iou_max >= pos_thr) & has_gt[:, None]
+    negative = torch.where(has_gt[:, None], roi_iou_max < neg_thr, torch.ones_like(positive))
+
+    n_pos_max = int(cf.train_rois_per_image * cf.roi_positive_ratio)
+    n_neg_max = max(int((1.0 / cf.roi_positive_ratio) * n_pos_max - n_pos_max), 1)
+    # positives: random subset of size <= n_pos_max (randperm in the reference, :532-534)
+    key = torch.where(positive, torch.rand(positive.shape, device=dev, generator=generator), torch.full(positive.shape, -1.0, device=dev))
+    pkey, pidx = torch.topk(key, min(n_pos_max, pc), dim=1)
+    pvalid = pkey >= 0
+    pos_count = pvalid.sum(1)                                                         # [B]
+    # negatives via SHEM (:579-585): pool = best poolsize*count negatives by max fg prob, `count` random ones of it
+    r = 1.0 / cf.roi_positive_ratio
+    neg_count = torch.clamp((r * pos_count.float() - pos_count.float()).long(), min=1)
+    fg = batch_mrcnn_class_scores.detach()[:, 1:].max(1)[0].view(B, pc)
+    nscore = torch.where(negative, fg, torch.full_like(fg, -1.0))
+    pool_max = min(cf.shem_poolsize * n_neg_max, pc)
+    pool_score, pool_idx = torch.topk(nscore, pool_max, dim=1)                        # sorted, best first
+    rank = torch.arange(pool_max, device=dev)[None, :]
+    in_pool = (pool_score >= 0) & (rank < (cf.shem_poolsize * neg_count)[:, None])
+    key2 = torch.where(in_pool, torch.rand(in_pool.shape, device=dev, generator=generator), torch.full(in_pool.shape, -1.0, device=dev))
+    nkey, nsel = torch.topk(key2, min(n_neg_max, pool_max), dim=1)
+    nidx = torch.gather(pool_idx, 1, nsel)
+    nvalid = (nkey >= 0) & (torch.arange(nkey.shape[1], device=dev)[None, :] < neg_count[:, None])
+
+    # positive targets
+    pos_rois = torch.gather(proposals, 1, pidx.unsqueeze(-1).expand(-1, -1, 2 * dim))  # [B, P, 2dim]
+    pos_assign = torch.gather(roi_gt_assign, 1, pidx)                                 # [B, P]
+    pos_gt_boxes = torch.gather(gt_boxes, 1, pos_assign.unsqueeze(-1).expand(-1, -1, 2 * dim))
+    pos_cls = torch.gather(gt_cls, 1, pos_assign)
+    dummy = torch.tensor([0., 0., 1., 1., 0., 1.] if dim == 3 else [0., 0., 1., 1.], device=dev)   # keeps log() finite
+    safe_rois = torch.where(pvalid.unsqueeze(-1), pos_rois, dummy.expand_as(pos_rois))
+    safe_gt = torch.where(pvalid.unsqueeze(-1), pos_gt_boxes, safe_rois)
+    std = torch.as_tensor(np.asarray(cf.bbox_std_dev, dtype=np.float32), device=dev)
+    deltas = mutils.box_refinement(safe_rois.view(-1, 2 * dim), safe_gt.view(-1, 2 * dim)) / std   # [B*P, 2dim]
+    # mask targets (:551-563): crop the assigned GT mask with the positive RoI, threshold at 0.5
+    P = pidx.shape[1]
+    gsel = torch.gather(gt_gidx, 1, pos_assign)
+    box_ids = torch.where(pvalid, gsel, torch.full_like(gsel, -1)).view(-1).to(torch.int32)
+    ra = ra2D(cf.mask_shape[0], cf.mask_shape[1], 0) if dim == 2 else ra3D(cf.mask_shape[0], cf.mask_shape[1], cf.mask_shape[2], 0)
+    if batch_gt_masks is not None and batch_gt_masks.shape[0] > 0:
+        with torch.no_grad():
+            masks = torch.round(ra(batch_gt_masks.float(), pos_rois.view(-1, 2 * dim).contiguous(), box_ids).squeeze(1))
+    else:
+        masks = torch.zeros((B * P,) + tuple(cf.mask_shape), device=dev)
+
+    Nn = nidx.shape[1]
+    base = (torch.arange(B, device=dev) * pc)[:, None]
+    sample_indices = torch.cat([(pidx + base), (nidx + base)], 1).view(-1)            # [B*(P+Nn)]
+    valid = torch.cat([pvalid, nvalid], 1).view(-1)
+    is_pos = torch.cat([pvalid, torch.zeros_like(nvalid)], 1).view(-1)
+    target_class_ids = torch.cat([torch.where(pvalid, pos_cls, torch.zeros_like(pos_cls)),
+                                  torch.zeros((B, Nn), dtype=pos_cls.dtype, device=dev)], 1).view(-1)
+    target_deltas = torch.cat([deltas.view(B, P, 2 * dim), torch.zeros((B, Nn, 2 * dim), device=dev)], 1).view(-1, 2 * dim)
+    target_masks = torch.cat([masks.view((B, P) + tuple(cf.mask_shape)),
+                              torch.zeros((B, Nn) + tuple(cf.mask_shape), device=dev)], 1).view((-1,) + tuple(cf.mask_shape))
+    target_deltas = target_deltas * is_pos.unsqueeze(-1).to(target_deltas.dtype)
+    return sample_indices, valid, is_pos, target_class_ids, target_deltas, target_masks
+
+
+def refine_detections(rois, probs, deltas, batch_ixs, cf, B):
+    """mrcnn.py:620-714 on fixed-size tensors.  Returns detections [B*M, 2*dim+3] = (pixel box rounded, batch_ix,
+    class_id, score) with M = model_max_instances_per_batch_element slots per element, and a validity mask.
+    One batched device NMS over all (element, class) groups replaces the per-element x per-class loop."""
+    L = _lib.lib()
+    import ctypes
+    dev = rois.device
+    dim = cf.dim
+    n = rois.shape[0]
+    pc = n // B
+    fg = cf.head_classes - 1
+    std = np.asarray(cf.rpn_bbox_std_dev, dtype=np.float32)       # quirk 8: rpn_bbox_std_dev, not bbox_std_dev (:650)
+    scale = torch.as_tensor(np.asarray(cf.scale, dtype=np.float32), device=dev)
+    win = [float(v) for v in cf.window]
+    no_clip = [-3e38, -3e38, 3e38, 3e38] + ([-3e38, 3e38] if dim == 3 else [])
+    groups_boxes, groups_scores = [], []
+    for c in range(1, fg + 1):
+        dec = mutils.decode_clip_boxes(rois, deltas[:, c, :].contiguous(), std, no_clip) * scale
+        dec = torch.round(mutils.clip_boxes(dec, win))
+        groups_boxes.append(dec.view(B, pc, 2 * dim))
+        groups_scores.append(probs[:, c].view(B, pc))
+    boxes = torch.stack(groups_boxes, 1).view(B * fg, pc, 2 * dim)          # group g = b*fg + (c-1)
+    scores = torch.stack(groups_scores, 1).view(B * fg, pc)
+    ok = scores >= cf.model_min_confidence
+    s_sorted, order = torch.sort(torch.where(ok, scores, torch.full_like(scores, -1.0)), dim=1, descending=True, stable=True)
+    b_sorted = torch.gather(boxes, 1, order.unsqueeze(-1).expand(-1, -1, 2 * dim))
+    dets = torch.cat([b_sorted, s_sorted.unsqueeze(-1)], 2).contiguous()
+    G = B * fg
+    keep = torch.empty((G, pc), dtype=torch.int64, device=dev)
+    num = torch.empty(G, dtype=torch.int32, device=dev)
+    wsb = G * L.mdt_nms_workspace_bytes(pc)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    fn = L.mdt_nms_3d_batched if dim == 3 else L.mdt_nms_2d_batched
+    with torch.cuda.device(dev):
+        rc = fn(_lib.ptr(dets), G, pc, ctypes.c_float(cf.detection_nms_threshold), _lib.NMS_RULE_GT, 0,
+                _lib.ptr(keep), pc, _lib.ptr(num), _lib.ptr(ws), wsb, _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_nms_batched")
+    kept = torch.zeros((G, pc + 1), dtype=torch.bool, device=dev)
+    kept.scatter_(1, torch.where(keep >= 0, keep, torch.full_like(keep, pc)), True)
+    kept = kept[:, :pc] & (s_sorted >= cf.model_min_confidence)
+    # top-k per batch element over its classes (:701-703)
+    M = cf.model_max_instances_per_batch_element
+    cand = torch.where(kept, s_sorted, torch.full_like(s_sorted, -1.0)).view(B, fg * pc)
+    top_s, top_i = torch.topk(cand, min(M, fg * pc), dim=1)
+    valid = top_s >= 0
+    cls_ids = (top_i // pc + 1).float()
+    top_b = torch.gather(b_sorted.view(B, fg * pc, 2 * dim), 1, top_i.unsqueeze(-1).expand(-1, -1, 2 * dim))
+    bix = torch.arange(B, device=dev, dtype=torch.float32)[:, None].expand_as(top_s)
+    result = torch.cat([top_b, bix.unsqueeze(-1), cls_ids.unsqueeze(-1), top_s.unsqueeze(-1)], 2)
+    result = result * valid.unsqueeze(-1).to(result.dtype)
+    return result.view(-1, 2 * dim + 3), valid.view(-1)
+
+
+############################################################
+#  Loss functions (masked, fixed-size)
+############################################################
+def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, anchors_f64, gt_boxes_list, cf, generator=None):
+    """compute_rpn_class_loss (mrcnn.py:176-214) + compute_rpn_bbox_loss (:217-240), batched over B.
+    rpn_match [B, A] int32 (-1 / 0 / >0) as returned by the matching kernel BEFORE sub-sampling; the
+    sub-sampling of surplus positives (model_utils.py:566-571) and SHEM are done here with random keys."""
+    dev = rpn_class_logits.device
+    B, A = rpn_match.shape
+    dim = cf.dim
+    n_pos_max = max(cf.rpn_train_anchors_per_image // 2, 1)
+    pos = rpn_match > 0
+    key = torch.where(pos, torch.rand(pos.shape, device=dev, generator=generator), torch.full(pos.shape, -1.0, device=dev))
+    pkey, pidx = torch.topk(key, n_pos_max, dim=1)
+    pvalid = pkey >= 0                                                        # [B, n_pos_max]
+    pos_count = pvalid.sum(1)
+    logits_pos = torch.gather(rpn_class_logits, 1, pidx.unsqueeze(-1).expand(-1, -1, 2))
+    ce_pos = F.cross_entropy(logits_pos.reshape(-1, 2), torch.ones(B * n_pos_max, dtype=torch.long, device=dev), reduction="none").view(B, -1)
+    pos_loss = (ce_pos * pvalid).sum(1) / pos_count.clamp(min=1)              # 0 when no positive
+    # negatives: SHEM over anchors labelled -1
+    neg = rpn_match == -1
+    neg_count = pos_count.clamp(min=1)
+    fgp = F.softmax(rpn_class_logits.detach(), dim=2)[:, :, 1]
+    pool_max = cf.shem_poolsize * n_pos_max
+    pool_score, pool_idx = torch.topk(torch.where(neg, fgp, torch.full_like(fgp, -1.0)), min(pool_max, A), dim=1)
+    rank = torch.arange(pool_score.shape[1], device=dev)[None, :]
+    in_pool = (pool_score >= 0) & (rank < (cf.shem_poolsize * neg_count)[:, None])
+    key2 = torch.where(in_pool, torch.rand(in_pool.shape, device=dev, generator=generator), torch.full(in_pool.shape, -1.0, device=dev))
+    nkey, nsel = torch.topk(key2, n_pos_max, dim=1)
+    nidx = torch.gather(pool_idx, 1, nsel)
+    nvalid = (nkey >= 0) & (torch.arange(n_pos_max, device=dev)[None, :] < neg_count[:, None])
+    logits_neg = torch.gather(rpn_class_logits, 1, nidx.unsqueeze(-1).expand(-1, -1, 2))
+    ce_neg = F.cross_entropy(logits_neg.reshape(-1, 2), torch.zeros(B * n_pos_max, dtype=torch.long, device=dev), reduction="none").view(B, -1)
+    neg_loss = (ce_neg * nvalid).sum(1) / nvalid.sum(1).clamp(min=1)
+    class_loss = ((pos_loss + neg_loss) / 2).mean()                           # mean over batch == sum(loss_b / B)
+
+    # bbox: smooth-L1 between predicted deltas of the kept positives and their targets
+    gmax = max(1, max(len(g) for g in gt_boxes_list))
+    gt_pad = np.zeros((B, gmax, 2 * dim), dtype=np.float64)
+    for b, g in enumerate(gt_boxes_list):
+        if len(g) > 0:
+            gt_pad[b, :len(g)] = np.asarray(g, dtype=np.float64)
+    gt_pad = torch.from_numpy(gt_pad).to(dev, non_blocking=True)
+    a_pos = anchors_f64[pidx.view(-1)]                                        # [B*n, 2dim] f64
+    g_assign = torch.gather(rpn_argmax.long(), 1, pidx)
+    g_pos = torch.gather(gt_pad, 1, g_assign.unsqueeze(-1).expand(-1, -1, 2 * dim)).view(-1, 2 * dim)
+    pv = pvalid.view(-1)
+    g_pos = torch.where(pv.unsqueeze(-1), g_pos, a_pos)                       # keep invalid rows finite
+    tgt = mutils.anchor_delta_targets(a_pos, g_pos, cf.rpn_bbox_std_dev).float().view(B, n_pos_max, 2 * dim)
+    pred = torch.gather(rpn_pred_deltas, 1, pidx.unsqueeze(-1).expand(-1, -1, 2 * dim))
+    sl1 = F.smooth_l1_loss(pred, tgt, reduction="none")
+    bbox_loss_b = (sl1 * pvalid.unsqueeze(-1)).sum((1, 2)) / (pos_count.clamp(min=1) * 2 * dim)
+    bbox_loss = bbox_loss_b.mean()
+    return class_loss, bbox_loss, (pidx, pvalid, nidx, nvalid)
+
+
+def compute_mrcnn_class_loss(target_class_ids, pred_class_logits, valid):
+    ce = F.cross_entropy(pred_class_logits, target_class_ids.long(), reduction="none")
+    return _masked_mean(ce, valid)
+
+
+def compute_mrcnn_bbox_loss(mrcnn_target_deltas, mrcnn_pred_deltas, target_class_ids, is_pos):
+    idx = torch.arange(mrcnn_pred_deltas.shape[0], device=mrcnn_pred_deltas.device)
+    pred = mrcnn_pred_deltas[idx, target_class_ids.long().clamp(min=0)]
+    sl1 = F.smooth_l1_loss(pred, mrcnn_target_deltas.detach(), reduction="none")
+    return _masked_mean(sl1, is_pos)
+
+
+def compute_mrcnn_mask_loss(target_masks, pred_masks, target_class_ids, is_pos):
+    idx = torch.arange(pred_masks.shape[0], device=pred_masks.device)
+    y_pred = pred_masks[idx, target_class_ids.long().clamp(min=0)]
+    bce = F.binary_cross_entropy(y_pred, target_masks.detach(), reduction="none")
+    return _masked_mean(bce, is_pos)
+
+
+############################################################
+#  Output handler
+############################################################
+def get_results(cf, img_shape, detections, det_valid, detection_masks, box_results_list=None, return_masks=True):
+    """mrcnn.py:717-799: restore the batch dimension, unmold, fill the results dict."""
+    det = detections.detach().cpu().numpy()[det_valid.detach().cpu().numpy()]
+    dim = cf.dim
+    if box_results_list is None:
+        box_results_list = [[] for _ in range(img_shape[0])]
+    masks_np = None
+    if return_masks and detection_masks is not None:
+        perm = (0, 2, 3, 1) if dim == 2 else (0, 2, 3, 4, 1)
+        masks_np = detection_masks.permute(*perm).detach().cpu().numpy()[det_valid.detach().cpu().numpy()]
+    batch_ixs = det[:, dim * 2] if det.shape[0] else np.zeros(0)
+    seg_preds = []
+    for ix in range(img_shape[0]):
+        sel = batch_ixs == ix
+        d = det[sel]
+        final_masks = np.zeros(img_shape[2:])
+        if d.shape[0] > 0:
+            boxes = d[:, :2 * dim].astype(np.int32)
+            class_ids = d[:, 2 * dim + 1].astype(np.int32)
+            scores = d[:, 2 * dim + 2]
+            ext = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+            if dim == 3:
+                ext = ext * (boxes[:, 5] - boxes[:, 4])
+            keep = ext > 0                                            # zero-area detections are dropped (:757-766)
+            boxes, class_ids, scores = boxes[keep], class_ids[keep], scores[keep]
+            if return_masks and masks_np is not None and boxes.shape[0] > 0:
+                from scipy.ndimage import zoom
+                m = masks_np[sel][keep]
+                full = []
+                for i in range(boxes.shape[0]):
+                    mi = m[i][..., class_ids[i]]
+                    bb = boxes[i]
+                    tgt = (bb[2] - bb[0], bb[3] - bb[1]) + ((bb[5] - bb[4],) if dim == 3 else ())
+                    fm = np.zeros(img_shape[2:])
+                    zm = zoom(mi, [t / s for t, s in zip(tgt, mi.shape)], order=1)
+                    sl = (slice(bb[0], bb[2]), slice(bb[1], bb[3])) + ((slice(bb[4], bb[5]),) if dim == 3 else ())
+                    fm[sl] = zm
+                    full.append(fm)
+                final_masks = np.max(np.array(full), 0) if full else final_masks
+            for i2, score in enumerate(scores):
+                box_results_list[ix].append({"box_coords": boxes[i2], "box_score": score, "box_type": "det",
+                                             "box_pred_class_id": class_ids[i2]})
+        seg_preds.append(final_masks)
+    return {"boxes": box_results_list, "seg_preds": np.round(np.array(seg_preds))[:, np.newaxis].astype("uint8")}
+
+
+############################################################
+#  Mask R-CNN
+############################################################
+class net(nn.Module):
+    def __init__(self, cf, logger=None, device=None):
+        super(net, self).__init__()
+        self.cf = cf
+        self.logger = logger
+        self.device_ = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.build()
+
+    def build(self):
+        h, w = self.cf.patch_size[:2]
+        if h / 2 ** 5 != int(h / 2 ** 5) or w / 2 ** 5 != int(w / 2 ** 5):
+            raise Exception("Image size must be dividable by 2 at least 5 times to avoid fractions when downscaling and upscaling.")
+        if len(self.cf.patch_size) == 3 and self.cf.patch_size[2] / 2 ** 3 != int(self.cf.patch_size[2] / 2 ** 3):
+            raise Exception("Image z dimension must be dividable by 2 at least 3 times to avoid fractions when downscaling and upscaling.")
+        conv = mutils.NDConvGenerator(self.cf.dim)
+        # anchors live on the device: float64 table for the matching kernel, fp32 copy for the proposal layer
+        self.anchors_f64, self.anchors = mutils.generate_pyramid_anchors(self.logger, self.cf, device=self.device_, return_f32=True)
+        self.fpn = backbone_module.FPN(self.cf, conv)
+        self.rpn = RPN(self.cf, conv)
+        self.classifier = Classifier(self.cf, conv)
+        self.mask = Mask(self.cf, conv)
+        self.to(self.device_)
+
+    @property
+    def np_anchors(self):
+        return self.anchors_f64.cpu().numpy()
+
+    # ------------------------------------------------------------------ forward passes
+    def forward(self, img, is_training=True):
+        """mrcnn.py:987-1050."""
+        cf = self.cf
+        B = img.shape[0]
+        fpn_outs = self.fpn(img)
+        rpn_feature_maps = [fpn_outs[i] for i in cf.pyramid_levels]
+        self.mrcnn_feature_maps = rpn_feature_maps
+        layer_outputs = [self.rpn(p) for p in rpn_feature_maps]
+        rpn_pred_logits, rpn_pred_probs, rpn_pred_deltas = [torch.cat(list(o), dim=1) for o in zip(*layer_outputs)]
+        proposal_count = cf.post_nms_rois_training if is_training else cf.post_nms_rois_inference
+        batch_rpn_rois, batch_proposal_boxes = proposal_layer(rpn_pred_probs, rpn_pred_deltas, proposal_count, self.anchors, cf)
+        batch_ixs = torch.arange(B, device=img.device, dtype=torch.float32).repeat_interleave(batch_rpn_rois.shape[1])
+        rpn_rois = batch_rpn_rois.reshape(-1, batch_rpn_rois.shape[2])
+        self.rpn_rois_batch_info = torch.cat((rpn_rois, batch_ixs.unsqueeze(1)), dim=1)
+        class_logits_list, bboxes_list = [], []
+        with torch.no_grad():
+            for chunk in self.rpn_rois_batch_info.split(cf.roi_chunk_size):
+                cl, bb = self.classifier(self.mrcnn_feature_maps, chunk)
+                class_logits_list.append(cl)
+                bboxes_list.append(bb)
+        batch_mrcnn_class_logits = torch.cat(class_logits_list, 0)
+        batch_mrcnn_bbox = torch.cat(bboxes_list, 0)
+        self.batch_mrcnn_class_scores = F.softmax(batch_mrcnn_class_logits, dim=1)
+        detections, det_valid = refine_detections(rpn_rois, self.batch_mrcnn_class_scores, batch_mrcnn_bbox, batch_ixs, cf, B)
+        dim = cf.dim
+        scale = torch.as_tensor(np.asarray(list(cf.scale) + [1], dtype=np.float32), device=img.device)
+        detection_boxes = detections[:, :dim * 2 + 1] / scale
+        detection_boxes = torch.cat([detection_boxes[:, :dim * 2],
+                                     torch.where(det_valid, detection_boxes[:, dim * 2], torch.full_like(detection_boxes[:, dim * 2], -1.0)).unsqueeze(1)], 1)
+        with torch.no_grad():
+            detection_masks = self.mask(self.mrcnn_feature_maps, detection_boxes)
+        return [rpn_pred_logits, rpn_pred_deltas, batch_proposal_boxes, detections, det_valid, detection_masks]
+
+    def loss_samples_forward(self, batch_gt_class_ids, batch_gt_boxes, batch_gt_masks, B):
+        """mrcnn.py:1052-1082."""
+        sample_ix, valid, is_pos, tcls, tdeltas, tmasks = detection_target_layer(
+            self.rpn_rois_batch_info, self.batch_mrcnn_class_scores, batch_gt_class_ids, batch_gt_boxes, batch_gt_masks, self.cf, B)
+        sample_proposals = self.rpn_rois_batch_info[sample_ix]
+        dim = self.cf.dim
+        sample_proposals = torch.cat([sample_proposals[:, :2 * dim],
+                                      torch.where(valid, sample_proposals[:, 2 * dim], torch.full_like(sample_proposals[:, 2 * dim], -1.0)).unsqueeze(1)], 1)
+        sample_logits, sample_boxes = self.classifier(self.mrcnn_feature_maps, sample_proposals)
+        sample_mask = self.mask(self.mrcnn_feature_maps, sample_proposals)
+        return [sample_logits, sample_boxes, sample_mask, tcls, tdeltas, tmasks, sample_proposals, valid, is_pos]
+
+    def train_forward(self, batch, is_validation=False, monitor=True):
+        """mrcnn.py:853-967.  batch: the reference's batch dict (numpy): 'data', 'roi_labels', 'bb_target', 'roi_masks'.
+        monitor=False skips building the python box lists (the loss terms are unchanged)."""
+        cf = self.cf
+        dev = self.device_
+        img = torch.from_numpy(np.ascontiguousarray(batch["data"])).to(dev, non_blocking=True).float() \
+            if not torch.is_tensor(batch["data"]) else batch["data"].to(dev).float()
+        gt_class_ids = batch["roi_labels"]
+        gt_boxes = batch["bb_target"]
+        B = img.shape[0]
+        # GT masks of all elements stacked [sum_G, 1, Y, X, (Z)] (uint8 over PCIe, float on the device)
+        masks_list = [torch.as_tensor(np.ascontiguousarray(m)) for m in batch["roi_masks"] if len(m) > 0]
+        gt_masks = torch.cat(masks_list, 0).to(dev, non_blocking=True) if masks_list else None
+
+        rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(img)
+        (mrcnn_class_logits, mrcnn_pred_deltas, mrcnn_pred_mask, target_class_ids, mrcnn_target_deltas, target_mask,
+         sample_proposals, s_valid, s_pos) = self.loss_samples_forward(gt_class_ids, gt_boxes, gt_masks, B)
+
+        # anchor matching per element on the device (the reference: numpy on one host core, mrcnn.py:894)
+        matches, argmaxes = [], []
+        neg_thr = 0.1 if cf.dim == 2 else 0.01
+        for b in range(B):
+            g = gt_boxes[b]
+            gt_t = torch.from_numpy(np.asarray(g, dtype=np.float64)).to(dev, non_blocking=True) if len(g) > 0 else None
+            m, am, _, _ = mutils.anchor_match_labels(self.anchors_f64, gt_t, None, neg_thr, float(cf.anchor_matching_iou))
+            matches.append(m)
+            argmaxes.append(am)
+        rpn_match = torch.stack(matches)
+        rpn_argmax = torch.stack(argmaxes)
+        batch_rpn_class_loss, batch_rpn_bbox_loss, rpn_samples = compute_rpn_losses(
+            rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, self.anchors_f64, gt_boxes, cf)
+
+        mrcnn_class_loss = compute_mrcnn_class_loss(target_class_ids, mrcnn_class_logits, s_valid)
+        mrcnn_bbox_loss = compute_mrcnn_bbox_loss(mrcnn_target_deltas, mrcnn_pred_deltas, target_class_ids, s_pos)
+        if not cf.frcnn_mode:
+            mrcnn_mask_loss = compute_mrcnn_mask_loss(target_mask, mrcnn_pred_mask, target_class_ids, s_pos)
+        else:
+            mrcnn_mask_loss = torch.zeros((), device=dev)
+        loss = batch_rpn_class_loss + batch_rpn_bbox_loss + mrcnn_class_loss + mrcnn_bbox_loss + mrcnn_mask_loss
+
+        results_dict = {"torch_loss": loss}
+        if monitor:
+            box_results_list = [[] for _ in range(B)]
+            for b in range(B):
+                for ix in range(len(gt_boxes[b])):
+                    box_results_list[b].append({"box_coords": batch["bb_target"][b][ix], "box_label": batch["roi_labels"][b][ix], "box_type": "gt"})
+            pidx, pvalid, nidx, nvalid = [t.cpu().numpy() for t in rpn_samples]
+            anchors_np = self.anchors.cpu().numpy()
+            props = proposal_boxes.cpu().numpy()
+            for b in range(B):
+                for a in anchors_np[pidx[b][pvalid[b]]]:
+                    box_results_list[b].append({"box_coords": a, "box_type": "pos_anchor"})
+                for a in anchors_np[nidx[b][nvalid[b]]]:
+                    box_results_list[b].append({"box_coords": a, "box_type": "neg_anchor"})
+                rp = props[b][props[b, :, -1].argsort()][::-1]
+                for r in rp[:cf.n_plot_rpn_props, :-1]:
+                    box_results_list[b].append({"box_coords": r, "box_type": "prop"})
+            sp = sample_proposals.detach().cpu().numpy()
+            tc = target_class_ids.cpu().numpy()
+            for ix, r in enumerate(sp):
+                if r[-1] >= 0:
+                    box_results_list[int(r[-1])].append({"box_coords": r[:-1] * cf.scale, "box_type": "pos_class" if tc[ix] > 0 else "neg_class"})
+            return_masks = cf.return_masks_in_val if is_validation else False
+            results_dict.update(get_results(cf, img.shape, detections, det_valid, detection_masks, box_results_list, return_masks=return_masks))
+            tcv = tc[s_valid.cpu().numpy()]
+            dcount = [int((tcv == c).sum()) for c in range(1, cf.head_classes)]
+            vals = torch.stack([loss.detach(), batch_rpn_class_loss.detach(), batch_rpn_bbox_loss.detach(), mrcnn_class_loss.detach(),
+                                mrcnn_bbox_loss.detach(), mrcnn_mask_loss.detach()]).cpu().numpy()      # one read-out instead of six .item()
+            results_dict["monitor_values"] = {"loss": float(vals[0]), "class_loss": float(vals[3])}
+            results_dict["logger_string"] = (
+                "loss: {0:.2f}, rpn_class: {1:.2f}, rpn_bbox: {2:.2f}, mrcnn_class: {3:.2f}, mrcnn_bbox: {4:.2f}, "
+                "mrcnn_mask: {5:.2f}, dcount {6}".format(vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], dcount))
+        return results_dict
+
+    def test_forward(self, batch, return_masks=True):
+        """mrcnn.py:969-985."""
+        img = batch["data"]
+        img = torch.from_numpy(np.ascontiguousarray(img)).to(self.device_).float() if not torch.is_tensor(img) else img.to(self.device_).float()
+        with torch.no_grad():
+            _, _, _, detections, det_valid, detection_masks = self.forward(img, is_training=False)
+        return get_results(self.cf, img.shape, detections, det_valid, detection_masks, return_masks=return_masks)
