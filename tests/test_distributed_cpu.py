@@ -1,0 +1,87 @@
+"""world_size-2 gloo tests (CPU) of the N > 1 path: flat-bucket gradient averaging incl. parameters that get
+no gradient on some rank, and the padded all_gather used by patch-sharded inference."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from medicaldetectiontoolkit_amd import distributed as mdist
+from medicaldetectiontoolkit_amd import training
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.used = nn.Linear(4, 3)
+        self.sometimes = nn.Linear(4, 3)   # gets a gradient on rank 0 only
+        self.never = nn.Linear(4, 3)       # like FPN.P1_conv2 in the reference: constructed, never used
+
+    def forward(self, x, use_second):
+        y = self.used(x)
+        if use_second:
+            y = y + self.sometimes(x)
+        return y.pow(2).mean()
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = Tiny()
+    torch.manual_seed(100 + rank)
+    x = torch.randn(5, 4)
+    loss = net(x, use_second=(rank == 0))
+    loss.backward()
+    training.FlatGradAllReduce(net)()
+    grads = {n: p.grad.clone() for n, p in net.named_parameters()}
+    # inference exchange: rank r contributes r + 1 rows
+    rows = torch.full((rank + 1, 3), float(rank))
+    gathered = mdist.gather_rows(rows)
+    shard = mdist.shard_indices(7)
+    if rank == 0:
+        torch.save({"grads": grads, "gathered": gathered, "shard": shard}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_and_gather_world2(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single-process reference: mean of the two ranks' gradients (missing gradient == zeros)
+    torch.manual_seed(0)
+    ref = Tiny()
+    sums = {n: torch.zeros_like(p) for n, p in ref.named_parameters()}
+    for rank in range(2):
+        ref.zero_grad()
+        torch.manual_seed(100 + rank)
+        x = torch.randn(5, 4)
+        ref(x, use_second=(rank == 0)).backward()
+        for n, p in ref.named_parameters():
+            if p.grad is not None:
+                sums[n] += p.grad
+    for n in sums:
+        assert torch.allclose(got["grads"][n], sums[n] / 2, atol=1e-7), n
+    assert torch.count_nonzero(got["grads"]["never.weight"]) == 0
+    assert got["gathered"].tolist() == [[0.0] * 3, [1.0] * 3, [1.0] * 3]
+    assert got["shard"] == [0, 2, 4, 6]
+
+
+def test_single_process_helpers_are_identity():
+    t = torch.arange(6.0).view(2, 3)
+    assert mdist.gather_rows(t) is t
+    assert mdist.shard_indices(5) == [0, 1, 2, 3, 4]
+    training.FlatGradAllReduce(Tiny())()   # no process group: no-op
