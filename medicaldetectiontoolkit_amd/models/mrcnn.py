@@ -324,8 +324,10 @@ def refine_detections(rois, probs, deltas, batch_ixs, cf, B):
 ############################################################
 #  Loss functions (masked, fixed-size)
 ############################################################
-def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, anchors_f64, gt_boxes_list, cf, generator=None):
-    """compute_rpn_class_loss (mrcnn.py:176-214) + compute_rpn_bbox_loss (:217-240), batched over B.
+def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, anchors_f64, gt_boxes_list, cf, generator=None,
+                       shem_poolsize=None):
+    """compute_rpn_class_loss (mrcnn.py:176-214) + compute_rpn_bbox_loss (:217-240), batched over B; with K-class
+    logits and class-id matches it is also retina_unet.compute_class_loss / compute_bbox_loss (retina_unet.py:126-189).
     rpn_match [B, A] int32 (-1 / 0 / >0) as returned by the matching kernel BEFORE sub-sampling; the
     sub-sampling of surplus positives (model_utils.py:566-571) and SHEM are done here with random keys."""
     dev = rpn_class_logits.device
@@ -337,23 +339,26 @@ def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas,
     pkey, pidx = torch.topk(key, n_pos_max, dim=1)
     pvalid = pkey >= 0                                                        # [B, n_pos_max]
     pos_count = pvalid.sum(1)
-    logits_pos = torch.gather(rpn_class_logits, 1, pidx.unsqueeze(-1).expand(-1, -1, 2))
-    ce_pos = F.cross_entropy(logits_pos.reshape(-1, 2), torch.ones(B * n_pos_max, dtype=torch.long, device=dev), reduction="none").view(B, -1)
+    K = rpn_class_logits.shape[-1]
+    poolsize = cf.shem_poolsize if shem_poolsize is None else shem_poolsize
+    logits_pos = torch.gather(rpn_class_logits, 1, pidx.unsqueeze(-1).expand(-1, -1, K))
+    tgt_pos = torch.gather(rpn_match, 1, pidx).clamp(min=0).long()          # 1 for the RPN, class id for Retina
+    ce_pos = F.cross_entropy(logits_pos.reshape(-1, K), tgt_pos.view(-1), reduction="none").view(B, -1)
     pos_loss = (ce_pos * pvalid).sum(1) / pos_count.clamp(min=1)              # 0 when no positive
     # negatives: SHEM over anchors labelled -1
     neg = rpn_match == -1
     neg_count = pos_count.clamp(min=1)
-    fgp = F.softmax(rpn_class_logits.detach(), dim=2)[:, :, 1]
-    pool_max = cf.shem_poolsize * n_pos_max
+    fgp = F.softmax(rpn_class_logits.detach(), dim=2)[:, :, 1:].max(dim=2)[0]
+    pool_max = poolsize * n_pos_max
     pool_score, pool_idx = torch.topk(torch.where(neg, fgp, torch.full_like(fgp, -1.0)), min(pool_max, A), dim=1)
     rank = torch.arange(pool_score.shape[1], device=dev)[None, :]
-    in_pool = (pool_score >= 0) & (rank < (cf.shem_poolsize * neg_count)[:, None])
+    in_pool = (pool_score >= 0) & (rank < (poolsize * neg_count)[:, None])
     key2 = torch.where(in_pool, torch.rand(in_pool.shape, device=dev, generator=generator), torch.full(in_pool.shape, -1.0, device=dev))
     nkey, nsel = torch.topk(key2, n_pos_max, dim=1)
     nidx = torch.gather(pool_idx, 1, nsel)
     nvalid = (nkey >= 0) & (torch.arange(n_pos_max, device=dev)[None, :] < neg_count[:, None])
-    logits_neg = torch.gather(rpn_class_logits, 1, nidx.unsqueeze(-1).expand(-1, -1, 2))
-    ce_neg = F.cross_entropy(logits_neg.reshape(-1, 2), torch.zeros(B * n_pos_max, dtype=torch.long, device=dev), reduction="none").view(B, -1)
+    logits_neg = torch.gather(rpn_class_logits, 1, nidx.unsqueeze(-1).expand(-1, -1, K))
+    ce_neg = F.cross_entropy(logits_neg.reshape(-1, K), torch.zeros(B * n_pos_max, dtype=torch.long, device=dev), reduction="none").view(B, -1)
     neg_loss = (ce_neg * nvalid).sum(1) / nvalid.sum(1).clamp(min=1)
     class_loss = ((pos_loss + neg_loss) / 2).mean()                           # mean over batch == sum(loss_b / B)
 

@@ -1,0 +1,241 @@
+"""Retina U-Net / Retina Net (2D / 3D) on the gfx950 hot-path kernels.
+
+Mirror of the reference's models/retina_unet.py (and retina_net.py, which differs only by the missing
+segmentation head): same module names / state_dict keys (Fpn, Classifier, BBRegressor, final_conv), same
+net(cf, logger) with train_forward / test_forward / forward.  Native call sites: per-(element, class) NMS in
+refine_detections (retina_unet.py:248-250) and the per-element numpy gt_anchor_matching (:416).
+
+refine_detections here runs ONE device NMS over the global top pre_nms_limit candidates: boxes of different
+(batch element, class) groups are shifted apart along y by a multiple of 4096 px, so cross-group IoU is exactly 0
+while in-group IoUs are unchanged bit for bit (rounded pixel coordinates and their +1 extents are exact in fp32) --
+equivalent to the reference's loop of per-group NMS calls, without its nonzero()/unique1d() host syncs.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..cuda_functions import _nms_impl
+from ..utils import model_utils as mutils
+from . import backbone as backbone_module
+from .mrcnn import compute_rpn_losses
+
+GROUP_SHIFT = 4096.0
+
+
+class Classifier(nn.Module):
+    """retina_unet.py:40-79."""
+
+    def __init__(self, cf, conv):
+        super(Classifier, self).__init__()
+        self.dim = conv.dim
+        self.n_classes = cf.head_classes
+        nf, s = cf.n_rpn_features, cf.rpn_anchor_stride
+        self.conv_1 = conv(cf.end_filts, nf, ks=3, stride=s, pad=1, relu=cf.relu)
+        self.conv_2 = conv(nf, nf, ks=3, stride=s, pad=1, relu=cf.relu)
+        self.conv_3 = conv(nf, nf, ks=3, stride=s, pad=1, relu=cf.relu)
+        self.conv_4 = conv(nf, nf, ks=3, stride=s, pad=1, relu=cf.relu)
+        self.conv_final = conv(nf, cf.n_anchors_per_pos * cf.head_classes, ks=3, stride=s, pad=1, relu=None)
+
+    def forward(self, x):
+        x = self.conv_4(self.conv_3(self.conv_2(self.conv_1(x))))
+        class_logits = self.conv_final(x)
+        axes = (0, 2, 3, 1) if self.dim == 2 else (0, 2, 3, 4, 1)
+        return [class_logits.permute(*axes).contiguous().view(x.size(0), -1, self.n_classes)]
+
+
+class BBRegressor(nn.Module):
+    """retina_unet.py:82-119."""
+
+    def __init__(self, cf, conv):
+        super(BBRegressor, self).__init__()
+        self.dim = conv.dim
+        nf, s = cf.n_rpn_features, cf.rpn_anchor_stride
+        self.conv_1 = conv(cf.end_filts, nf, ks=3, stride=s, pad=1, relu=cf.relu)
+        self.conv_2 = conv(nf, nf, ks=3, stride=s, pad=1, relu=cf.relu)
+        self.conv_3 = conv(nf, nf, ks=3, stride=s, pad=1, relu=cf.relu)
+        self.conv_4 = conv(nf, nf, ks=3, stride=s, pad=1, relu=cf.relu)
+        self.conv_final = conv(nf, cf.n_anchors_per_pos * self.dim * 2, ks=3, stride=s, pad=1, relu=None)
+
+    def forward(self, x):
+        x = self.conv_4(self.conv_3(self.conv_2(self.conv_1(x))))
+        bb_logits = self.conv_final(x)
+        axes = (0, 2, 3, 1) if self.dim == 2 else (0, 2, 3, 4, 1)
+        return [bb_logits.permute(*axes).contiguous().view(x.size(0), -1, self.dim * 2)]
+
+
+def batch_dice(pred, y, false_positive_weight=1.0, smooth=1e-6):
+    """utils/model_utils.py:845-866: soft dice over the batch pseudo-volume, foreground classes only."""
+    axes = (0,) + tuple(range(2, pred.dim()))
+    intersect = (pred * y).sum(axes)
+    denom = (false_positive_weight * pred + y).sum(axes)
+    return torch.mean(((2 * intersect + smooth) / (denom + smooth))[1:])
+
+
+def refine_detections(anchors, probs, deltas, B, cf):
+    """retina_unet.py:194-271.  anchors [A, 2*dim] fp32; probs [B*A, K]; deltas [B*A, 2*dim].
+    Returns detections [B*M, 2*dim+3] (pixel box rounded, batch_ix, class_id, score) and a validity mask."""
+    dev = probs.device
+    dim = cf.dim
+    A = anchors.shape[0]
+    fg = probs.shape[1] - 1
+    fg_probs = probs[:, 1:].contiguous()
+    n_pre = min(cf.pre_nms_limit, fg_probs.numel())
+    flat_probs, keep_ix = torch.topk(fg_probs.view(-1), n_pre, sorted=True)            # :208-210
+    row = torch.div(keep_ix, fg, rounding_mode="floor")
+    cls = keep_ix % fg + 1
+    bix = torch.div(row, A, rounding_mode="floor")
+    scale = torch.as_tensor(np.asarray(cf.scale, dtype=np.float32), device=dev)
+    no_clip = [-3e38, -3e38, 3e38, 3e38] + ([-3e38, 3e38] if dim == 3 else [])
+    dec = mutils.decode_clip_boxes((anchors[row % A] / scale).contiguous(), deltas[row].contiguous(),
+                                   np.asarray(cf.rpn_bbox_std_dev, dtype=np.float32), no_clip) * scale      # :226-228
+    rois = torch.round(mutils.clip_boxes(dec, [float(v) for v in cf.window]))
+    # one NMS for all (element, class) groups: shift groups apart along y
+    group = (bix * fg + (cls - 1)).float()
+    shifted = rois.clone()
+    shifted[:, 0] += group * GROUP_SHIFT
+    shifted[:, 2] += group * GROUP_SHIFT
+    dets = torch.cat([shifted, flat_probs.unsqueeze(1)], 1).contiguous()               # already sorted by score
+    keep, num = _nms_impl.nms_sorted(dets, float(cf.detection_nms_threshold), dim)
+    kept = torch.zeros(n_pre + 1, dtype=torch.bool, device=dev)
+    kept[torch.where(keep >= 0, keep, torch.full_like(keep, n_pre))] = True
+    kept = kept[:n_pre]
+    # top model_max_instances_per_batch_element per batch element (:261-263)
+    M = cf.model_max_instances_per_batch_element
+    per_b = torch.where(kept[None, :] & (bix[None, :] == torch.arange(B, device=dev)[:, None]), flat_probs[None, :],
+                        torch.full((1, 1), -1.0, device=dev))
+    top_s, top_i = torch.topk(per_b, min(M, n_pre), dim=1)
+    valid = top_s >= 0
+    out = torch.cat([rois[top_i], torch.arange(B, device=dev, dtype=torch.float32)[:, None, None].expand(-1, top_i.shape[1], 1),
+                     cls[top_i].float().unsqueeze(-1), top_s.unsqueeze(-1)], 2)
+    out = out * valid.unsqueeze(-1).to(out.dtype)
+    return out.view(-1, 2 * dim + 3), valid.view(-1)
+
+
+def get_results(cf, img_shape, detections, det_valid, seg_logits, box_results_list=None):
+    """retina_unet.py:275-335."""
+    det = detections.detach().cpu().numpy()[det_valid.detach().cpu().numpy()]
+    dim = cf.dim
+    if box_results_list is None:
+        box_results_list = [[] for _ in range(img_shape[0])]
+    batch_ixs = det[:, dim * 2] if det.shape[0] else np.zeros(0)
+    for ix in range(img_shape[0]):
+        d = det[batch_ixs == ix]
+        if d.shape[0] == 0:
+            continue
+        boxes = d[:, :2 * dim].astype(np.int32)
+        class_ids = d[:, 2 * dim + 1].astype(np.int32)
+        scores = d[:, 2 * dim + 2]
+        ext = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+        if dim == 3:
+            ext = ext * (boxes[:, 5] - boxes[:, 4])
+        for ix2 in np.nonzero(ext > 0)[0]:
+            if scores[ix2] >= cf.model_min_confidence:
+                box_results_list[ix].append({"box_coords": boxes[ix2], "box_score": scores[ix2], "box_type": "det",
+                                             "box_pred_class_id": class_ids[ix2]})
+    results_dict = {"boxes": box_results_list}
+    if seg_logits is None:
+        results_dict["seg_preds"] = np.zeros(img_shape)[:, 0][:, np.newaxis]
+    else:
+        results_dict["seg_preds"] = F.softmax(seg_logits, 1).argmax(1).cpu().numpy()[:, np.newaxis].astype("uint8")
+    return results_dict
+
+
+class net(nn.Module):
+    def __init__(self, cf, logger=None, device=None):
+        super(net, self).__init__()
+        self.cf = cf
+        self.logger = logger
+        self.device_ = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.build()
+
+    def build(self):
+        h, w = self.cf.patch_size[:2]
+        if h / 2 ** 5 != int(h / 2 ** 5) or w / 2 ** 5 != int(w / 2 ** 5):
+            raise Exception("Image size must be dividable by 2 at least 5 times to avoid fractions when downscaling and upscaling.")
+        conv = mutils.NDConvGenerator(self.cf.dim)
+        self.anchors_f64, self.anchors = mutils.generate_pyramid_anchors(self.logger, self.cf, device=self.device_, return_f32=True)
+        self.Fpn = backbone_module.FPN(self.cf, conv, operate_stride1=self.cf.operate_stride1)
+        self.Classifier = Classifier(self.cf, conv)
+        self.BBRegressor = BBRegressor(self.cf, conv)
+        if self.cf.model == "retina_unet":
+            self.final_conv = conv(self.cf.end_filts, self.cf.num_seg_classes, ks=1, pad=0, norm=None, relu=None)
+        self.to(self.device_)
+
+    @property
+    def np_anchors(self):
+        return self.anchors_f64.cpu().numpy()
+
+    def forward(self, img):
+        """retina_unet.py:477-513."""
+        fpn_outs = self.Fpn(img)
+        off = 1 if self.cf.operate_stride1 else 0
+        seg_logits = self.final_conv(fpn_outs[0]) if self.cf.model == "retina_unet" else None
+        selected = [fpn_outs[i + off] for i in self.cf.pyramid_levels]
+        class_logits = torch.cat([self.Classifier(p)[0] for p in selected], dim=1)
+        bb_outputs = torch.cat([self.BBRegressor(p)[0] for p in selected], dim=1)
+        B = class_logits.shape[0]
+        flat_class_softmax = F.softmax(class_logits.detach().view(-1, class_logits.shape[-1]), 1)
+        flat_bb_outputs = bb_outputs.detach().view(-1, bb_outputs.shape[-1])
+        detections, det_valid = refine_detections(self.anchors, flat_class_softmax, flat_bb_outputs, B, self.cf)
+        return detections, det_valid, class_logits, bb_outputs, seg_logits
+
+    def train_forward(self, batch, monitor=True, **kwargs):
+        """retina_unet.py:381-457."""
+        cf, dev = self.cf, self.device_
+        img = torch.from_numpy(np.ascontiguousarray(batch["data"])).to(dev, non_blocking=True).float() \
+            if not torch.is_tensor(batch["data"]) else batch["data"].to(dev).float()
+        gt_class_ids, gt_boxes = batch["roi_labels"], batch["bb_target"]
+        B = img.shape[0]
+        detections, det_valid, class_logits, pred_deltas, seg_logits = self.forward(img)
+        matches, argmaxes = [], []
+        neg_thr = 0.1 if cf.dim == 2 else 0.01
+        for b in range(B):
+            g = gt_boxes[b]
+            if len(g) > 0:
+                gt_t = torch.from_numpy(np.asarray(g, dtype=np.float64)).to(dev, non_blocking=True)
+                cls_t = torch.from_numpy(np.asarray(gt_class_ids[b]).astype(np.int32)).to(dev, non_blocking=True)
+            else:
+                gt_t, cls_t = None, None
+            m, am, _, _ = mutils.anchor_match_labels(self.anchors_f64, gt_t, cls_t, neg_thr, float(cf.anchor_matching_iou))
+            matches.append(m)
+            argmaxes.append(am)
+        batch_class_loss, batch_bbox_loss, samples = compute_rpn_losses(
+            torch.stack(matches), torch.stack(argmaxes), class_logits, pred_deltas, self.anchors_f64, gt_boxes, cf, shem_poolsize=20)
+        loss = batch_class_loss + batch_bbox_loss
+        seg_dice = seg_ce = None
+        if seg_logits is not None:
+            var_seg = torch.from_numpy(np.ascontiguousarray(batch["seg"])).to(dev, non_blocking=True).long()
+            ohe = F.one_hot(var_seg[:, 0], cf.num_seg_classes).movedim(-1, 1).float()
+            seg_dice = 1 - batch_dice(F.softmax(seg_logits, dim=1), ohe)
+            seg_ce = F.cross_entropy(seg_logits, var_seg[:, 0])
+            loss = loss + (seg_dice + seg_ce) / 2
+        results_dict = {"torch_loss": loss}
+        if monitor:
+            box_results_list = [[] for _ in range(B)]
+            for b in range(B):
+                for ix in range(len(gt_boxes[b])):
+                    box_results_list[b].append({"box_coords": batch["bb_target"][b][ix], "box_label": batch["roi_labels"][b][ix], "box_type": "gt"})
+            pidx, pvalid, nidx, nvalid = [t.cpu().numpy() for t in samples]
+            anchors_np = self.anchors.cpu().numpy()
+            for b in range(B):
+                for a in anchors_np[pidx[b][pvalid[b]]]:
+                    box_results_list[b].append({"box_coords": a, "box_type": "pos_anchor"})
+                for a in anchors_np[nidx[b][nvalid[b]]]:
+                    box_results_list[b].append({"box_coords": a, "box_type": "neg_anchor"})
+            results_dict.update(get_results(cf, img.shape, detections, det_valid, seg_logits, box_results_list))
+            vals = [loss, batch_class_loss, batch_bbox_loss] + ([seg_dice, seg_ce] if seg_logits is not None else [])
+            v = torch.stack([x.detach() for x in vals]).cpu().numpy()
+            results_dict["monitor_values"] = {"loss": float(v[0]), "class_loss": float(v[1])}
+            results_dict["logger_string"] = "loss: {0:.2f}, class: {1:.2f}, bbox: {2:.2f}".format(v[0], v[1], v[2]) + (
+                ", seg dice: {0:.3f}, seg ce: {1:.3f}, mean pix. pr.: {2:.5f}".format(v[3], v[4], float(np.mean(results_dict["seg_preds"])))
+                if seg_logits is not None else "")
+        return results_dict
+
+    def test_forward(self, batch, **kwargs):
+        """retina_unet.py:459-475."""
+        img = batch["data"]
+        img = torch.from_numpy(np.ascontiguousarray(img)).to(self.device_).float() if not torch.is_tensor(img) else img.to(self.device_).float()
+        with torch.no_grad():
+            detections, det_valid, _, _, seg_logits = self.forward(img)
+        return get_results(self.cf, img.shape, detections, det_valid, seg_logits)
