@@ -47,3 +47,84 @@ def weighted_box_clustering(dets, box_patch_id, thresh, n_ens, device=None):
     p = torch.from_numpy(np.ascontiguousarray(pid_int[order].astype(np.int32))).to(device)
     s, c = weighted_box_clustering_device(d, p, float(thresh), float(n_ens), int(pid_int.max()) + 1)
     return list(s.cpu().numpy()), [list(r) for r in c.cpu().numpy()]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# patch-tiled prediction of one patient (predictor.py:370-455 spatial_tiling_forward + :458-510
+# batch_tiling_forward + :514-550 apply_wbc_to_patient), patches sharded over ranks
+# ----------------------------------------------------------------------------------------------------------
+def box_patch_center_factor(box_coords, patch_size):
+    """predictor.py:428-430: mean over axes of norm.pdf(centre, loc=ps/2, scale=0.8*ps/2) * sqrt(2 pi) * 0.8*ps/2,
+    i.e. exp(-0.5 * ((centre - ps/2) / (0.8 * ps/2))**2)."""
+    dim = len(patch_size)
+    c = np.asarray(box_coords, dtype=np.float64)
+    centres = [(c[0] + c[2]) / 2, (c[1] + c[3]) / 2] + ([(c[4] + c[5]) / 2] if dim == 3 else [])
+    half = np.asarray(patch_size, dtype=np.float64) / 2
+    return float(np.mean([np.exp(-0.5 * ((bc - pc) / (pc * 0.8)) ** 2) for bc, pc in zip(centres, half)]))
+
+
+def predict_patient(net, data, cf, n_ens=1, amp_dtype=None, rank_ix="0", n_aug="0", with_seg=False):
+    """data: numpy [C, Y, X, Z] (3D) whole-patient volume.  Tiles it (get_patch_crop_coords), forwards the patches
+    of THIS rank in chunks of cf.batch_size, moves boxes to patient coordinates with patch-centre factor and
+    overlap count, all_gathers the rows across ranks and consolidates per class with the WBC kernel.
+    Returns results_dict {'boxes': [[box dicts]], 'seg_preds': ...} like predictor.predict_patient."""
+    from . import distributed as mdist
+    from .utils.dataloader_utils import get_patch_crop_coords
+    dim = cf.dim
+    assert dim == 3, "patch-tiled 3D prediction (2D slices go through merge_2D_to_3D in the reference: out of scope)"
+    dev = net.device_
+    spatial = data.shape[1:]
+    coords = get_patch_crop_coords(np.zeros(spatial, dtype=np.uint8), cf.patch_size)
+    n_patches = coords.shape[0]
+    overlap = np.zeros(spatial, dtype=np.uint8)
+    for pc in coords:
+        overlap[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += 1
+    mine = mdist.shard_indices(n_patches)
+    rows = []
+    seg_sum = np.zeros(spatial, dtype=np.float16) if with_seg else None
+    for i in range(0, len(mine), cf.batch_size):
+        chunk = mine[i:i + cf.batch_size]
+        patches = np.stack([data[:, coords[p][0]:coords[p][1], coords[p][2]:coords[p][3], coords[p][4]:coords[p][5]] for p in chunk])
+        batch = {"data": patches.astype(np.float32)}
+        if amp_dtype is not None:
+            with torch.autocast("cuda", dtype=amp_dtype):
+                res = net.test_forward(batch, return_masks=False) if "return_masks" in net.test_forward.__code__.co_varnames else net.test_forward(batch)
+        else:
+            res = net.test_forward(batch, return_masks=False) if "return_masks" in net.test_forward.__code__.co_varnames else net.test_forward(batch)
+        for k, p in enumerate(chunk):
+            pc = coords[p]
+            if with_seg:
+                seg_sum[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += res["seg_preds"][k][0]
+            for box in res["boxes"][k]:
+                if box["box_type"] != "det":
+                    continue
+                c = np.asarray(box["box_coords"], dtype=np.float64)
+                fac = box_patch_center_factor(c, cf.patch_size)
+                c = c + np.array([pc[0], pc[2], pc[0], pc[2], pc[4], pc[4]])
+                rows.append(list(c) + [float(box["box_score"]), float(box["box_pred_class_id"]), fac, float(p)])
+    local = torch.tensor(rows, dtype=torch.float64, device=dev).view(-1, 10)
+    allrows = mdist.gather_rows(local).cpu().numpy()
+    out_boxes = []
+    if allrows.shape[0] > 0:
+        # overlap count under the box; the reference slices the y axis with x coordinates and vice versa
+        # (predictor.py:434, SURVEY quirk 5) -- reproduced
+        novs = np.zeros(allrows.shape[0])
+        for i, r in enumerate(allrows):
+            ic = [int(np.floor(v)) if ix % 2 == 0 else int(np.ceil(v)) for ix, v in enumerate(r[:6])]
+            region = overlap[ic[1]:ic[3], ic[0]:ic[2], ic[4]:ic[5]]
+            novs[i] = float(np.mean(region)) if region.size else 0.0
+        for cl in sorted(cf.class_dict.keys()):
+            sel = allrows[:, 7] == cl
+            if not sel.any():
+                continue
+            dets = np.concatenate([allrows[sel, :6], allrows[sel, 6:7], allrows[sel, 8:9], novs[sel, None]], 1)
+            pid = np.array(["%s_%s_%d" % (rank_ix, n_aug, int(p)) for p in allrows[sel, 9]])
+            ks, kc = weighted_box_clustering(dets, pid, cf.wcs_iou, n_ens, device=dev)
+            for s, c in zip(ks, kc):
+                out_boxes.append({"box_type": "det", "box_coords": np.array(c), "box_score": s, "box_pred_class_id": cl})
+    res = {"boxes": [out_boxes], "n_patches": n_patches, "n_raw_boxes": int(allrows.shape[0])}
+    if with_seg:
+        m = overlap > 0
+        seg_sum[m] /= overlap[m]
+        res["seg_preds"] = seg_sum[None, None]
+    return res

@@ -82,3 +82,27 @@ def test_refine_detections_group_shift_equals_per_group_nms(cuda):
         idx = np.nonzero(g == k)[0]
         per |= set(idx[nms_gpu(dets[torch.from_numpy(idx).to(cuda)], 1e-5).cpu().numpy()].tolist())
     assert one == per
+
+
+def test_patch_tiled_prediction_with_wbc(cuda):
+    """BASELINE config 5 in miniature: volume -> overlapping patches -> test_forward -> patient coordinates ->
+    weighted box clustering (device); also under bf16 autocast."""
+    from medicaldetectiontoolkit_amd import predictor
+    cf = Configs(dim=3, model="mrcnn", patch_size=[64, 64, 32], batch_size=4)
+    torch.manual_seed(0)
+    net = mrcnn.net(cf, device=cuda)
+    rng = np.random.default_rng(0)
+    vol = rng.standard_normal((1, 100, 90, 48)).astype(np.float32)
+    res = predictor.predict_patient(net, vol, cf, n_ens=1)
+    from medicaldetectiontoolkit_amd.utils.dataloader_utils import get_patch_crop_coords
+    n_expected = get_patch_crop_coords(vol[0], cf.patch_size).shape[0]
+    assert res["n_patches"] == n_expected and n_expected > 4
+    assert len(res["boxes"]) == 1 and len(res["boxes"][0]) <= res["n_raw_boxes"]
+    for b in res["boxes"][0]:
+        c = b["box_coords"]
+        assert len(c) == 6 and 0 < b["box_score"] <= 1.0 + 1e-9 and b["box_pred_class_id"] in (1, 2)
+        assert c[0] >= -1 and c[2] <= 101 and c[1] >= -1 and c[3] <= 91 and c[4] >= -1 and c[5] <= 49
+    res16 = predictor.predict_patient(net, vol, cf, n_ens=1, amp_dtype=torch.bfloat16)
+    assert res16["n_patches"] == n_expected
+    f = predictor.box_patch_center_factor([0, 0, 64, 64, 0, 32], [64, 64, 32])
+    assert abs(f - 1.0) < 1e-12                     # box centred in the patch -> factor 1
