@@ -475,6 +475,12 @@ class net(nn.Module):
         self.classifier = Classifier(self.cf, conv)
         self.mask = Mask(self.cf, conv)
         self.to(self.device_)
+        # optional NDHWC ("channels last") weights/activations for the MIOpen/CK conv path: removes the
+        # NCDHW<->NDHWC transposes CK's grouped-conv kernels otherwise insert
+        self.memory_format = None
+        if getattr(self.cf, "channels_last", False):
+            self.memory_format = torch.channels_last_3d if self.cf.dim == 3 else torch.channels_last
+            self.to(memory_format=self.memory_format)
 
     @property
     def np_anchors(self):
@@ -485,6 +491,8 @@ class net(nn.Module):
         """mrcnn.py:987-1050."""
         cf = self.cf
         B = img.shape[0]
+        if self.memory_format is not None:
+            img = img.contiguous(memory_format=self.memory_format)
         fpn_outs = self.fpn(img)
         rpn_feature_maps = [fpn_outs[i] for i in cf.pyramid_levels]
         self.mrcnn_feature_maps = rpn_feature_maps
@@ -537,8 +545,11 @@ class net(nn.Module):
         gt_boxes = batch["bb_target"]
         B = img.shape[0]
         # GT masks of all elements stacked [sum_G, 1, Y, X, (Z)] (uint8 over PCIe, float on the device)
-        masks_list = [torch.as_tensor(np.ascontiguousarray(m)) for m in batch["roi_masks"] if len(m) > 0]
-        gt_masks = torch.cat(masks_list, 0).to(dev, non_blocking=True) if masks_list else None
+        if "roi_masks_device" in batch:          # already resident in HBM (utils.synthetic_data.to_device)
+            gt_masks = batch["roi_masks_device"]
+        else:
+            masks_list = [torch.as_tensor(np.ascontiguousarray(m)) for m in batch["roi_masks"] if len(m) > 0]
+            gt_masks = torch.cat(masks_list, 0).to(dev, non_blocking=True) if masks_list else None
 
         rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(img)
         (mrcnn_class_logits, mrcnn_pred_deltas, mrcnn_pred_mask, target_class_ids, mrcnn_target_deltas, target_mask,

@@ -205,7 +205,8 @@ class net(nn.Module):
         loss = batch_class_loss + batch_bbox_loss
         seg_dice = seg_ce = None
         if seg_logits is not None:
-            var_seg = torch.from_numpy(np.ascontiguousarray(batch["seg"])).to(dev, non_blocking=True).long()
+            var_seg = (batch["seg"].to(dev) if torch.is_tensor(batch["seg"]) else
+                       torch.from_numpy(np.ascontiguousarray(batch["seg"])).to(dev, non_blocking=True)).long()
             ohe = F.one_hot(var_seg[:, 0], cf.num_seg_classes).movedim(-1, 1).float()
             seg_dice = 1 - batch_dice(F.softmax(seg_logits, dim=1), ohe)
             seg_ce = F.cross_entropy(seg_logits, var_seg[:, 0])

@@ -46,3 +46,16 @@ def make_batch(patch_size, batch_size, seed=0, max_objects=3, radius=(4, 12), n_
         class_target.append([l - 1 for l in labels])
     return {"data": data, "seg": seg, "pid": ["synthetic_%d_%d" % (seed, b) for b in range(batch_size)],
             "class_target": class_target, "bb_target": bb_target, "roi_labels": roi_labels, "roi_masks": roi_masks}
+
+
+def to_device(batch, device):
+    """Upload the bulky entries of a batch dict once (image, stacked GT masks, seg); box lists stay host numpy.
+    train_forward accepts the result unchanged ('data' may be a device tensor; 'roi_masks_device' = GT masks of
+    all elements stacked [sum_G, 1, Y, X, (Z)] uint8)."""
+    import torch
+    out = dict(batch)
+    out["data"] = torch.from_numpy(np.ascontiguousarray(batch["data"])).to(device)
+    masks = [torch.from_numpy(np.ascontiguousarray(m)) for m in batch["roi_masks"] if len(m) > 0]
+    out["roi_masks_device"] = torch.cat(masks, 0).to(device) if masks else None
+    out["seg"] = torch.from_numpy(np.ascontiguousarray(batch["seg"])).to(device)
+    return out
