@@ -165,30 +165,40 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_pass1_kernel(
     }
 }
 
-// pass 2 (one block): reduce partials per GT, then apply step 2 (model_utils.py:556-559)
+// pass 2 (one block): reduce partials per GT (all threads), then apply step 2 (model_utils.py:556-559)
 // in GT order, not overriding step-3 positives (:562-563 runs after step 2).
 __global__ __launch_bounds__(256) void match_pass2_kernel(
     const double *__restrict__ part_val, const int *__restrict__ part_idx, int n_blocks, int G,
     const int *__restrict__ gt_cls, double pos_thresh, const double *__restrict__ iou_max,
     int *__restrict__ matches, int *__restrict__ gt_best)
 {
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    __shared__ double s_v[4];
+    __shared__ int s_i[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int g = 0; g < G; ++g) {
         double bv = -1.0;
         int bi = 0x7fffffff;
-        for (int b = 0; b < n_blocks; ++b) {
+        for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
             const double v = part_val[(size_t)b * G + g];
             const int i = part_idx[(size_t)b * G + g];
             if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
         }
-        gt_best[g] = bi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int g = 0; g < G; ++g) {
-            const int a = gt_best[g];
-            if (a == 0x7fffffff) continue;
-            if (!(iou_max[a] >= pos_thresh)) matches[a] = gt_cls ? gt_cls[g] : 1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_down(bv, off);
+            const int oi = __shfl_down(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
+        if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
+            gt_best[g] = bi;
+            // step 2 (model_utils.py:556-559) in GT order; step-3 positives (:562-563) are not overridden
+            if (bi != 0x7fffffff && !(iou_max[bi] >= pos_thresh)) matches[bi] = gt_cls ? gt_cls[g] : 1;
+        }
+        __syncthreads();
     }
 }
 

@@ -974,6 +974,119 @@ inline int check_launch()
     return MDT_ERR_LAUNCH_FAILED;
 }
 
+// Forward, LDS-staged form: one workgroup per (RoI, channel group).  The RoI's bounding sub-box of the feature
+// map (rows along the contiguous axis) is staged in LDS with coalesced loads, one channel at a time, and all
+// ch*cw*cd outputs of that channel are interpolated from LDS: each feature voxel is read from global memory once
+// per RoI instead of up to 8 times through scattered 4-byte gathers.  Same arithmetic (bit-exact) as
+// crop_fwd_kernel.  NOT the default: it measured slower than the direct gather (see launch_fwd).
+constexpr int FWDS_THREADS = 256;
+constexpr int FWDS_BOX_FLOATS = 6144;   // 24 KB sub-box budget
+
+template <int DIM>
+__global__ __launch_bounds__(FWDS_THREADS) void crop_fwd_staged_kernel(
+    const float *__restrict__ image, const float *__restrict__ boxes,
+    const int *__restrict__ box_ind, int B, int H, int W, int D,
+    int ch, int cw, int cd, int C, int ch_per_wg, float *__restrict__ crops)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *sbox = reinterpret_cast<float *>(smem_raw);                      // [FWDS_BOX_FLOATS]
+    AxisEntry *tab = reinterpret_cast<AxisEntry *>(sbox + FWDS_BOX_FLOATS);  // [ch + cw + cd]
+    __shared__ int s_ext[8];                                                 // ylo, ny, xlo, nx, zlo, nz, fits
+
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int P = ch * cw * cd;
+    const int c0 = blockIdx.y * ch_per_wg;
+    const int c1 = min(C, c0 + ch_per_wg);
+    const int b_in = box_ind[n];
+    float *out = crops + ((long long)n * C + c0) * P;
+    if (b_in < 0 || b_in >= B) {
+        for (int e = tid; e < (c1 - c0) * P; e += FWDS_THREADS) out[e] = 0.0f;
+        return;
+    }
+    const float *bx = boxes + (long long)n * (2 * DIM);
+    for (int t = tid; t < ch + cw + cd; t += FWDS_THREADS) {
+        AxisEntry e;
+        if (t < ch) e = axis_entry(bx[0], bx[2], H, ch, t);
+        else if (t < ch + cw) e = axis_entry(bx[1], bx[3], W, cw, t - ch);
+        else {
+            if (DIM == 3) e = axis_entry(bx[4], bx[5], D, cd, t - ch - cw);
+            else { e.lo = 0; e.lerp = 0.0f; }
+        }
+        tab[t] = e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+        const int off[3] = {0, ch, ch + cw}, np_[3] = {ch, cw, cd};
+        for (int a = 0; a < 3; ++a)
+            for (int q = 0; q < np_[a]; ++q) { lo[a] = min(lo[a], tab[off[a] + q].lo); hi[a] = max(hi[a], entry_hi(tab[off[a] + q])); }
+        s_ext[0] = lo[0]; s_ext[1] = hi[0] - lo[0] + 1;
+        s_ext[2] = lo[1]; s_ext[3] = hi[1] - lo[1] + 1;
+        s_ext[4] = lo[2]; s_ext[5] = hi[2] - lo[2] + 1;
+        s_ext[6] = ((long long)s_ext[1] * s_ext[3] * s_ext[5] <= FWDS_BOX_FLOATS) ? 1 : 0;
+    }
+    __syncthreads();
+    const int ylo = s_ext[0], ny = s_ext[1], xlo = s_ext[2], nx = s_ext[3], zlo = s_ext[4], nz = s_ext[5];
+    const bool fits = s_ext[6] != 0;
+    const long long vol = (long long)H * W * D;
+    const int nbox = ny * nx * nz;
+
+    for (int c = c0; c < c1; ++c) {
+        const float *pimage = image + ((long long)b_in * C + c) * vol;
+        if (fits) {
+            __syncthreads();   // previous channel's reads of sbox are done
+            for (int t = tid; t < nbox; t += FWDS_THREADS) {
+                const int z = t % nz;
+                const int r = t / nz;
+                const int x = r % nx;
+                const int y = r / nx;
+                sbox[t] = pimage[((long long)(ylo + y) * W + (xlo + x)) * D + (zlo + z)];
+            }
+            __syncthreads();
+        }
+        float *o = crops + ((long long)n * C + c) * P;
+        for (int e = tid; e < P; e += FWDS_THREADS) {
+            int idx = e, z = 0;
+            if (DIM == 3) { z = idx % cd; idx /= cd; }
+            const int x = idx % cw;
+            const int y = idx / cw;
+            const AxisEntry ey = tab[y], ex = tab[ch + x];
+            const int top = ey.lo, bottom = entry_hi(ey), left = ex.lo, right = entry_hi(ex);
+            int front = 0, back = 0;
+            float zl = 0.0f;
+            if (DIM == 3) { const AxisEntry ez = tab[ch + cw + z]; front = ez.lo; back = entry_hi(ez); zl = ez.lerp; }
+            float tlf, trf, blf, brf, tlb, trb, blb, brb;
+            if (fits) {
+                const int t_ = (top - ylo) * nx, b_ = (bottom - ylo) * nx, l_ = left - xlo, r_ = right - xlo;
+                const int f_ = front - zlo, k_ = back - zlo;
+                tlf = sbox[(t_ + l_) * nz + f_]; trf = sbox[(t_ + r_) * nz + f_];
+                blf = sbox[(b_ + l_) * nz + f_]; brf = sbox[(b_ + r_) * nz + f_];
+                tlb = sbox[(t_ + l_) * nz + k_]; trb = sbox[(t_ + r_) * nz + k_];
+                blb = sbox[(b_ + l_) * nz + k_]; brb = sbox[(b_ + r_) * nz + k_];
+            } else {
+                const long long rt_l = (long long)D * (left + (long long)W * top), rt_r = (long long)D * (right + (long long)W * top);
+                const long long rb_l = (long long)D * (left + (long long)W * bottom), rb_r = (long long)D * (right + (long long)W * bottom);
+                tlf = pimage[front + rt_l]; trf = pimage[front + rt_r]; blf = pimage[front + rb_l]; brf = pimage[front + rb_r];
+                tlb = pimage[back + rt_l]; trb = pimage[back + rt_r]; blb = pimage[back + rb_l]; brb = pimage[back + rb_r];
+            }
+            if (DIM == 3) {
+                const float top_front = tlf + (trf - tlf) * ex.lerp;
+                const float bottom_front = blf + (brf - blf) * ex.lerp;
+                const float top_back = tlb + (trb - tlb) * ex.lerp;
+                const float bottom_back = blb + (brb - blb) * ex.lerp;
+                const float frontv = top_front + (bottom_front - top_front) * ey.lerp;
+                const float backv = top_back + (bottom_back - top_back) * ey.lerp;
+                o[e] = frontv + (backv - frontv) * zl;
+            } else {
+                const float topv = tlf + (trf - tlf) * ex.lerp;
+                const float bottomv = blf + (brf - blf) * ex.lerp;
+                o[e] = topv + (bottomv - topv) * ey.lerp;
+            }
+        }
+    }
+}
+
 template <int DIM>
 int launch_fwd(const float *image, const float *boxes, const int *box_ind, int N, int B,
                int H, int W, int D, int ch, int cw, int cd, int C, float *crops, hipStream_t s)
@@ -983,12 +1096,32 @@ int launch_fwd(const float *image, const float *boxes, const int *box_ind, int N
     const long long per_roi = (long long)C * ch * cw * cd;
     if (N == 0 || per_roi == 0) return MDT_OK;
     if (per_roi > 0x7fffffffLL) return MDT_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)(ch + cw + cd) * sizeof(AxisEntry);
-    if (lds > 60 * 1024) return MDT_ERR_UNSUPPORTED;
+    const size_t tab_bytes = (size_t)(ch + cw + cd) * sizeof(AxisEntry);
+    if (tab_bytes > 24 * 1024) return MDT_ERR_UNSUPPORTED;
+    // Measured on MI355X (profiles/r01_microbench.jsonl): the direct gather wins at every reference shape
+    // (N=600 (7,7,3): 35 vs 58 us; N=240 (14,14,5): 56 vs 73 us) -- L1/L2 absorb the corner re-reads and the staged
+    // form pays two barriers per channel -- so direct is the default; MDT_FWD_KERNEL=staged selects the other.
+    const char *force = getenv("MDT_FWD_KERNEL");
+    const bool direct = !(force && force[0] == 's');
+    if (!direct) {
+        // channels per workgroup: enough workgroups to fill the chip, but amortise the table build
+        int cpw = (int)(((long long)N * C + 4095) / 4096);
+        if (cpw < 1) cpw = 1;
+        if (cpw > C) cpw = C;
+        const int gy = (C + cpw - 1) / cpw;
+        if (gy <= 65535) {
+            const size_t lds = (size_t)FWDS_BOX_FLOATS * sizeof(float) + tab_bytes;
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(crop_fwd_staged_kernel<DIM>, dim3((unsigned)N, (unsigned)gy), dim3(FWDS_THREADS), lds, s,
+                               image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, cpw, crops);
+            return check_launch();
+        }
+    }
     const long long slabs = (per_roi + FWD_SLAB - 1) / FWD_SLAB;
     if (slabs > 65535) return MDT_ERR_UNSUPPORTED;
     dim3 grid((unsigned)N, (unsigned)slabs);
-    (void)hipGetLastError(); hipLaunchKernelGGL(crop_fwd_kernel<DIM>, grid, dim3(FWD_THREADS), lds, s,
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(crop_fwd_kernel<DIM>, grid, dim3(FWD_THREADS), tab_bytes, s,
                        image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, crops);
     return check_launch();
 }

@@ -293,3 +293,16 @@ def test_nms_worst_case_50000(cuda):
     dets = nms_boxes(rng, 50000)
     got = nms_3D(_t(dets, cuda), 1e-5).cpu().numpy()
     assert np.array_equal(got, oracle.gpu_nms(dets, 1e-5, True))
+
+
+def test_roialign3d_forward_staged_variant_bitexact(cuda, monkeypatch):
+    """The LDS-staged forward (selectable with MDT_FWD_KERNEL=staged) computes the same bits as the direct one."""
+    rng = np.random.default_rng(21)
+    image = rng.normal(size=(3, 5, 16, 16, 32)).astype(np.float32)
+    boxes = random_boxes_3d(rng, 40, spill=True)
+    boxes[0] = [0.0, 0.0, 1.0, 1.0, 0.0, 1.0]           # whole volume: does not fit the LDS budget -> direct reads
+    box_ind = rng.integers(-1, 3, size=40).astype(np.int32)
+    want = oracle.crop_and_resize_forward(image, boxes, box_ind, (7, 7, 3))
+    monkeypatch.setenv("MDT_FWD_KERNEL", "staged")
+    got = _roi_align_impl.crop_forward(_t(image, cuda), _t(boxes, cuda), _t(box_ind, cuda), (7, 7, 3))
+    assert np.array_equal(got.cpu().numpy(), want)

@@ -79,8 +79,13 @@ def main():
             if N <= 48:
                 report("roialign3d_bwd_atomic_" + tag,
                        timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="atomic"), args.iters), bwd_bytes)
-            report("roialign3d_fwd_" + tag,
+            os.environ["MDT_FWD_KERNEL"] = "staged"
+            report("roialign3d_fwd_staged_" + tag,
                    timeit(lambda: _roi_align_impl.crop_forward(image, boxes, box_ind, crop), args.iters), fwd_bytes)
+            os.environ["MDT_FWD_KERNEL"] = "direct"
+            report("roialign3d_fwd_direct_" + tag,
+                   timeit(lambda: _roi_align_impl.crop_forward(image, boxes, box_ind, crop), args.iters), fwd_bytes)
+            os.environ.pop("MDT_FWD_KERNEL")
             if refra is not None and N <= 600:
                 out = torch.empty(shape, device=dev)
 
