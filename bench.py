@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--patch", type=str, default="128,128,128")
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--model", type=str, default="mrcnn", choices=["mrcnn", "retina_unet"],
+                    help="mrcnn = BASELINE config 3 (headline); retina_unet = config 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", type=int, default=1)
     ap.add_argument("--host-batches", action="store_true", help="hand numpy batches to train_forward (PCIe-inclusive rate)")
@@ -95,16 +97,16 @@ def main():
     from medicaldetectiontoolkit_amd import training
     from medicaldetectiontoolkit_amd.configs import Configs
     from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
-    from medicaldetectiontoolkit_amd.models import mrcnn
+    from medicaldetectiontoolkit_amd.models import mrcnn, retina_unet
     from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch, to_device
 
     # MIOpen's immediate-mode heuristics pick naive 3D solvers for the 18/36/72-channel convolutions of this
     # backbone (3.2 s per step); the exhaustive find selects im2col+GEMM / CK kernels (42x faster, profiles/).
     torch.backends.cudnn.benchmark = True
     patch = [int(v) for v in args.patch.split(",")]
-    cf = Configs(dim=3, model="mrcnn", patch_size=patch, batch_size=args.batch, channels_last=bool(args.channels_last))
+    cf = Configs(dim=3, model=args.model, patch_size=patch, batch_size=args.batch, channels_last=bool(args.channels_last))
     torch.manual_seed(0)          # identical initial weights on every rank
-    net = mrcnn.net(cf, device=dev)
+    net = (mrcnn if args.model == "mrcnn" else retina_unet).net(cf, device=dev)
     torch.manual_seed(1000 + rank)
     opt = training.build_optimizer(net, cf)
     sync = training.FlatGradAllReduce(net) if world > 1 else None
@@ -154,18 +156,18 @@ def main():
                         "alg_bytes_per_launch": int(np.mean(byts)), "avg_us": round(float(np.mean(dur)) * 1e6, 2), "launches": len(recs),
                         "mean_rois_on_level": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "mrcnn":
             try:
                 cpu = cpu_baseline(cf)
             except Exception as e:  # the baseline must never take the bench line down
                 cpu = {"value": None, "unit": "patches/s", "cores": int(torch.get_num_threads()), "kind": "port", "sample": "failed: %r" % (e,)}
         patches = args.batch * world * args.steps
         out = {
-            "metric": "3D patches/sec (train), 128^3 Mask R-CNN", "value": round(patches / elapsed, 3), "unit": "patches/s",
+            "metric": "3D patches/sec (train), 128^3 %s" % ("Mask R-CNN" if args.model == "mrcnn" else "Retina U-Net"), "value": round(patches / elapsed, 3), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host numpy batches, PCIe inclusive)" if args.host_batches else " (resident in HBM)"),
-            "config": {"workload": "LIDC-shape 3D Mask R-CNN (3D RoIAlign + 3D NMS), %s fp32 patches, batch %d per GPU, random-init weights, "
-                                   "Adam lr 1e-4" % ("x".join(map(str, patch)), args.batch),
+            "config": {"workload": "LIDC-shape 3D %s, %s fp32 patches, batch %d per GPU, random-init weights, Adam lr 1e-4" % (
+                           "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),
                        "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over RCCL)" % world,
                        "global_batch": args.batch * world},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -11,11 +11,11 @@
 //     the row box is broadcast with v_readlane and one __ballot per row IS the
 //     u64 mask word.  Only blocks on/above the diagonal are computed.
 //   * scan kernel: one workgroup per problem.  Wave 0 resolves a 64-box block
-//     entirely in registers (ffs over the not-yet-removed bits, v_readlane of the
-//     diagonal words); all waves then OR the kept rows' remaining mask words
-//     into the `removed` bitmap held in LDS.  Blocks that are already fully
-//     removed cost no memory traffic; an optional max_keep stops the scan early
-//     (the RPN keeps only the first 75-500 boxes, models/mrcnn.py:348).
+//     with a parallel, ballot-based greedy pass over the block's symmetric
+//     overlap words; all waves then OR the kept rows' remaining mask words
+//     (prefetched one block ahead) into the `removed` bitmap held in LDS.  An
+//     optional max_keep stops the scan early (the RPN keeps only the first
+//     75-500 boxes, models/mrcnn.py:348).
 //   Nothing is copied to the host and no memory is allocated.
 // Compiled with -ffp-contract=off so the IoU rounds like the uncontracted oracle
 // (the denominator Sa + Sb - interS would otherwise be contracted).
@@ -104,7 +104,11 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
         for (int q = 0; q < STRIDE - 1; ++q) a.c[q] = bcast(rowb.c[q], i);
         const float v = box_iou<STRIDE>(a, colb);  // a = current (row) box, b = column box
         bool pred = (rule == MDT_NMS_RULE_GT) ? (v > thresh) : (v >= thresh);
-        pred = pred && (col_idx < n) && (col_idx > row_start * 64 + i);
+        // public (row-major) mask: strictly-upper bits only, like the reference.  Internal block-major mask:
+        // diagonal blocks hold the SYMMETRIC relation (the IoU is bitwise symmetric), which lets the scan kernel
+        // resolve a block with ballots instead of a 64-step serial loop.
+        const int row_g = row_start * 64 + i;
+        pred = pred && (col_idx < n) && (block_major ? (col_idx != row_g) : (col_idx > row_g));
         const u64 bal = __ballot(pred);
         if (lane == i) word = bal;
     }
@@ -116,14 +120,36 @@ constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_WAVES = SCAN_THREADS / 64;
 constexpr int SCAN_PF = 6;   // column words prefetched per lane before the resolve (covers n <= 6208 in one round)
 
-__device__ __forceinline__ u64 bcast64(u64 v, int src_lane)
+
+// grid: batch; block: SCAN_THREADS; dynamic LDS: col_blocks * 8 bytes.  mask is block-major with symmetric
+// diagonal blocks.
+//
+// Per 64-box row block k:
+//   * the words this workgroup will need (diagonal + the later column blocks of row block k) were prefetched
+//     one iteration earlier -- they depend on nothing -- so their latency hides behind block k-1;
+//   * wave 0 resolves the block with a PARALLEL greedy pass: lane i holds the set of earlier boxes of the block
+//     that overlap it; each round, a still-undecided box is removed if a kept earlier box overlaps it, kept if no
+//     undecided earlier box overlaps it (two ballots per round; the fixed point is exactly the sequential greedy
+//     result, reached in as many rounds as the longest dependency chain, typically 2-6);
+//   * all 16 waves OR the kept rows' later words into the LDS `removed` bitmap (ds_or_b64).
+struct ScanRow {
+    u64 pre[SCAN_PF];
+    u64 diag;
+};
+
+__device__ __forceinline__ ScanRow scan_load(const u64 *__restrict__ mask, int k, int col_blocks, int wave, int lane)
 {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffULL), src_lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src_lane);
-    return ((u64)hi << 32) | (u64)lo;
+    ScanRow r;
+    const u64 *rowblk = mask + (long long)k * col_blocks * 64;
+#pragma unroll
+    for (int q = 0; q < SCAN_PF; ++q) {
+        const int j = k + 1 + wave + SCAN_WAVES * q;
+        r.pre[q] = (j < col_blocks) ? rowblk[(long long)j * 64 + lane] : 0ULL;
+    }
+    r.diag = (wave == 0) ? rowblk[(long long)k * 64 + lane] : 0ULL;
+    return r;
 }
 
-// grid: batch; block: SCAN_THREADS; dynamic LDS: col_blocks * 8 bytes.  mask is block-major.
 __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
     const u64 *__restrict__ mask, int n, int max_keep,
     long long *__restrict__ keep, int keep_stride, int *__restrict__ num_out)
@@ -143,35 +169,42 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
 
     for (int j = tid; j < col_blocks; j += SCAN_THREADS) remv[j] = 0ULL;
     if (tid == 0) { s_kept = 0ULL; s_nkept = 0; }
+    ScanRow cur = scan_load(mask, 0, col_blocks, wave, lane);
     __syncthreads();
 
     int nkept = 0;
     for (int k = 0; k < col_blocks; ++k) {
+        ScanRow nxt;
+        // prefetch the next row block unless it is ALREADY fully removed (bits only ever get set, so it stays dead)
+        bool want_next = false;
+        if (k + 1 < col_blocks) {
+            const int rows_next = min(n - (k + 1) * 64, 64);
+            const u64 valid_next = (rows_next == 64) ? ~0ULL : ((1ULL << rows_next) - 1ULL);
+            want_next = (~remv[k + 1] & valid_next) != 0ULL;
+        }
+        if (want_next) nxt = scan_load(mask, k + 1, col_blocks, wave, lane);
+        else {
+#pragma unroll
+            for (int q = 0; q < SCAN_PF; ++q) nxt.pre[q] = 0ULL;
+            nxt.diag = 0ULL;
+        }
         const int rows_here = min(n - k * 64, 64);
         const u64 valid = (rows_here == 64) ? ~0ULL : ((1ULL << rows_here) - 1ULL);
-        u64 r = remv[k];
-        if ((~r & valid) == 0ULL) continue;  // block already fully removed (uniform: LDS value after a barrier)
-
-        // every wave prefetches "its" later column words of this row block; they do not depend on
-        // which rows end up kept, so the loads fly while wave 0 resolves the block.
-        const u64 *rowblk = mask + (long long)k * col_blocks * 64;
-        u64 pre[SCAN_PF];
-#pragma unroll
-        for (int q = 0; q < SCAN_PF; ++q) {
-            const int j = k + 1 + wave + SCAN_WAVES * q;
-            pre[q] = (j < col_blocks) ? rowblk[(long long)j * 64 + lane] : 0ULL;
-        }
+        const u64 r = remv[k];
+        if ((~r & valid) == 0ULL) { cur = nxt; continue; }   // block already fully removed (uniform)
 
         if (wave == 0) {
-            const u64 d = rowblk[(long long)k * 64 + lane];   // diagonal words (rows >= n hold 0)
+            const u64 lower = cur.diag & ((1ULL << lane) - 1ULL);   // earlier boxes of this block overlapping box `lane`
+            u64 undecided = ~r & valid;
             u64 kept = 0ULL;
-            u64 cand = ~r & valid;
-            while (cand) {
-                const int i = __ffsll((long long)cand) - 1;
-                kept |= 1ULL << i;
-                r |= bcast64(d, i);
-                const u64 above = (i == 63) ? 0ULL : (~0ULL << (i + 1));
-                cand = ~r & valid & above;
+            while (undecided) {
+                const bool mine = (undecided >> lane) & 1ULL;
+                const bool killed = mine && (lower & kept) != 0ULL;
+                const bool safe = mine && !killed && (lower & undecided) == 0ULL;
+                const u64 k_new = __ballot(safe);
+                const u64 r_new = __ballot(killed);
+                kept |= k_new;
+                undecided &= ~(k_new | r_new);
             }
             if ((kept >> lane) & 1ULL) {
                 const int pos = nkept + __popcll(kept & ((1ULL << lane) - 1ULL));
@@ -188,9 +221,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
 #pragma unroll
         for (int q = 0; q < SCAN_PF; ++q) {
             const int j = k + 1 + wave + SCAN_WAVES * q;
-            if (mine && pre[q] != 0ULL) atomicOr(&remv[j], pre[q]);
+            if (mine && cur.pre[q] != 0ULL) atomicOr(&remv[j], cur.pre[q]);
         }
         // columns beyond the prefetch window (large n), 4 loads in flight per lane
+        const u64 *rowblk = mask + (long long)k * col_blocks * 64;
         for (int j0 = k + 1 + SCAN_WAVES * SCAN_PF + wave; j0 < col_blocks; j0 += 4 * SCAN_WAVES) {
             u64 w[4];
 #pragma unroll
@@ -203,6 +237,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
                 if (w[q] != 0ULL) atomicOr(&remv[j0 + q * SCAN_WAVES], w[q]);
         }
         __syncthreads();
+        cur = nxt;
     }
 
     const int nout = min(nkept, limit);

@@ -161,6 +161,10 @@ class net(nn.Module):
         if self.cf.model == "retina_unet":
             self.final_conv = conv(self.cf.end_filts, self.cf.num_seg_classes, ks=1, pad=0, norm=None, relu=None)
         self.to(self.device_)
+        self.memory_format = None
+        if getattr(self.cf, "channels_last", False):
+            self.memory_format = torch.channels_last_3d if self.cf.dim == 3 else torch.channels_last
+            self.to(memory_format=self.memory_format)
 
     @property
     def np_anchors(self):
@@ -168,6 +172,8 @@ class net(nn.Module):
 
     def forward(self, img):
         """retina_unet.py:477-513."""
+        if self.memory_format is not None:
+            img = img.contiguous(memory_format=self.memory_format)
         fpn_outs = self.Fpn(img)
         off = 1 if self.cf.operate_stride1 else 0
         seg_logits = self.final_conv(fpn_outs[0]) if self.cf.model == "retina_unet" else None

@@ -31,6 +31,16 @@ fns = {
     "nms6000": lambda: _nms_impl.nms_sorted(ds, 0.7, 3),
     "nms6000_keep75": lambda: _nms_impl.nms_sorted(ds, 0.7, 3, max_keep=75),
 }
-for _ in range(iters):
-    fns[case]()
-torch.cuda.synchronize()
+if case == "pmc_bwd":
+    # calibration dispatches (known byte count: plain 151 MB fill) followed by the op under test
+    out = torch.empty(shape, device=dev)
+    for _ in range(iters):
+        out.zero_()
+    torch.cuda.synchronize()
+    for _ in range(iters):
+        fns["bwd_fast"]()
+    torch.cuda.synchronize()
+else:
+    for _ in range(iters):
+        fns[case]()
+    torch.cuda.synchronize()
