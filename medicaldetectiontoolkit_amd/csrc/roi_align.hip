@@ -614,22 +614,31 @@ __device__ __forceinline__ void expand_role(const FastParams &p, char *smem_raw,
     }
 
     const float *bx = p.boxes + (long long)r * (2 * DIM);
+    int *fl = reinterpret_cast<int *>(R + ((nuy_max + nux_max + nuz_max + 1) & ~1));   // [2][H + W + D] first / last sample per index
+    const int Ltot = p.H + p.W + ((DIM == 3) ? p.D : 0);
     for (int t = tid; t < nwords; t += EXP_THREADS) bits[t] = 0ULL;
+    for (int t = tid; t < Ltot; t += EXP_THREADS) { fl[t] = 32767; fl[Ltot + t] = -1; }
     __syncthreads();
     for (int q = tid; q < psum; q += EXP_THREADS) {
         AxisEntry e;
         u64 *bw;
-        if (q < p.ph) { e = axis_entry(bx[0], bx[2], p.H, p.ph, q); bw = bits; }
-        else if (q < p.ph + p.pw) { e = axis_entry(bx[1], bx[3], p.W, p.pw, q - p.ph); bw = bits + p.wy; }
+        int base, pq;
+        if (q < p.ph) { e = axis_entry(bx[0], bx[2], p.H, p.ph, q); bw = bits; base = 0; pq = q; }
+        else if (q < p.ph + p.pw) { e = axis_entry(bx[1], bx[3], p.W, p.pw, q - p.ph); bw = bits + p.wy; base = p.H; pq = q - p.ph; }
         else {
-            bw = bits + p.wy + p.wx;
+            bw = bits + p.wy + p.wx; base = p.H + p.W; pq = q - p.ph - p.pw;
             if (DIM == 3) e = axis_entry(bx[4], bx[5], p.D, p.pd, q - p.ph - p.pw);
             else { e.lo = 0; e.lerp = 0.0f; }
         }
         tab[q] = e;
-        atomicOr(&bw[e.lo >> 6], 1ULL << (e.lo & 63));
         const int hi = entry_hi(e);
+        atomicOr(&bw[e.lo >> 6], 1ULL << (e.lo & 63));
         atomicOr(&bw[hi >> 6], 1ULL << (hi & 63));
+        if (DIM == 3 || q < p.ph + p.pw) {
+            // first / last sample touching each voxel index: one LDS atomicMin/Max per (sample, floor|ceil)
+            atomicMin(&fl[base + e.lo], pq); atomicMax(&fl[Ltot + base + e.lo], pq);
+            atomicMin(&fl[base + hi], pq);   atomicMax(&fl[Ltot + base + hi], pq);
+        }
     }
     __syncthreads();
     if (tid < 3) {
@@ -644,24 +653,7 @@ __device__ __forceinline__ void expand_role(const FastParams &p, char *smem_raw,
 
     // touched index list U, per-position sample range R; the c-group-0 workgroup also publishes
     // the header and the index -> position tables for phase B.
-    // first/last sample per touched index: one LDS atomicMin/atomicMax per (sample, floor|ceil)
-    int *fl = reinterpret_cast<int *>(R + ((nuy_max + nux_max + nuz_max + 1) & ~1));   // [2][H + W + D]
     {
-        const int Ltot = p.H + p.W + ((DIM == 3) ? p.D : 0);
-        for (int t = tid; t < Ltot; t += EXP_THREADS) { fl[t] = 32767; fl[Ltot + t] = -1; }
-        __syncthreads();
-        for (int q = tid; q < psum; q += EXP_THREADS) {
-            const AxisEntry e = tab[q];
-            int base, pq;
-            if (q < p.ph) { base = 0; pq = q; }
-            else if (q < p.ph + p.pw) { base = p.H; pq = q - p.ph; }
-            else { base = p.H + p.W; pq = q - p.ph - p.pw; }
-            if (DIM == 2 && q >= p.ph + p.pw) continue;
-            const int hi = entry_hi(e);
-            atomicMin(&fl[base + e.lo], pq); atomicMax(&fl[Ltot + base + e.lo], pq);
-            atomicMin(&fl[base + hi], pq);   atomicMax(&fl[Ltot + base + hi], pq);
-        }
-        __syncthreads();
         const int L[3] = {p.H, p.W, (DIM == 3) ? p.D : 1};
         const int woff[3] = {0, p.wy, p.wy + p.wx};
         const int uoff[3] = {0, nuy_max, nuy_max + nux_max};
@@ -1240,7 +1232,9 @@ int launch_bwd_fast(const float *grads, const float *boxes, const int *box_ind, 
     int n_expand = 0, gy = 1;
     p.ch_per_wg = 1;
     if (N > 0) {
-        int cpw = (int)(((long long)N * C + 2047) / 2048);
+        long long wg_target = 2048;
+        { const char *e = getenv("MDT_EXP_WGS"); if (e) wg_target = atoll(e); }
+        int cpw = (int)(((long long)N * C + wg_target - 1) / wg_target);
         if (cpw < 1) cpw = 1;
         if (cpw > C) cpw = C;
         p.ch_per_wg = cpw;

@@ -56,3 +56,40 @@ def test_patch_tiler_matches_reference_golden():
         ps = [int(v) for v in ps.split("x")]
         assert np.array_equal(get_patch_crop_coords(np.zeros(shape, np.uint8), ps), g[k]), k
     assert g["patch_512x512x256_128x128x128"].shape == (75, 6)      # BASELINE config 5 work list
+
+
+def test_state_dict_keys_match_reference_modules():
+    """Checkpoint compatibility: every module has the reference's parameter names and shapes
+    (tests/golden/state_dict_keys.json was produced from the reference's own classes)."""
+    import json
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from medicaldetectiontoolkit_amd.models import backbone, mrcnn, retina_unet
+    from medicaldetectiontoolkit_amd.utils.model_utils import NDConvGenerator
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))
+    for tag, kw in (("mrcnn3d", dict(dim=3, model="mrcnn")), ("mrcnn2d", dict(dim=2, model="mrcnn")),
+                    ("retina_unet3d", dict(dim=3, model="retina_unet")), ("retina_net2d", dict(dim=2, model="retina_net"))):
+        cf = Configs(**kw)
+        conv = NDConvGenerator(cf.dim)
+        if "mrcnn" in tag:
+            mods = {"fpn": backbone.FPN(cf, conv), "rpn": mrcnn.RPN(cf, conv), "classifier": mrcnn.Classifier(cf, conv),
+                    "mask": mrcnn.Mask(cf, conv)}
+        else:
+            mods = {"Fpn": backbone.FPN(cf, conv, operate_stride1=cf.operate_stride1), "Classifier": retina_unet.Classifier(cf, conv),
+                    "BBRegressor": retina_unet.BBRegressor(cf, conv)}
+            if cf.model == "retina_unet":
+                mods["final_conv"] = conv(cf.end_filts, cf.num_seg_classes, ks=1, pad=0, norm=None, relu=None)
+        mine = {p + "." + k: list(v.shape) for p, m in mods.items() for k, v in m.state_dict().items()}
+        assert mine == gold[tag], tag
+    n = sum(int(__import__("numpy").prod(s)) for s in gold["mrcnn3d"].values())
+    assert n == 4937876          # SURVEY section 6: 3D Mask R-CNN parameter count
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under medicaldetectiontoolkit_amd/ may import, load or exec it."""
+    pkg = os.path.join(ROOT, "medicaldetectiontoolkit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for bad in ("import oracle", "from oracle", "libmdt_oracle", "oracle/_ref"):
+                    assert bad not in text, (os.path.join(dirpath, f), bad)
