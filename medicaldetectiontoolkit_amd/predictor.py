@@ -63,10 +63,22 @@ def box_patch_center_factor(box_coords, patch_size):
     return float(np.mean([np.exp(-0.5 * ((bc - pc) / (pc * 0.8)) ** 2) for bc, pc in zip(centres, half)]))
 
 
-def predict_patient(net, data, cf, n_ens=1, amp_dtype=None, rank_ix="0", n_aug="0", with_seg=False):
+def _forward_patches(net, data, coords, chunk_ids, cf, amp_dtype, with_seg):
+    patches = np.stack([data[:, coords[p][0]:coords[p][1], coords[p][2]:coords[p][3], coords[p][4]:coords[p][5]] for p in chunk_ids])
+    batch = {"data": np.ascontiguousarray(patches, dtype=np.float32)}
+    kw = {"return_masks": False} if "return_masks" in net.test_forward.__code__.co_varnames else {}
+    if amp_dtype is not None:
+        with torch.autocast("cuda", dtype=amp_dtype):
+            return net.test_forward(batch, **kw)
+    return net.test_forward(batch, **kw)
+
+
+def predict_patient(net, data, cf, n_ens=None, amp_dtype=None, rank_ix="0", test_aug=False, with_seg=False):
     """data: numpy [C, Y, X, Z] (3D) whole-patient volume.  Tiles it (get_patch_crop_coords), forwards the patches
     of THIS rank in chunks of cf.batch_size, moves boxes to patient coordinates with patch-centre factor and
     overlap count, all_gathers the rows across ranks and consolidates per class with the WBC kernel.
+    test_aug=True adds the reference's three mirrored passes (flip y, flip x, flip both; predictor.py:279-367) with
+    the boxes mirrored back; n_ens defaults to the number of passes (expected predictions per position).
     Returns results_dict {'boxes': [[box dicts]], 'seg_preds': ...} like predictor.predict_patient."""
     from . import distributed as mdist
     from .utils.dataloader_utils import get_patch_crop_coords
@@ -74,34 +86,50 @@ def predict_patient(net, data, cf, n_ens=1, amp_dtype=None, rank_ix="0", n_aug="
     assert dim == 3, "patch-tiled 3D prediction (2D slices go through merge_2D_to_3D in the reference: out of scope)"
     dev = net.device_
     spatial = data.shape[1:]
+    Y, X = spatial[0], spatial[1]
     coords = get_patch_crop_coords(np.zeros(spatial, dtype=np.uint8), cf.patch_size)
     n_patches = coords.shape[0]
     overlap = np.zeros(spatial, dtype=np.uint8)
     for pc in coords:
         overlap[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += 1
-    mine = mdist.shard_indices(n_patches)
+    augs = [(False, False)] + ([(True, False), (False, True), (True, True)] if test_aug else [])
+    if n_ens is None:
+        n_ens = len(augs)
+    # work items = (aug, patch), sharded round-robin over ranks
+    items = [(a, p) for a in range(len(augs)) for p in range(n_patches)]
+    mine = [items[i] for i in mdist.shard_indices(len(items))]
     rows = []
-    seg_sum = np.zeros(spatial, dtype=np.float16) if with_seg else None
-    for i in range(0, len(mine), cf.batch_size):
-        chunk = mine[i:i + cf.batch_size]
-        patches = np.stack([data[:, coords[p][0]:coords[p][1], coords[p][2]:coords[p][3], coords[p][4]:coords[p][5]] for p in chunk])
-        batch = {"data": patches.astype(np.float32)}
-        if amp_dtype is not None:
-            with torch.autocast("cuda", dtype=amp_dtype):
-                res = net.test_forward(batch, return_masks=False) if "return_masks" in net.test_forward.__code__.co_varnames else net.test_forward(batch)
-        else:
-            res = net.test_forward(batch, return_masks=False) if "return_masks" in net.test_forward.__code__.co_varnames else net.test_forward(batch)
-        for k, p in enumerate(chunk):
-            pc = coords[p]
-            if with_seg:
-                seg_sum[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += res["seg_preds"][k][0]
-            for box in res["boxes"][k]:
-                if box["box_type"] != "det":
-                    continue
-                c = np.asarray(box["box_coords"], dtype=np.float64)
-                fac = box_patch_center_factor(c, cf.patch_size)
-                c = c + np.array([pc[0], pc[2], pc[0], pc[2], pc[4], pc[4]])
-                rows.append(list(c) + [float(box["box_score"]), float(box["box_pred_class_id"]), fac, float(p)])
+    seg_sum = np.zeros(spatial, dtype=np.float32) if with_seg else None
+    for a, (fy, fx) in enumerate(augs):
+        ids = [p for (aa, p) in mine if aa == a]
+        if not ids:
+            continue
+        d = data
+        c_a = coords.copy()
+        if fy:      # mirrored image + mirrored crop coordinates (get_mirrored_patch_crops, predictor.py:777-816)
+            d = d[:, ::-1]
+            c_a[:, 0], c_a[:, 1] = Y - coords[:, 1], Y - coords[:, 0]
+        if fx:
+            d = d[:, :, ::-1]
+            c_a[:, 2], c_a[:, 3] = X - coords[:, 3], X - coords[:, 2]
+        for i in range(0, len(ids), cf.batch_size):
+            chunk = ids[i:i + cf.batch_size]
+            res = _forward_patches(net, d, c_a, chunk, cf, amp_dtype, with_seg)
+            for k, p in enumerate(chunk):
+                pc = c_a[p]
+                if with_seg and a == 0:
+                    seg_sum[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += res["seg_preds"][k][0]
+                for box in res["boxes"][k]:
+                    if box["box_type"] != "det":
+                        continue
+                    c = np.asarray(box["box_coords"], dtype=np.float64)
+                    fac = box_patch_center_factor(c, cf.patch_size)
+                    c = c + np.array([pc[0], pc[2], pc[0], pc[2], pc[4], pc[4]])
+                    if fy:
+                        c[0], c[2] = Y - c[2], Y - c[0]
+                    if fx:
+                        c[1], c[3] = X - c[3], X - c[1]
+                    rows.append(list(c) + [float(box["box_score"]), float(box["box_pred_class_id"]), fac, float(a * n_patches + p)])
     local = torch.tensor(rows, dtype=torch.float64, device=dev).view(-1, 10)
     allrows = mdist.gather_rows(local).cpu().numpy()
     out_boxes = []
@@ -111,18 +139,18 @@ def predict_patient(net, data, cf, n_ens=1, amp_dtype=None, rank_ix="0", n_aug="
         novs = np.zeros(allrows.shape[0])
         for i, r in enumerate(allrows):
             ic = [int(np.floor(v)) if ix % 2 == 0 else int(np.ceil(v)) for ix, v in enumerate(r[:6])]
-            region = overlap[ic[1]:ic[3], ic[0]:ic[2], ic[4]:ic[5]]
+            region = overlap[max(ic[1], 0):ic[3], max(ic[0], 0):ic[2], max(ic[4], 0):ic[5]]
             novs[i] = float(np.mean(region)) if region.size else 0.0
         for cl in sorted(cf.class_dict.keys()):
             sel = allrows[:, 7] == cl
             if not sel.any():
                 continue
             dets = np.concatenate([allrows[sel, :6], allrows[sel, 6:7], allrows[sel, 8:9], novs[sel, None]], 1)
-            pid = np.array(["%s_%s_%d" % (rank_ix, n_aug, int(p)) for p in allrows[sel, 9]])
+            pid = np.array(["%s_%d_%d" % (rank_ix, int(q) // n_patches, int(q) % n_patches) for q in allrows[sel, 9]])
             ks, kc = weighted_box_clustering(dets, pid, cf.wcs_iou, n_ens, device=dev)
             for s, c in zip(ks, kc):
                 out_boxes.append({"box_type": "det", "box_coords": np.array(c), "box_score": s, "box_pred_class_id": cl})
-    res = {"boxes": [out_boxes], "n_patches": n_patches, "n_raw_boxes": int(allrows.shape[0])}
+    res = {"boxes": [out_boxes], "n_patches": n_patches, "n_raw_boxes": int(allrows.shape[0]), "n_passes": len(augs)}
     if with_seg:
         m = overlap > 0
         seg_sum[m] /= overlap[m]

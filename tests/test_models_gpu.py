@@ -104,5 +104,11 @@ def test_patch_tiled_prediction_with_wbc(cuda):
         assert c[0] >= -1 and c[2] <= 101 and c[1] >= -1 and c[3] <= 91 and c[4] >= -1 and c[5] <= 49
     res16 = predictor.predict_patient(net, vol, cf, n_ens=1, amp_dtype=torch.bfloat16)
     assert res16["n_patches"] == n_expected
+    # test-time augmentation: 4 mirrored passes, boxes mirrored back into the original frame
+    res_tta = predictor.predict_patient(net, vol, cf, test_aug=True)
+    assert res_tta["n_passes"] == 4 and res_tta["n_raw_boxes"] >= res["n_raw_boxes"]
+    for b in res_tta["boxes"][0]:
+        c = b["box_coords"]
+        assert c[0] >= -1 and c[2] <= 101 and c[1] >= -1 and c[3] <= 91 and c[2] >= c[0] and c[3] >= c[1]
     f = predictor.box_patch_center_factor([0, 0, 64, 64, 0, 32], [64, 64, 32])
     assert abs(f - 1.0) < 1e-12                     # box centred in the patch -> factor 1
