@@ -149,12 +149,22 @@ def main():
             byts = [4.0 * p2_shape[0] * p2_shape[1] * V + 4.0 * int(m["n_valid"].item()) * p2_shape[1] * P + 28.0 * m["n_rows"] for _, m in recs]
             dur = [d for d, _ in recs]
             achieved = float(np.mean(byts)) / float(np.mean(dur))
+            mean_rois = float(np.mean([int(m["n_valid"].item()) for _, m in recs]))
+            # HBM traffic per launch from rocprofv3 PMC passes of this very op (WRITE_SIZE + 2 x FETCH_SIZE, KB;
+            # profiles/r01_pmc/traffic.json, collected with tools/gpu_pmc.sh) -- counters cannot be read inside the bench
+            traffic, traffic_src = None, None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic.json")))
+                key = "no_rois_on_level" if mean_rois < 0.5 else "48_rois_on_level"
+                traffic, traffic_src = tj[key]["hbm_bytes"], "profiles/r01_pmc/traffic.json[%s]" % key
+            except Exception:
+                pass
             roofline = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_BPS, 4), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_BPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "RoIAlign-3D backward, P2 %s, pool %s (expand||zero-fill + patch kernels, op-level)" % (
                             "x".join(map(str, p2_shape)), "x".join(map(str, cf.mask_pool_size))),
                         "alg_bytes_per_launch": int(np.mean(byts)), "avg_us": round(float(np.mean(dur)) * 1e6, 2), "launches": len(recs),
-                        "mean_rois_on_level": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
+                        "mean_rois_on_level": round(mean_rois, 2)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.model == "mrcnn":
             try:

@@ -20,6 +20,8 @@ rng = np.random.default_rng(0)
 shape = (8, 36, 32, 32, 128)
 boxes = torch.from_numpy(random_boxes_3d(rng, N)).to(dev)
 box_ind = torch.from_numpy(rng.integers(0, 8, size=N).astype(np.int32)).to(dev)
+if os.environ.get("MDT_INVALID"):        # all rows routed to other pyramid levels (what the random-init bench sees on P2)
+    box_ind = torch.full_like(box_ind, -1)
 g = torch.randn((N, 36) + crop, device=dev)
 image = torch.randn(shape, device=dev)
 dets = nms_boxes(rng, 6000)
