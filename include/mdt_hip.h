@@ -257,6 +257,21 @@ int mdt_weighted_box_clustering(const double *dets_sorted, const int *patch_ids,
                                 double *out_scores, double *out_coords, int *num_out,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* 2D -> 3D merge of per-slice detections                                     */
+/* ------------------------------------------------------------------------- */
+/*
+ * Replaces nms_2to3D  predictor.py:710-773 (float64).
+ * dets_sorted [n, 6] f64 rows (y1, x1, y2, x2, score, slice_id) sorted by descending score; slice ids are integers in
+ * [0, n_slices).  Outputs: keep [n] i64 = positions in the sorted list of the cluster cores, in creation order;
+ * keep_z [n, 2] f64 = (z1, z2) = (first connected slice - 1, last connected slice + 1); num_out [1] i32 (device).
+ * workspace: mdt_nms_2to3d_workspace_bytes(n).
+ */
+size_t mdt_nms_2to3d_workspace_bytes(int n);
+int mdt_nms_2to3d(const double *dets_sorted, int n, int n_slices, double thresh,
+                  long long *keep, double *keep_z, int *num_out,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,8 @@ _SIGNATURES = {
     "mdt_generate_anchors": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "mdt_anchor_match_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mdt_anchor_match": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_nms_2to3d_workspace_bytes": (c_size_t, [c_int]),
+    "mdt_nms_2to3d": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_wbc_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mdt_weighted_box_clustering": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }

@@ -49,6 +49,53 @@ def weighted_box_clustering(dets, box_patch_id, thresh, n_ens, device=None):
     return list(s.cpu().numpy()), [list(r) for r in c.cpu().numpy()]
 
 
+def nms_2to3D(dets, thresh, device=None):
+    """Drop-in for predictor.nms_2to3D (predictor.py:710-773): dets (n, (y1, x1, y2, x2, score, slice_id)) numpy;
+    returns (keep, keep_z): indices into `dets` of the cluster cores and their [z1, z2] extents.
+    Score ties are ordered "lower index first" (the reference's argsort()[::-1] is unstable)."""
+    dets = np.asarray(dets, dtype=np.float64)
+    n = dets.shape[0]
+    if n == 0:
+        return [], []
+    L = _lib.lib()
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    order = np.argsort(-dets[:, 4], kind="stable")
+    d = torch.from_numpy(np.ascontiguousarray(dets[order])).to(device)
+    n_slices = int(dets[:, 5].max()) + 1
+    keep = torch.empty(n, dtype=torch.int64, device=device)
+    keep_z = torch.empty((n, 2), dtype=torch.float64, device=device)
+    num = torch.zeros(1, dtype=torch.int32, device=device)
+    wsb = L.mdt_nms_2to3d_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        rc = L.mdt_nms_2to3d(_lib.ptr(d), n, n_slices, ctypes.c_double(float(thresh)), _lib.ptr(keep), _lib.ptr(keep_z),
+                             _lib.ptr(num), _lib.ptr(ws), wsb, _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_nms_2to3d")
+    k = int(num.item())
+    return [int(order[j]) for j in keep[:k].cpu().numpy()], [list(z) for z in keep_z[:k].cpu().numpy()]
+
+
+def merge_2D_to_3D_preds_per_patient(in_patient_results_list, class_dict, merge_3D_iou, device=None):
+    """predictor.py:554-593: 2D patient results (slices in the batch dimension) -> 3D results (dummy batch dim 1)."""
+    out = []
+    for cl in list(class_dict.keys()):
+        boxes, slice_ids = [], []
+        for bix, b in enumerate(in_patient_results_list):
+            det = [box for box in b if box["box_type"] == "det" and box["box_pred_class_id"] == cl]
+            boxes += det
+            slice_ids += [bix] * len(det)
+        if not boxes:
+            continue
+        coords = np.array([b["box_coords"] for b in boxes], dtype=np.float64)
+        scores = np.array([b["box_score"] for b in boxes], dtype=np.float64)
+        keep_ix, keep_z = nms_2to3D(np.concatenate((coords, scores[:, None], np.array(slice_ids, dtype=np.float64)[:, None]), axis=1),
+                                    merge_3D_iou, device=device)
+        for kix, kz in zip(keep_ix, keep_z):
+            out.append({"box_type": "det", "box_coords": list(coords[kix]) + kz, "box_score": scores[kix], "box_pred_class_id": cl})
+    out += [box for b in in_patient_results_list for box in b if box["box_type"] == "gt"]
+    return [out]
+
+
 # ----------------------------------------------------------------------------------------------------------
 # patch-tiled prediction of one patient (predictor.py:370-455 spatial_tiling_forward + :458-510
 # batch_tiling_forward + :514-550 apply_wbc_to_patient), patches sharded over ranks

@@ -48,8 +48,7 @@ class FlatGradAllReduce(object):
 
 def train_step(net, optimizer, batch, grad_sync=None, monitor=False):
     """exec.py:68-74: results = net.train_forward(batch); zero_grad; loss.backward(); optimizer.step()."""
-    results = net.train_forward(batch, monitor=monitor) if "monitor" in net.train_forward.__code__.co_varnames \
-        else net.train_forward(batch)
+    results = net.train_forward(batch, monitor=monitor)
     optimizer.zero_grad(set_to_none=True)
     results["torch_loss"].backward()
     if grad_sync is not None:

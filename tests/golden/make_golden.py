@@ -168,6 +168,23 @@ def main():
         out[key + "_scores"] = np.array(ks)
         out[key + "_coords"] = np.array(kc).reshape(len(ks), 2 * dim)
 
+    # ---------------- 2D -> 3D merge ----------------
+    for n, n_obj in ((120, 5), (900, 25)):
+        ctr = rng.uniform(30, 220, size=(n_obj, 2))
+        zc = rng.integers(5, 60, size=n_obj)
+        zr = rng.integers(1, 6, size=n_obj)
+        which = rng.integers(0, n_obj, size=n)
+        c = ctr[which] + rng.normal(0, 1.5, size=(n, 2))
+        sz = rng.uniform(8, 24, size=(n, 2))
+        sl = zc[which] + rng.integers(-8, 9, size=n) * (rng.random(n) < 0.9) * np.minimum(1, zr[which])   # mostly near the core, with holes
+        sl = np.clip(zc[which] + np.round(rng.normal(0, zr[which])).astype(int) + (rng.random(n) < 0.1) * rng.integers(4, 9, size=n), 0, 79)
+        dets = np.stack([c[:, 0] - sz[:, 0] / 2, c[:, 1] - sz[:, 1] / 2, c[:, 0] + sz[:, 0] / 2, c[:, 1] + sz[:, 1] / 2,
+                         rng.permutation(np.linspace(0.05, 0.99, n)), sl.astype(np.float64)], 1)
+        keep, keep_z = ref_predictor.nms_2to3D(dets.copy(), 0.1)
+        out["m2to3_n%d_dets" % n] = dets
+        out["m2to3_n%d_keep" % n] = np.array(keep, dtype=np.int64)
+        out["m2to3_n%d_keep_z" % n] = np.array(keep_z, dtype=np.float64)
+
     # ---------------- patch tiling ----------------
     for shape, ps in (((512, 512, 256), (128, 128, 128)), ((512, 512, 256), (128, 128, 64)), ((300, 260), (128, 128)),
                       ((128, 128, 128), (128, 128, 128)), ((200, 180, 70), (128, 128, 64))):
