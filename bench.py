@@ -90,6 +90,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:   # N processes share the host: do not let each spin up one intra-op thread per core
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)

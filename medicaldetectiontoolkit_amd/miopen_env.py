@@ -10,6 +10,20 @@ CACHE_DIR = os.path.join(HERE, "miopen_cache")
 
 def setup(cache_dir=None):
     d = cache_dir or os.environ.get("MDT_MIOPEN_CACHE", CACHE_DIR)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and cache_dir is None and "MDT_MIOPEN_CACHE" not in os.environ:
+        # one process per GPU: every rank works on its own copy of the in-tree cache, so N ranks never write the
+        # same find-db / kernel-cache files concurrently
+        import shutil
+        import tempfile
+        rank = os.environ.get("RANK", "0")
+        dst = os.path.join(tempfile.gettempdir(), "mdt_miopen_cache_rank%s_%d" % (rank, os.getuid()))
+        try:
+            if os.path.isdir(d) and not os.path.isdir(dst):
+                shutil.copytree(d, dst)
+            d = dst
+        except OSError:
+            pass
     try:
         os.makedirs(os.path.join(d, "db"), exist_ok=True)
         os.makedirs(os.path.join(d, "kernels"), exist_ok=True)
