@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--model", type=str, default="mrcnn", choices=["mrcnn", "retina_unet"],
                     help="mrcnn = BASELINE config 3 (headline); retina_unet = config 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-adam", type=int, default=0)
+    ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
     ap.add_argument("--channels-last", type=int, default=1)
     ap.add_argument("--host-batches", action="store_true", help="hand numpy batches to train_forward (PCIe-inclusive rate)")
     args = ap.parse_args()
@@ -88,13 +90,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()      # == local_rank whenever there is one GPU per rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:   # N processes share the host: do not let each spin up one intra-op thread per core
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     from medicaldetectiontoolkit_amd import training
     from medicaldetectiontoolkit_amd.configs import Configs
@@ -110,7 +116,7 @@ def main():
     torch.manual_seed(0)          # identical initial weights on every rank
     net = (mrcnn if args.model == "mrcnn" else retina_unet).net(cf, device=dev)
     torch.manual_seed(1000 + rank)
-    opt = training.build_optimizer(net, cf)
+    opt = training.build_optimizer(net, cf, fused=bool(args.fused_adam))
     sync = training.FlatGradAllReduce(net) if world > 1 else None
     # rank-disjoint synthetic patch streams, generated before the timed region (the reference's loader runs in
     # background worker processes and is excluded from its own per-batch timing, exec.py:68-77)
@@ -175,12 +181,13 @@ def main():
                 cpu = {"value": None, "unit": "patches/s", "cores": int(torch.get_num_threads()), "kind": "port", "sample": "failed: %r" % (e,)}
         patches = args.batch * world * args.steps
         out = {
-            "metric": "3D patches/sec (train), 128^3 %s" % ("Mask R-CNN" if args.model == "mrcnn" else "Retina U-Net"), "value": round(patches / elapsed, 3), "unit": "patches/s",
+            "metric": "3D patches/sec (train), %s %s" % ("^3".join([str(patch[0]), ""]) if len(set(patch)) == 1 else "x".join(map(str, patch)),
+                                                       "Mask R-CNN" if args.model == "mrcnn" else "Retina U-Net"), "value": round(patches / elapsed, 3), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host numpy batches, PCIe inclusive)" if args.host_batches else " (resident in HBM)"),
             "config": {"workload": "LIDC-shape 3D %s, %s fp32 patches, batch %d per GPU, random-init weights, Adam lr 1e-4" % (
                            "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),
-                       "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over RCCL)" % world,
+                       "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over %s)" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "global_batch": args.batch * world},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -1247,7 +1247,10 @@ int launch_bwd_fast(const float *grads, const float *boxes, const int *box_ind, 
     long long n_zero = (n_total / 4 + EXP_THREADS - 1) / EXP_THREADS;
     if (n_zero > 4096) n_zero = 4096;
     if (n_zero < 1) n_zero = 1;
-    (void)hipGetLastError(); hipLaunchKernelGGL(crop_bwd_expand_zero_kernel<DIM>, dim3((unsigned)(n_expand + n_zero)), dim3(EXP_THREADS), ldsA, s,
+    // (a variant with the zero-fill on a forked internal stream measured 57-65 us vs 29-52 us: the event
+    //  fork/join costs more than the freed workgroup slots gain -- DESIGN.md 4.1)
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(crop_bwd_expand_zero_kernel<DIM>, dim3((unsigned)(n_expand + n_zero)), dim3(EXP_THREADS), ldsA, s,
                        p, n_expand, gy, n_vec4, tail_begin, n_total);
     if (check_launch() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
     if (N == 0) return MDT_OK;

@@ -5,8 +5,11 @@ import torch
 import torch.distributed as dist
 
 
-def build_optimizer(net, cf):
-    return torch.optim.Adam(net.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay)
+def build_optimizer(net, cf, fused=False):
+    """exec.py:39: Adam(lr=cf.learning_rate[0], weight_decay=cf.weight_decay); fused=True uses torch's single-kernel
+    multi-tensor implementation (same update rule)."""
+    kw = {"fused": True} if fused else {}
+    return torch.optim.Adam(net.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay, **kw)
 
 
 class FlatGradAllReduce(object):
