@@ -19,4 +19,4 @@ for a, b in ev:
     a.record(); fn(); b.record()
 torch.cuda.synchronize()
 t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
-print(json.dumps({"N": N, "invalid": bool(os.environ.get("MDT_INVALID")), "fork": bool(os.environ.get("MDT_BWD_FORK")), "median_us": round(t[20], 2), "min_us": round(t[0], 2)}))
+print(json.dumps({"N": N, "invalid": bool(os.environ.get("MDT_INVALID")), "median_us": round(t[20], 2), "min_us": round(t[0], 2)}))
