@@ -85,3 +85,27 @@ def test_single_process_helpers_are_identity():
     assert mdist.gather_rows(t) is t
     assert mdist.shard_indices(5) == [0, 1, 2, 3, 4]
     training.FlatGradAllReduce(Tiny())()   # no process group: no-op
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """last_checkpoint/params.pth = {'epoch','state_dict','optimizer'} (utils/exp_utils.py:178-192) and the bare
+    state_dict form of '<epoch>_best_checkpoint' both load back."""
+    from medicaldetectiontoolkit_amd.utils import exp_utils
+    torch.manual_seed(0)
+    net = Tiny()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    net(torch.randn(3, 4), True).backward()
+    opt.step()
+    exp_utils.save_last_checkpoint(str(tmp_path), net, opt, epoch=7, monitor_metrics={"train": {"loss": [None, 1.0]}})
+    exp_utils.save_best_checkpoint(str(tmp_path), net, epoch=7)
+    raw = torch.load(str(tmp_path / "last_checkpoint" / "params.pth"))
+    assert set(raw) == {"epoch", "state_dict", "optimizer"} and raw["epoch"] == 7
+    net2 = Tiny()
+    opt2 = torch.optim.Adam(net2.parameters(), lr=1e-3)
+    start, metrics = exp_utils.load_checkpoint(str(tmp_path / "last_checkpoint"), net2, opt2)
+    assert start == 8 and metrics["train"]["loss"][1] == 1.0
+    for a, b in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(a, b)
+    net3 = Tiny()
+    start3, _ = exp_utils.load_checkpoint(str(tmp_path / "7_best_checkpoint"), net3)
+    assert start3 == 1 and all(torch.equal(a, b) for a, b in zip(net.parameters(), net3.parameters()))

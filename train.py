@@ -1,0 +1,99 @@
+"""Thin, DDP-aware training driver = the reference's exec.py train() loop (exec.py:30-110) on synthetic patches.
+
+  python train.py --model mrcnn --epochs 2 --batches 20 --exp-dir /tmp/mdt_exp [--resume]
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...
+
+Per epoch: cf.num_train_batches steps of training.train_step (forward, backward, one flat gradient all-reduce, Adam),
+per-batch log line like exec.py:75-79, then a reference-format checkpoint (rank 0).  Real-data loaders / validation /
+model selection are out of scope; this exists so the hot path can be exercised as a training job.
+"""
+import argparse
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from medicaldetectiontoolkit_amd import miopen_env  # noqa: E402
+miopen_env.setup()
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="mrcnn", choices=["mrcnn", "retina_unet", "retina_net"])
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--patch", default="128,128,128")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--batches", type=int, default=10, help="cf.num_train_batches")
+    ap.add_argument("--exp-dir", default="/tmp/mdt_exp")
+    ap.add_argument("--resume", action="store_true", help="exec.py --resume_to_checkpoint: continue from <exp-dir>/fold_0/last_checkpoint")
+    ap.add_argument("--backend", default="nccl")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    torch.backends.cudnn.benchmark = True
+
+    from medicaldetectiontoolkit_amd import training
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from medicaldetectiontoolkit_amd.models import mrcnn, retina_unet
+    from medicaldetectiontoolkit_amd.utils import exp_utils
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch, to_device
+
+    patch = [int(v) for v in args.patch.split(",")]
+    cf = Configs(dim=args.dim, model=args.model, patch_size=patch, batch_size=args.batch, channels_last=True,
+                 num_epochs=args.epochs, num_train_batches=args.batches)
+    torch.manual_seed(0)
+    net = (mrcnn if args.model == "mrcnn" else retina_unet).net(cf, device=dev)
+    opt = training.build_optimizer(net, cf)
+    sync = training.FlatGradAllReduce(net) if world > 1 else None
+    fold_dir = os.path.join(args.exp_dir, "fold_0")
+    start_epoch = 1
+    if args.resume and os.path.exists(os.path.join(fold_dir, "last_checkpoint", "params.pth")):
+        start_epoch, _ = exp_utils.load_checkpoint(os.path.join(fold_dir, "last_checkpoint"), net, opt, map_location=dev)
+        if rank == 0:
+            print("resumed to checkpoint at epoch {}".format(start_epoch), flush=True)
+    torch.manual_seed(1000 + rank)
+
+    metrics = {"train": {"loss": [None]}}
+    for epoch in range(start_epoch, cf.num_epochs + 1):
+        for g in opt.param_groups:                       # exec.py:59-60: per-epoch learning-rate list
+            g["lr"] = cf.learning_rate[min(epoch - 1, len(cf.learning_rate) - 1)]
+        t_epoch = time.time()
+        losses = []
+        for bix in range(cf.num_train_batches):
+            batch = to_device(make_batch(patch, args.batch, seed=((epoch * 100003 + bix) * world + rank)), dev)
+            t0 = time.time()
+            res = training.train_step(net, opt, batch, grad_sync=sync, monitor=(bix == cf.num_train_batches - 1))
+            loss = float(res["torch_loss"].detach())
+            losses.append(loss)
+            if rank == 0:
+                print("tr. batch {0}/{1} (ep. {2}) tot {3:.3f}s || loss: {4:.3f} {5}".format(
+                    bix + 1, cf.num_train_batches, epoch, time.time() - t0, loss, res.get("logger_string", "")[:90]), flush=True)
+        metrics["train"]["loss"].append(sum(losses) / max(len(losses), 1))
+        exp_utils.save_last_checkpoint(fold_dir, net, opt, epoch, metrics)
+        if rank == 0:
+            print("epoch {0} done in {1:.1f}s, mean loss {2:.4f}, {3:.1f} patches/s".format(
+                epoch, time.time() - t_epoch, metrics["train"]["loss"][-1],
+                cf.num_train_batches * args.batch * world / (time.time() - t_epoch)), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
