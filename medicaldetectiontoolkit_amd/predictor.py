@@ -120,17 +120,16 @@ def _forward_patches(net, data, coords, chunk_ids, cf, amp_dtype, with_seg):
     return net.test_forward(batch, **kw)
 
 
-def predict_patient(net, data, cf, n_ens=None, amp_dtype=None, rank_ix="0", test_aug=False, with_seg=False):
-    """data: numpy [C, Y, X, Z] (3D) whole-patient volume.  Tiles it (get_patch_crop_coords), forwards the patches
-    of THIS rank in chunks of cf.batch_size, moves boxes to patient coordinates with patch-centre factor and
-    overlap count, all_gathers the rows across ranks and consolidates per class with the WBC kernel.
-    test_aug=True adds the reference's three mirrored passes (flip y, flip x, flip both; predictor.py:279-367) with
-    the boxes mirrored back; n_ens defaults to the number of passes (expected predictions per position).
-    Returns results_dict {'boxes': [[box dicts]], 'seg_preds': ...} like predictor.predict_patient."""
+def collect_raw_boxes(net, data, cf, amp_dtype=None, rank_ix="0", test_aug=False, with_seg=False):
+    """Patch-tiled forward of one patient WITHOUT consolidation (predictor.py:279-455): returns
+    (raw_boxes, info) where raw_boxes is the reference's per-patient box-dict list in patient coordinates, each det
+    carrying 'patch_id' = "<rank_ix>_<aug>_<patch>", 'box_patch_center_factor' and 'box_n_overlaps'
+    (this is what the reference pickles as raw_pred_boxes_list, predictor.py:192-194).  Patches (x mirrored passes)
+    are sharded round-robin over ranks and the rows all_gathered."""
     from . import distributed as mdist
     from .utils.dataloader_utils import get_patch_crop_coords
     dim = cf.dim
-    assert dim == 3, "patch-tiled 3D prediction (2D slices go through merge_2D_to_3D in the reference: out of scope)"
+    assert dim == 3, "patch-tiled 3D prediction (2D slices go through merge_2D_to_3D_preds_per_patient)"
     dev = net.device_
     spatial = data.shape[1:]
     Y, X = spatial[0], spatial[1]
@@ -140,9 +139,6 @@ def predict_patient(net, data, cf, n_ens=None, amp_dtype=None, rank_ix="0", test
     for pc in coords:
         overlap[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += 1
     augs = [(False, False)] + ([(True, False), (False, True), (True, True)] if test_aug else [])
-    if n_ens is None:
-        n_ens = len(augs)
-    # work items = (aug, patch), sharded round-robin over ranks
     items = [(a, p) for a in range(len(augs)) for p in range(n_patches)]
     mine = [items[i] for i in mdist.shard_indices(len(items))]
     rows = []
@@ -179,27 +175,82 @@ def predict_patient(net, data, cf, n_ens=None, amp_dtype=None, rank_ix="0", test
                     rows.append(list(c) + [float(box["box_score"]), float(box["box_pred_class_id"]), fac, float(a * n_patches + p)])
     local = torch.tensor(rows, dtype=torch.float64, device=dev).view(-1, 10)
     allrows = mdist.gather_rows(local).cpu().numpy()
-    out_boxes = []
-    if allrows.shape[0] > 0:
+    raw = []
+    for r in allrows:
         # overlap count under the box; the reference slices the y axis with x coordinates and vice versa
         # (predictor.py:434) -- reproduced
-        novs = np.zeros(allrows.shape[0])
-        for i, r in enumerate(allrows):
-            ic = [int(np.floor(v)) if ix % 2 == 0 else int(np.ceil(v)) for ix, v in enumerate(r[:6])]
-            region = overlap[max(ic[1], 0):ic[3], max(ic[0], 0):ic[2], max(ic[4], 0):ic[5]]
-            novs[i] = float(np.mean(region)) if region.size else 0.0
-        for cl in sorted(cf.class_dict.keys()):
-            sel = allrows[:, 7] == cl
-            if not sel.any():
-                continue
-            dets = np.concatenate([allrows[sel, :6], allrows[sel, 6:7], allrows[sel, 8:9], novs[sel, None]], 1)
-            pid = np.array(["%s_%d_%d" % (rank_ix, int(q) // n_patches, int(q) % n_patches) for q in allrows[sel, 9]])
-            ks, kc = weighted_box_clustering(dets, pid, cf.wcs_iou, n_ens, device=dev)
-            for s, c in zip(ks, kc):
-                out_boxes.append({"box_type": "det", "box_coords": np.array(c), "box_score": s, "box_pred_class_id": cl})
-    res = {"boxes": [out_boxes], "n_patches": n_patches, "n_raw_boxes": int(allrows.shape[0]), "n_passes": len(augs)}
+        ic = [int(np.floor(v)) if ix % 2 == 0 else int(np.ceil(v)) for ix, v in enumerate(r[:6])]
+        region = overlap[max(ic[1], 0):ic[3], max(ic[0], 0):ic[2], max(ic[4], 0):ic[5]]
+        q = int(r[9])
+        raw.append({"box_type": "det", "box_coords": r[:6].copy(), "box_score": float(r[6]), "box_pred_class_id": int(r[7]),
+                    "patch_id": "%s_%d_%d" % (rank_ix, q // n_patches, q % n_patches), "box_patch_center_factor": float(r[8]),
+                    "box_n_overlaps": float(np.mean(region)) if region.size else 0.0})
+    info = {"n_patches": n_patches, "n_passes": len(augs)}
     if with_seg:
         m = overlap > 0
         seg_sum[m] /= overlap[m]
-        res["seg_preds"] = seg_sum[None, None]
+        info["seg_preds"] = seg_sum[None, None]
+    return raw, info
+
+
+def apply_wbc_to_patient(raw_boxes, cf, n_ens, device=None):
+    """predictor.py:514-550 for one (3D) patient: per foreground class weighted box clustering of the raw boxes;
+    ground-truth boxes are passed through."""
+    out = []
+    for cl in sorted(cf.class_dict.keys()):
+        sel = [b for b in raw_boxes if b["box_type"] == "det" and b["box_pred_class_id"] == cl]
+        if not sel:
+            continue
+        dets = np.array([list(b["box_coords"]) + [b["box_score"], b["box_patch_center_factor"], b["box_n_overlaps"]] for b in sel])
+        pid = np.array([b["patch_id"] for b in sel])
+        ks, kc = weighted_box_clustering(dets, pid, cf.wcs_iou, n_ens, device=device)
+        for s_, c_ in zip(ks, kc):
+            out.append({"box_type": "det", "box_coords": np.array(c_), "box_score": s_, "box_pred_class_id": cl})
+    out.extend([b for b in raw_boxes if b["box_type"] == "gt"])
+    return out
+
+
+def predict_patient(net, data, cf, n_ens=None, amp_dtype=None, rank_ix="0", test_aug=False, with_seg=False):
+    """data: numpy [C, Y, X, Z] whole-patient volume -> {'boxes': [[box dicts]], ...} like predictor.predict_patient:
+    collect_raw_boxes (tiling, optional mirrored passes, gather over ranks) + apply_wbc_to_patient.
+    n_ens defaults to the number of passes (expected predictions per position)."""
+    raw, info = collect_raw_boxes(net, data, cf, amp_dtype=amp_dtype, rank_ix=rank_ix, test_aug=test_aug, with_seg=with_seg)
+    if n_ens is None:
+        n_ens = info["n_passes"]
+    res = {"boxes": [apply_wbc_to_patient(raw, cf, n_ens, device=net.device_)], "n_patches": info["n_patches"],
+           "n_raw_boxes": len(raw), "n_passes": info["n_passes"]}
+    if with_seg:
+        res["seg_preds"] = info["seg_preds"]
     return res
+
+
+def predict_test_set(net, patients, cf, checkpoint_paths=None, out_dir=None, test_aug=None, amp_dtype=None):
+    """predictor.py:122-216 in miniature: temporal ensembling over saved epochs (each checkpoint = one ensemble member,
+    patch ids prefixed with its rank), raw predictions pickled in the reference's format
+    ('raw_pred_boxes_list.pickle' = [[boxes_per_batch_element, pid], ...]), then WBC per patient with
+    n_ens = n_checkpoints x n_mirrored_passes.  patients: iterable of (data [C,Y,X,Z], pid)."""
+    import os
+    import pickle
+    from .utils import exp_utils
+    test_aug = cf.test_aug if test_aug is None else test_aug
+    members = list(checkpoint_paths) if checkpoint_paths else [None]
+    raw_per_patient = {}
+    order = []
+    n_passes = 1
+    for rank_ix, ckpt in enumerate(members):
+        if ckpt is not None:
+            exp_utils.load_checkpoint(ckpt, net, map_location=net.device_)
+        for data, pid in patients:
+            raw, info = collect_raw_boxes(net, data, cf, amp_dtype=amp_dtype, rank_ix=str(rank_ix), test_aug=test_aug)
+            n_passes = info["n_passes"]
+            if pid not in raw_per_patient:
+                raw_per_patient[pid] = []
+                order.append(pid)
+            raw_per_patient[pid] += raw
+    raw_list = [[[raw_per_patient[pid]], pid] for pid in order]
+    if out_dir is not None and exp_utils._is_rank0():
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "raw_pred_boxes_list.pickle"), "wb") as handle:
+            pickle.dump(raw_list, handle)
+    n_ens = len(members) * n_passes
+    return [[[apply_wbc_to_patient(boxes[0], cf, n_ens, device=net.device_)], pid] for boxes, pid in raw_list]

@@ -112,3 +112,29 @@ def test_patch_tiled_prediction_with_wbc(cuda):
         assert c[0] >= -1 and c[2] <= 101 and c[1] >= -1 and c[3] <= 91 and c[2] >= c[0] and c[3] >= c[1]
     f = predictor.box_patch_center_factor([0, 0, 64, 64, 0, 32], [64, 64, 32])
     assert abs(f - 1.0) < 1e-12                     # box centred in the patch -> factor 1
+
+
+def test_predict_test_set_ensembling_and_raw_pickle(cuda, tmp_path):
+    """Temporal ensembling over two saved checkpoints + the reference's raw-prediction pickle format."""
+    import pickle
+    from medicaldetectiontoolkit_amd import predictor, training
+    from medicaldetectiontoolkit_amd.utils import exp_utils
+    cf = Configs(dim=3, model="mrcnn", patch_size=[64, 64, 32], batch_size=4)
+    torch.manual_seed(0)
+    net = mrcnn.net(cf, device=cuda)
+    opt = training.build_optimizer(net, cf)
+    ck = []
+    for ep in (1, 2):
+        training.train_step(net, opt, make_batch(cf.patch_size, 2, seed=ep))
+        exp_utils.save_best_checkpoint(str(tmp_path), net, ep)
+        ck.append(str(tmp_path / ("%d_best_checkpoint" % ep)))
+    rng = np.random.default_rng(1)
+    patients = [(rng.standard_normal((1, 80, 70, 40)).astype(np.float32), "p%d" % i) for i in range(2)]
+    res = predictor.predict_test_set(net, patients, cf, checkpoint_paths=ck, out_dir=str(tmp_path), test_aug=False)
+    assert [pid for _, pid in res] == ["p0", "p1"] and all(len(b) == 1 for b, _ in res)
+    raw = pickle.load(open(str(tmp_path / "raw_pred_boxes_list.pickle"), "rb"))
+    assert len(raw) == 2 and raw[0][1] == "p0"
+    members = {b["patch_id"].split("_")[0] for b in raw[0][0][0]}
+    assert members <= {"0", "1"}
+    for b in raw[0][0][0]:
+        assert {"box_coords", "box_score", "box_pred_class_id", "patch_id", "box_patch_center_factor", "box_n_overlaps"} <= set(b)
