@@ -24,49 +24,11 @@
 // HBM-bound gather/scatter work: no MFMA.  Algorithmic bytes:
 //   bwd: 4*B*C*V (grad_image written once) + 4*N*C*P (grads read once) + 28*N.
 
-#include <hip/hip_runtime.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <stdint.h>
-#include <stdlib.h>
-#include "mdt_hip.h"
+#include "roi_align_common.h"
+
+using namespace mdt_ra;
 
 namespace {
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-struct AxisEntry {
-    int lo;      // floorf(in)
-    float lerp;  // in - lo;  ceilf(in) == lo + (lerp > 0)
-};
-
-// crop_and_resize_kernel.cu:51-75 -- see oracle/mdt_oracle.c sample_coord for the
-// type analysis (the 0.5 literals are double).
-__device__ __forceinline__ float sample_coord(float a1, float a2, int L, int P, int p)
-{
-    float in;
-    if (P > 1) {
-        const float scale = (a2 - a1) * (float)L / (float)P;
-        const float t = a1 * (float)L + (float)p * scale + scale / 2.0f;
-        in = (float)((double)t - 0.5);
-    } else {
-        in = (float)(0.5 * (double)(a1 + a2) * (double)L);
-    }
-    if (in > (float)(L - 1)) in = (float)(L - 1);
-    if (in < 0.0f) in = 0.0f;
-    return in;
-}
-
-__device__ __forceinline__ AxisEntry axis_entry(float a1, float a2, int L, int P, int p)
-{
-    const float in = sample_coord(a1, a2, L, P, p);
-    AxisEntry e;
-    e.lo = (int)floorf(in);
-    e.lerp = in - (float)e.lo;
-    return e;
-}
-
-__device__ __forceinline__ int entry_hi(const AxisEntry &e) { return e.lo + (e.lerp > 0.0f ? 1 : 0); }
 
 // ---------------------------------------------------------------------------
 // forward
@@ -555,15 +517,6 @@ struct FastParams {
     int lds_cache;       // RoIs whose header/tables phase B caches in LDS
 };
 
-// weight of sample entry e towards voxel index idx (sum of the floor and ceil contributions)
-__device__ __forceinline__ float axis_weight(const AxisEntry &e, int idx)
-{
-    float w = 0.0f;
-    if (e.lo == idx) w = 1.0f - e.lerp;
-    if (entry_hi(e) == idx) w = w + e.lerp;   // lo == hi happens only with lerp == 0
-    return w;
-}
-
 __device__ __forceinline__ int bitmap_pos(const u64 *words, const int *prefix, int idx)
 {
     const u64 w = words[idx >> 6];
@@ -957,14 +910,6 @@ __global__ __launch_bounds__(256) void crop_bwd3d_atomic_kernel(
     }
 }
 
-inline int check_launch()
-{
-    const hipError_t e = hipGetLastError();
-    if (e == hipSuccess) return MDT_OK;
-    if (getenv("MDT_VERBOSE")) fprintf(stderr, "libmdt_hip: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
-    return MDT_ERR_LAUNCH_FAILED;
-}
-
 // Forward, LDS-staged form: one workgroup per (RoI, channel group).  The RoI's bounding sub-box of the feature
 // map (rows along the contiguous axis) is staged in LDS with coalesced loads, one channel at a time, and all
 // ch*cw*cd outputs of that channel are interpolated from LDS: each feature voxel is read from global memory once
@@ -1259,6 +1204,13 @@ int launch_bwd_fast(const float *grads, const float *boxes, const int *box_ind, 
     return check_launch();
 }
 
+// MDT_BWD_KERNEL=twophase selects the round-1 separable two-kernel form (A/B measurements)
+inline bool bwd_force_twophase()
+{
+    const char *v = getenv("MDT_BWD_KERNEL");
+    return v && v[0] == 't';
+}
+
 }  // namespace
 
 extern "C" {
@@ -1290,6 +1242,10 @@ size_t mdt_crop_and_resize_backward_workspace_bytes(int dim, int num_boxes, int 
     if (num_boxes <= 0 || depth <= 0 || crop_height <= 0 || crop_width <= 0 || image_height <= 0 || image_width <= 0)
         return 256;
     const int d3 = dim == 3;
+    if (!bwd_force_twophase() &&
+        bwd_territory_supported(d3 ? 3 : 2, num_boxes, 1, image_height, image_width, d3 ? image_zdepth : 1,
+                                crop_height, crop_width, d3 ? crop_zdepth : 1, depth))
+        return 256;   // default single-launch form needs no workspace
     return fast_layout(d3 ? 3 : 2, num_boxes, depth, image_height, image_width, d3 ? image_zdepth : 1,
                        crop_height, crop_width, d3 ? crop_zdepth : 1).total;
 }
@@ -1317,6 +1273,11 @@ int mdt_crop_and_resize_3d_backward(const float *grads, const float *boxes, cons
                                     int ch, int cw, int cd, int depth,
                                     float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
 {
+    if (!bwd_force_twophase()) {
+        const int rt = launch_bwd_territory(3, grads, boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth,
+                                            grads_image, (hipStream_t)stream);
+        if (rt != MDT_ERR_UNSUPPORTED) return rt;
+    }
     const int rc = launch_bwd_fast<3>(grads, boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth,
                                       grads_image, workspace, workspace_bytes, (hipStream_t)stream);
     if (rc == MDT_ERR_UNSUPPORTED)   // pool extents beyond the LDS budget: exact-order kernel handles any shape
@@ -1330,6 +1291,11 @@ int mdt_crop_and_resize_2d_backward(const float *grads, const float *boxes, cons
                                     int ch, int cw, int depth,
                                     float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
 {
+    if (!bwd_force_twophase()) {
+        const int rt = launch_bwd_territory(2, grads, boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth,
+                                            grads_image, (hipStream_t)stream);
+        if (rt != MDT_ERR_UNSUPPORTED) return rt;
+    }
     const int rc = launch_bwd_fast<2>(grads, boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth,
                                       grads_image, workspace, workspace_bytes, (hipStream_t)stream);
     if (rc == MDT_ERR_UNSUPPORTED)
