@@ -64,17 +64,18 @@ int mdt_crop_and_resize_3d_forward(
  * Replaces CropAndResizeBackpropImageLaucher (3D)
  *   crop_and_resize_kernel.h:14-18 (kernel: crop_and_resize_kernel.cu:154-304)
  *   together with BOTH zero-fills of grads_image (crop_and_resize.py:40 and
- *   crop_and_resize_gpu.c:61): grads_image is written exactly once, without atomics.
+ *   crop_and_resize_gpu.c:61): every byte of grads_image is written exactly once, without atomics.
  * grads [num_boxes, depth, ch, cw, cd]; grads_image [batch, depth, H, W, D].
  *
- * Default form (separable, two kernels): phase A pushes each (RoI, channel) gradient block
- * through the three per-axis interpolation matrices in LDS and writes a compact block
- * (<= 8*ch*cw*cd floats) to `workspace`; phase B streams grads_image out tile by tile, adding
- * one value per overlapping RoI.  Deterministic run to run; sums are reassociated relative to
- * the reference's flat 8-corner scatter, so values agree to fp32 rounding (bar: 1e-4).
- * workspace: mdt_crop_and_resize_backward_workspace_bytes(3, num_boxes, depth, H, W, D, ch, cw, cd),
- * 16-byte aligned (per-RoI headers + index tables + the compact blocks);
- * pool extents too large for the LDS budget fall back to the _ordered kernel.
+ * Default form: ONE launch, no workspace (csrc/roi_align_bwd.hip).  Workgroups of a "zero" role stream 16-byte zero
+ * stores over everything outside the index bounding boxes of the RoIs ("territory", a bitmap every workgroup
+ * rebuilds from `boxes`); one workgroup per (batch element, channel) of a "scatter" role computes the territory
+ * from LDS: per-axis interpolation as separable streaming passes into compact per-RoI blocks, then one ordered sum
+ * per voxel over the RoIs covering it.  Deterministic run to run; sums are reassociated relative to the
+ * reference's flat 8-corner scatter, so values agree to fp32 rounding (bar: 1e-4).
+ * workspace: mdt_crop_and_resize_backward_workspace_bytes(...) -- 256 bytes (unused) whenever the default form
+ * supports the shape; shapes beyond its LDS budgets (pool extents > 64, very large maps) run the two-kernel form
+ * below and need its workspace; pool extents beyond that form's budget fall back to the _ordered kernel.
  */
 size_t mdt_crop_and_resize_backward_workspace_bytes(int dim, int num_boxes, int depth,
                                                    int image_height, int image_width, int image_zdepth,
@@ -84,6 +85,28 @@ int mdt_crop_and_resize_3d_backward(
     int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
     int crop_height, int crop_width, int crop_zdepth, int depth,
     float *grads_image, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Two-kernel separable form (round-1 default, kept as A/B baseline and fallback): kernel 1 = per-(RoI, channel)
+ * expansion into compact blocks in `workspace` running beside a zero-fill role; kernel 2 patches the touched voxels.
+ * workspace: mdt_crop_and_resize_backward_twophase_workspace_bytes(...), 16-byte aligned.  Same numerics contract. */
+size_t mdt_crop_and_resize_backward_twophase_workspace_bytes(int dim, int num_boxes, int depth,
+                                                            int image_height, int image_width, int image_zdepth,
+                                                            int crop_height, int crop_width, int crop_zdepth);
+int mdt_crop_and_resize_3d_backward_twophase(
+    const float *grads, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
+    int crop_height, int crop_width, int crop_zdepth, int depth,
+    float *grads_image, void *workspace, size_t workspace_bytes, void *stream);
+int mdt_crop_and_resize_2d_backward_twophase(
+    const float *grads, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width,
+    int crop_height, int crop_width, int depth,
+    float *grads_image, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Tuning hook of the default backward (tools/bwd_stage_probe.py, tools/bwd_trace_probe.py): when set to a device buffer of
+ * >= 64 + 4 * grid int64 entries the kernel records per-stage / per-workgroup wall-clock stamps there; NULL (default)
+ * turns it off.  Not part of the reference's interface. */
+void mdt_debug_bwd_timestamps(long long *dev_buf);
 
 /* Exact-order form: gather kernel that adds, per voxel, the terms in exactly the order a
  * sequential out_idx loop would (corner order of crop_and_resize_kernel.cu:256-301), so the

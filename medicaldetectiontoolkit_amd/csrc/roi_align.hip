@@ -1204,12 +1204,11 @@ int launch_bwd_fast(const float *grads, const float *boxes, const int *box_ind, 
     return check_launch();
 }
 
-// MDT_BWD_KERNEL=twophase selects the round-1 separable two-kernel form (A/B measurements)
-inline bool bwd_force_twophase()
-{
-    const char *v = getenv("MDT_BWD_KERNEL");
-    return v && v[0] == 't';
-}
+// The single-launch territory form walks the RoIs of one batch element inside one workgroup (rounds of <= 8): right
+// for the training call sites (<= 6 RoIs per element, mrcnn.py:1075; lidc configs.py:258), slower than the two-kernel
+// form once a batch element carries dozens of RoIs (measured: N = 600 on P2 1.4 ms vs 0.25 ms).  The launcher only
+// knows N, so the switch is on N.
+constexpr int BWD_TERRITORY_MAX_BOXES = 128;
 
 }  // namespace
 
@@ -1242,7 +1241,7 @@ size_t mdt_crop_and_resize_backward_workspace_bytes(int dim, int num_boxes, int 
     if (num_boxes <= 0 || depth <= 0 || crop_height <= 0 || crop_width <= 0 || image_height <= 0 || image_width <= 0)
         return 256;
     const int d3 = dim == 3;
-    if (!bwd_force_twophase() &&
+    if (num_boxes <= BWD_TERRITORY_MAX_BOXES &&
         bwd_territory_supported(d3 ? 3 : 2, num_boxes, 1, image_height, image_width, d3 ? image_zdepth : 1,
                                 crop_height, crop_width, d3 ? crop_zdepth : 1, depth))
         return 256;   // default single-launch form needs no workspace
@@ -1273,7 +1272,7 @@ int mdt_crop_and_resize_3d_backward(const float *grads, const float *boxes, cons
                                     int ch, int cw, int cd, int depth,
                                     float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (!bwd_force_twophase()) {
+    if (num_boxes <= BWD_TERRITORY_MAX_BOXES) {
         const int rt = launch_bwd_territory(3, grads, boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth,
                                             grads_image, (hipStream_t)stream);
         if (rt != MDT_ERR_UNSUPPORTED) return rt;
@@ -1291,7 +1290,7 @@ int mdt_crop_and_resize_2d_backward(const float *grads, const float *boxes, cons
                                     int ch, int cw, int depth,
                                     float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (!bwd_force_twophase()) {
+    if (num_boxes <= BWD_TERRITORY_MAX_BOXES) {
         const int rt = launch_bwd_territory(2, grads, boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth,
                                             grads_image, (hipStream_t)stream);
         if (rt != MDT_ERR_UNSUPPORTED) return rt;
@@ -1302,6 +1301,35 @@ int mdt_crop_and_resize_2d_backward(const float *grads, const float *boxes, cons
         return launch_bwd<2>(grads, boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth, grads_image,
                              (hipStream_t)stream);
     return rc;
+}
+
+size_t mdt_crop_and_resize_backward_twophase_workspace_bytes(int dim, int num_boxes, int depth,
+                                                            int image_height, int image_width, int image_zdepth,
+                                                            int crop_height, int crop_width, int crop_zdepth)
+{
+    if (num_boxes <= 0 || depth <= 0 || crop_height <= 0 || crop_width <= 0 || image_height <= 0 || image_width <= 0)
+        return 256;
+    const int d3 = dim == 3;
+    return fast_layout(d3 ? 3 : 2, num_boxes, depth, image_height, image_width, d3 ? image_zdepth : 1,
+                       crop_height, crop_width, d3 ? crop_zdepth : 1).total;
+}
+
+int mdt_crop_and_resize_3d_backward_twophase(const float *grads, const float *boxes, const int *box_ind,
+                                             int num_boxes, int batch, int H, int W, int D,
+                                             int ch, int cw, int cd, int depth,
+                                             float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return launch_bwd_fast<3>(grads, boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth,
+                              grads_image, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int mdt_crop_and_resize_2d_backward_twophase(const float *grads, const float *boxes, const int *box_ind,
+                                             int num_boxes, int batch, int H, int W,
+                                             int ch, int cw, int depth,
+                                             float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return launch_bwd_fast<2>(grads, boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth,
+                              grads_image, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int mdt_crop_and_resize_3d_backward_atomic(const float *grads, const float *boxes, const int *box_ind,

@@ -51,7 +51,8 @@ typedef unsigned long long u64;
 constexpr int T_CAND = 64;         // RoIs scanned per chunk (N <= T_CAND: box table read once per workgroup)
 constexpr int T_GMAX = 8;          // RoIs staged per round (upper bound)
 constexpr int T_HDR = 16;          // ints per staged RoI: bbq[4] (packed bounds, E offset), r, nuy, nux, nuz, aoff, boff, inv, line prefixes of passes 2 / 3
-constexpr int T_LDS_MAX = 64 * 1024;
+constexpr int T_LDS_MAX = 80 * 1024;   // gfx950: 160 KB per CU, two workgroups of this kernel stay resident per CU
+constexpr int T_SEGLIST = 2048;         // territory segments listed in LDS (beyond: rank search per segment)
 
 struct SEntry {                    // one sample of one axis: lerp towards the ceil index, compact position of the floor index
     float lerp;
@@ -75,6 +76,8 @@ struct TParams {
     int a_floats, b_floats;        // LDS budgets of the two ping-pong regions
     int ssplit;                    // scatter workgroups per volume
     int parts, rows_per_part;      // zero workgroups in the grid (0: merged into the scatter role), rows of each
+    int zero_per_vol;              // 0: a zero workgroup's run of rows may cross volumes (bitmaps of all batch elements in LDS);
+                                   // k > 0: k zero workgroups per volume, each inside one volume (large batch: one bitmap only)
     int upr, upr_shift;            // store units per row (VEC floats each), log2 or -1
     int useg_shift;                // log2(units per segment) when nseg > 1
     int H4, W4, D4, pos_stride;    // per-RoI index->position table: y | x | z, each padded to 4 bytes
@@ -83,7 +86,7 @@ struct TParams {
     long long *ts;                 // tuning only: wall-clock stamps (or null)
     int dbg;                       // tuning only: bit0 zero role exits at once; bit1 per-workgroup trace; bits 4.. scatter role stops after stage k
     // LDS byte offsets (region A at 0)
-    int off_b, off_tab, off_pos, off_mask, off_hdr, off_bm, off_pref, off_list, off_misc;
+    int off_b, off_tab, off_pos, off_mask, off_hdr, off_bm, off_pref, off_list, off_seg, off_misc;
 };
 
 __device__ __forceinline__ void set_bits(u64 *bm, int s, int e)   // inclusive bit range
@@ -262,8 +265,9 @@ __device__ __forceinline__ void stream_line(const float *in, int istride, float 
     if (p0 + 1 < nu) out[(p0 + 1) * ostride] = acc1;
 }
 
-// QUAD: S == 32 and 16-byte stores possible -> one lane per four consecutive voxels in stage (d)
-template <int DIM, int VEC, bool QUAD, int NT>
+// SL > 0: segments of S = 4 * SL floats and 16-byte stores -> one lane per four consecutive voxels in stage (d), SL lanes
+// per segment; SL == 0: scalar stage (d), 32 lanes per segment (any S)
+template <int DIM, int VEC, int SL, int NT>
 __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
     int *pref = reinterpret_cast<int *>(smem_raw + p.off_pref);                   // [bw + 1]
     int *list = reinterpret_cast<int *>(smem_raw + p.off_list);                   // [T_CAND]
     float *lbox = reinterpret_cast<float *>(list + T_CAND);                       // [T_CAND][6] boxes of the listed RoIs
+    unsigned short *seglist = reinterpret_cast<unsigned short *>(smem_raw + p.off_seg);   // [T_SEGLIST] bit index of the s-th territory segment
     int *wave_cnt = reinterpret_cast<int *>(smem_raw + p.off_misc);               // [T_CAND / 64]
     int *misc = wave_cnt + 4;                                                     // [0] RoIs that fit this round, [1] / [2] lines of passes 2 / 3
     short *cand = reinterpret_cast<short *>(smem_raw);
@@ -303,13 +308,22 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
         // one contiguous run of rows of the whole [B*C*R] row space per workgroup; the grid holds as many zero
         // workgroups as stay resident next to the scatter workgroups, so each pays the bitmap prologue once
         const long long zi = (long long)blockIdx.x - n_scatter;
+        u64 *bm_all = reinterpret_cast<u64 *>(smem_raw + T_CAND * 8 * sizeof(short));   // regions A/B are unused here
+        if (p.zero_per_vol > 0) {
+            const int vol = (int)(zi / p.zero_per_vol);
+            const int r0 = (int)(zi - (long long)vol * p.zero_per_vol) * p.rows_per_part;
+            const int r1 = min(p.R, r0 + p.rows_per_part);
+            if (r0 >= r1 || (p.dbg & 1)) return;
+            build_bitmap<DIM, NT>(p, vol / p.C, bm_all, cand, wave_cnt, nullptr, nullptr);
+            zero_rows<VEC>(p, bm_all, vol, r0, r1, tid, NT);
+            return;
+        }
         const long long g0 = zi * p.rows_per_part;
         const long long total_rows = (long long)p.B * p.C * p.R;
         long long g1 = g0 + p.rows_per_part;
         if (g1 > total_rows) g1 = total_rows;
         if (g0 >= g1 || (p.dbg & 1)) return;
         TSTAMP(0);
-        u64 *bm_all = reinterpret_cast<u64 *>(smem_raw + T_CAND * 8 * sizeof(short));   // [B][bw], regions A/B are unused here
         build_bitmap<DIM, NT>(p, -1, bm_all, cand, wave_cnt, nullptr, nullptr);
         TSTAMP(1);
         for (long long g = g0; g < g1;) {
@@ -355,19 +369,33 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
     }
     __syncthreads();
     const int nterr = pref[p.bw];
-    TSTAMP(2);
     if (nterr == 0) return;
+    // bit index of the s-th territory segment, one thread per bitmap word
+    for (int w = tid; w < p.bw; w += NT) {
+        u64 m = bm[w];
+        int k = pref[w];
+        while (m && k < T_SEGLIST) {
+            const int bpos = __ffsll((long long)m) - 1;
+            seglist[k++] = (unsigned short)((w << 6) + bpos);
+            m &= m - 1;
+        }
+    }
+    __syncthreads();
+    TSTAMP(2);
 
     const int psum = p.ph + p.pw + p.pd;
     const int P = p.P;
     float *ovol = p.out + (long long)vol * p.R * p.L;
-    constexpr int SLOT_LANES = QUAD ? 8 : 32;            // lanes per territory segment in stage (d)
+    constexpr bool QUAD = SL > 0;
+    constexpr int SLOT_LANES = QUAD ? SL : 32;           // lanes per territory segment in stage (d)
     constexpr int SLOTS = NT / SLOT_LANES;
     constexpr int WSLOTS = 64 / SLOT_LANES;              // segments per wave and iteration
     const int slot = tid / SLOT_LANES, sl = tid % SLOT_LANES;
     // word prefix of the territory bitmap in registers (rank -> word search by ballot, no LDS round trips)
-    const bool small_bm = p.bw <= 64;
-    const int prefreg = (small_bm && lane < p.bw) ? pref[lane] : 0x7fffffff;
+    const bool small_bm = p.bw <= 256;
+    int prefreg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) prefreg[k] = (small_bm && lane + 64 * k < p.bw) ? pref[lane + 64 * k] : 0x7fffffff;
     int round = 0;
 
     for (int rb = 0; rb < p.N; rb += T_CAND) {
@@ -618,25 +646,33 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
             for (int s0 = split * SLOTS; s0 < nterr; s0 += SLOTS * p.ssplit) {
                 const int s = s0 + slot;
                 const bool valid = s < nterr;
-                int w;
-                if (small_bm) {        // word holding the s-th set bit: popcount of (word prefix <= s) over the wave
-                    w = 0;
-#pragma unroll
-                    for (int k = 0; k < WSLOTS; ++k) {
-                        const int tgt = __builtin_amdgcn_readlane(s, k * SLOT_LANES);
-                        const int wk = __popcll(__ballot(prefreg <= tgt)) - 1;
-                        if ((lane / SLOT_LANES) == k) w = wk;
-                    }
+                int bit;
+                if (s0 + SLOTS <= T_SEGLIST) {          // uniform: the whole iteration is inside the list
+                    if (!valid) continue;
+                    bit = seglist[s];
                 } else {
-                    int wlo = 0, whi = p.bw - 1;
-                    while (wlo < whi) {
-                        const int mid = (wlo + whi + 1) >> 1;
-                        if (pref[mid] <= s) wlo = mid; else whi = mid - 1;
+                    int w;
+                    if (small_bm) {        // word holding the s-th set bit: popcount of (word prefix <= s) over the wave
+                        w = 0;
+#pragma unroll
+                        for (int k = 0; k < WSLOTS; ++k) {
+                            const int tgt = __builtin_amdgcn_readlane(s, k * SLOT_LANES);
+                            const int wk = __popcll(__ballot(prefreg[0] <= tgt)) + __popcll(__ballot(prefreg[1] <= tgt)) +
+                                           __popcll(__ballot(prefreg[2] <= tgt)) + __popcll(__ballot(prefreg[3] <= tgt)) - 1;
+                            if ((lane / SLOT_LANES) == k) w = wk;
+                        }
+                    } else {
+                        int wlo = 0, whi = p.bw - 1;
+                        while (wlo < whi) {
+                            const int mid = (wlo + whi + 1) >> 1;
+                            if (pref[mid] <= s) wlo = mid; else whi = mid - 1;
+                        }
+                        w = wlo;
                     }
-                    w = wlo;
+                    if (!valid) continue;
+                    bit = (w << 6) + nth_set_bit(bm[w], s - pref[w]);
                 }
-                if (!valid) continue;
-                const int bit = (w << 6) + nth_set_bit(bm[w], s - pref[w]);
+                if (s0 == split * SLOTS) TSTAMP(8);
                 const int row = bit / p.nseg;
                 const int seg = bit - row * p.nseg;
                 int y, x = 0;
@@ -645,8 +681,9 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                 int4 bbq[T_GMAX];
 #pragma unroll
                 for (int j = 0; j < T_GMAX; ++j) bbq[j] = *reinterpret_cast<const int4 *>(hdr + ((j < ng) ? j : 0) * T_HDR);
+                if (s0 == split * SLOTS) TSTAMP(9);
                 if (QUAD) {
-                    const int ci0 = seg * 32 + sl * 4;      // four consecutive indices along the contiguous axis
+                    const int ci0 = seg * (4 * SL) + sl * 4;   // four consecutive indices along the contiguous axis
                     v4f *dst = reinterpret_cast<v4f *>(ovol + (long long)row * p.L + ci0);
                     v4f acc = {0.f, 0.f, 0.f, 0.f};
                     bool touched = false;
@@ -682,6 +719,7 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                         }
                     }
                     if (round == 0 || touched) *dst = acc;
+                    if (s0 == split * SLOTS) TSTAMP(10);
                 } else {
                     for (int ci = seg * p.S + sl; ci < (seg + 1) * p.S; ci += SLOT_LANES) {
                         float *dst = ovol + (long long)row * p.L + ci;
@@ -728,8 +766,12 @@ inline int ilog2_exact(int v)
     return s;
 }
 
+// Launch-geometry knobs (MDT_BWD_*) exist for the tuning scripts under tools/; they are honoured only when
+// MDT_BWD_TUNE is set in the environment, so a normal call never touches getenv beyond the first one.
 inline int env_int(const char *name, int dflt)
 {
+    static const bool tune = getenv("MDT_BWD_TUNE") != nullptr;
+    if (!tune) return dflt;
     const char *v = getenv(name);
     return (v && v[0]) ? atoi(v) : dflt;
 }
@@ -749,7 +791,12 @@ int territory_plan(int dim, int N, int B, int H, int W, int D, int ph, int pw, i
     p.N = N; p.B = B; p.C = C; p.H = H; p.W = W; p.D = D; p.ph = ph; p.pw = pw; p.pd = pd;
     p.R = (dim == 3) ? H * W : H;
     p.L = (dim == 3) ? D : W;
-    p.S = (p.L % 32 == 0) ? 32 : p.L;
+    {
+        int seg = env_int("MDT_BWD_SEG", 8);
+        if (seg != 32 && seg != 16 && seg != 8) seg = 8;
+        while (seg < 32 && ((long long)p.R * (p.L / seg) > 16384)) seg *= 2;    // keep the bitmap small
+        p.S = (vec == 4 && p.L % seg == 0) ? seg : ((p.L % 32 == 0) ? 32 : p.L);
+    }
     p.nseg = p.L / p.S;
     const long long nbits = (long long)p.R * p.nseg;
     if (nbits > 65536) return MDT_ERR_UNSUPPORTED;
@@ -777,7 +824,12 @@ int territory_plan(int dim, int N, int B, int H, int W, int D, int ph, int pw, i
     }
     if (a_max < (size_t)p.P4) a_max = p.P4;
     // zero role keeps the bitmaps of all batch elements behind the cand scratch (regions A/B are idle there)
-    const size_t zero_need = (size_t)T_CAND * 8 * sizeof(short) + (size_t)B * p.bw * sizeof(u64);
+    size_t zero_need = (size_t)T_CAND * 8 * sizeof(short) + (size_t)B * p.bw * sizeof(u64);
+    p.zero_per_vol = 0;
+    if (zero_need > (size_t)T_LDS_MAX / 2) {      // large batch: zero workgroups stay inside one volume, one bitmap
+        p.zero_per_vol = 1;
+        zero_need = (size_t)T_CAND * 8 * sizeof(short) + (size_t)p.bw * sizeof(u64);
+    }
     const int psum = ph + pw + pd;
     const size_t lds_cap = (size_t)env_int("MDT_BWD_LDS_CAP", T_LDS_MAX);
     int G = T_GMAX;
@@ -788,7 +840,7 @@ int territory_plan(int dim, int N, int B, int H, int W, int D, int ph, int pw, i
         const size_t rest = align16((size_t)G * psum * sizeof(SEntry)) + align16((size_t)G * p.pos_stride) +
                             align16((size_t)G * p.mask_stride * sizeof(u64)) +
                             align16((size_t)G * T_HDR * sizeof(int)) + align16((size_t)p.bw * sizeof(u64)) +
-                            align16((size_t)(p.bw + 1) * sizeof(int)) + (size_t)T_CAND * 7 * sizeof(int) + 16 * sizeof(int);
+                            align16((size_t)(p.bw + 1) * sizeof(int)) + (size_t)T_CAND * 7 * sizeof(int) + (size_t)T_SEGLIST * sizeof(unsigned short) + 16 * sizeof(int);
         size_t a_fl = (size_t)G * p.P4;                      // all G gradient blocks resident
         if (a_fl < a_max) a_fl = a_max;
         if (rest + (a_fl + b_max) * sizeof(float) + 64 > lds_cap) continue;
@@ -805,6 +857,7 @@ int territory_plan(int dim, int N, int B, int H, int W, int D, int ph, int pw, i
         p.off_bm = (int)off;   off += align16((size_t)p.bw * sizeof(u64));
         p.off_pref = (int)off; off += align16((size_t)(p.bw + 1) * sizeof(int));
         p.off_list = (int)off; off += (size_t)T_CAND * 7 * sizeof(int);
+        p.off_seg = (int)off;  off += (size_t)T_SEGLIST * sizeof(unsigned short);
         p.off_misc = (int)off; off += 16 * sizeof(int);
         lds = off;
         if (off <= lds_cap && zero_need <= off) break;
@@ -839,10 +892,16 @@ inline int cu_count()
     return n;
 }
 
-template <int DIM, int VEC, bool QUAD, int NT>
+template <int DIM, int VEC, int SL, int NT>
 void launch_variant(TParams &p, size_t lds, hipStream_t s)
 {
-    auto kernel = crop_bwd_territory_kernel<DIM, VEC, QUAD, NT>;
+    auto kernel = crop_bwd_territory_kernel<DIM, VEC, SL, NT>;
+    static bool optin = false;
+    if (!optin) {   // more than 64 KB of dynamic LDS needs the explicit opt-in
+        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_MAX);
+        (void)hipGetLastError();
+        optin = true;
+    }
     const long long nvol = (long long)p.B * p.C;
     const long long n_scatter = nvol * p.ssplit;
     if (p.parts != 0) {
@@ -856,8 +915,17 @@ void launch_variant(TParams &p, size_t lds, hipStream_t s)
         }
         const long long total_rows = nvol * p.R;
         if (z > total_rows) z = (int)total_rows;
-        p.rows_per_part = (int)((total_rows + z - 1) / z);
-        p.parts = (int)((total_rows + p.rows_per_part - 1) / p.rows_per_part);
+        if (p.zero_per_vol > 0) {
+            int k = (int)((z + nvol / 2) / nvol);
+            if (k < 1) k = 1;
+            if (k > p.R) k = p.R;
+            p.rows_per_part = (p.R + k - 1) / k;
+            p.zero_per_vol = (p.R + p.rows_per_part - 1) / p.rows_per_part;
+            p.parts = (int)(nvol * p.zero_per_vol);
+        } else {
+            p.rows_per_part = (int)((total_rows + z - 1) / z);
+            p.parts = (int)((total_rows + p.rows_per_part - 1) / p.rows_per_part);
+        }
     }
     const long long grid = n_scatter + p.parts;
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds, s, p);
@@ -866,10 +934,11 @@ void launch_variant(TParams &p, size_t lds, hipStream_t s)
 template <int DIM, int NT>
 void launch_nt(TParams &p, size_t lds, int vec, hipStream_t s)
 {
-    const bool quad = (vec == 4 && p.S == 32);
-    if (quad) launch_variant<DIM, 4, true, NT>(p, lds, s);
-    else if (vec == 4) launch_variant<DIM, 4, false, NT>(p, lds, s);
-    else launch_variant<DIM, 1, false, NT>(p, lds, s);
+    if (vec == 4 && p.S == 32) launch_variant<DIM, 4, 8, NT>(p, lds, s);
+    else if (vec == 4 && p.S == 16) launch_variant<DIM, 4, 4, NT>(p, lds, s);
+    else if (vec == 4 && p.S == 8) launch_variant<DIM, 4, 2, NT>(p, lds, s);
+    else if (vec == 4) launch_variant<DIM, 4, 0, NT>(p, lds, s);
+    else launch_variant<DIM, 1, 0, NT>(p, lds, s);
 }
 
 long long *g_bwd_ts = nullptr;
@@ -903,7 +972,7 @@ int launch_bwd_territory(int dim, const float *grads, const float *boxes, const 
     const long long nvol = (long long)B * C;
     const long long vol_bytes = vol_floats * 4;
     int nt = env_int("MDT_BWD_THREADS", 512);
-    if (nt != 256 && nt != 512 && nt != 1024) nt = 512;
+    if (nt != 256 && nt != 512) nt = 512;
     if (vol_bytes <= 32 * 1024) nt = 256;
     p.parts = (vol_bytes > 32 * 1024) ? 1 : 0;      // > 0: zero role exists (count fixed in launch_variant)
     p.rows_per_part = p.R;
@@ -918,11 +987,11 @@ int launch_bwd_territory(int dim, const float *grads, const float *boxes, const 
     if (dim == 3) {
         if (nt == 256) launch_nt<3, 256>(p, lds, vec, s);
         else if (nt == 512) launch_nt<3, 512>(p, lds, vec, s);
-        else launch_nt<3, 1024>(p, lds, vec, s);
+        else launch_nt<3, 512>(p, lds, vec, s);
     } else {
         if (nt == 256) launch_nt<2, 256>(p, lds, vec, s);
         else if (nt == 512) launch_nt<2, 512>(p, lds, vec, s);
-        else launch_nt<2, 1024>(p, lds, vec, s);
+        else launch_nt<2, 512>(p, lds, vec, s);
     }
     return check_launch();
 }

@@ -60,10 +60,24 @@ def crop_forward(image, boxes, box_ind, crop, extrapolation_value=0.0):
     return crops
 
 
+_SMALL_WS = {}
+
+
+def _workspace(nbytes, device):
+    """the default kernel needs no workspace (the query answers 256 bytes): reuse one tiny buffer per device"""
+    if nbytes <= 256:
+        ws = _SMALL_WS.get(device)
+        if ws is None:
+            ws = _SMALL_WS[device] = torch.empty(256, dtype=torch.uint8, device=device)
+        return ws
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
 def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False):
     """grads [N, C, *crop] -> grad_image of shape im_size; fully written by the kernel(s).
-    mode: "fast" (default, separable two-phase), "ordered" (bit-exact vs the sequential oracle),
-    "atomic" (reference algorithm, A/B only)."""
+    mode: "fast" (default: single-launch territory kernel, csrc/roi_align_bwd.hip), "twophase" (round-1 separable
+    two-kernel form, A/B and fallback for shapes beyond the LDS budgets), "ordered" (bit-exact vs the sequential
+    oracle), "atomic" (reference algorithm, A/B only)."""
     if atomic:
         mode = "atomic"
     dim = len(im_size) - 2
@@ -85,12 +99,16 @@ def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False):
         s = _lib.current_stream_ptr()
         head = [_lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(box_ind), n, im_size[0]] + list(im_size[2:]) + \
             list(crop) + [im_size[1], _lib.ptr(grad_image)]
-        if mode == "fast":
-            wsb = L.mdt_crop_and_resize_backward_workspace_bytes(
-                dim, n, im_size[1], im_size[2], im_size[3], im_size[4] if dim == 3 else 1,
-                crop[0], crop[1], crop[2] if dim == 3 else 1)
-            ws = torch.empty(wsb, dtype=torch.uint8, device=grads.device)
-            fn = L.mdt_crop_and_resize_3d_backward if dim == 3 else L.mdt_crop_and_resize_2d_backward
+        if mode in ("fast", "twophase"):
+            query = L.mdt_crop_and_resize_backward_workspace_bytes if mode == "fast" else \
+                L.mdt_crop_and_resize_backward_twophase_workspace_bytes
+            wsb = query(dim, n, im_size[1], im_size[2], im_size[3], im_size[4] if dim == 3 else 1,
+                        crop[0], crop[1], crop[2] if dim == 3 else 1)
+            ws = _workspace(wsb, grads.device)
+            if mode == "fast":
+                fn = L.mdt_crop_and_resize_3d_backward if dim == 3 else L.mdt_crop_and_resize_2d_backward
+            else:
+                fn = L.mdt_crop_and_resize_3d_backward_twophase if dim == 3 else L.mdt_crop_and_resize_2d_backward_twophase
             rc = fn(*(head + [_lib.ptr(ws), wsb, s]))
         elif mode == "ordered":
             fn = L.mdt_crop_and_resize_3d_backward_ordered if dim == 3 else L.mdt_crop_and_resize_2d_backward_ordered

@@ -1,4 +1,5 @@
 import os, sys, json, ctypes
+os.environ["MDT_BWD_TUNE"] = "1"
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from medicaldetectiontoolkit_amd import _lib
@@ -22,16 +23,15 @@ g = torch.randn((N, C, 14, 14, 5), device=dev)
 L = _lib.lib()
 ts = torch.zeros(32, dtype=torch.int64, device=dev)
 L._handle if False else None
-fn = ctypes.CDLL(_lib.LIB_PATH).mdt_debug_bwd_timestamps
-fn.argtypes = [ctypes.c_void_p]
-fn(ctypes.c_void_p(ts.data_ptr()))
+_lib.lib().mdt_debug_bwd_timestamps(ctypes.c_void_p(ts.data_ptr()))
 names = ["start", "bitmap", "prefix", "tab(a)", "compact(b)", "offsets", "passes(c)", "combine(d)"]
 for nt in ("512",):
     os.environ["MDT_BWD_THREADS"] = nt
     for zero_off in (0,):
         os.environ["MDT_BWD_DBG"] = str(zero_off)
-        for name, (bx, ind) in {"rand": (boxes, ind_rand), "train": (boxes_train, ind_train)}.items():
-            for wg in (0, 5, 150, 287):
+        ind_bal = torch.arange(N, dtype=torch.int32, device=dev) % B
+        for name, (bx, ind) in {"balanced": (boxes, ind_bal), "train": (boxes_train, ind_train)}.items():
+            for wg in (0, 150):
                 os.environ["MDT_BWD_DBG_WG"] = str(wg)
                 for _ in range(3):
                     ts.zero_()
@@ -39,4 +39,4 @@ for nt in ("512",):
                     torch.cuda.synchronize()
                 t = ts.cpu().numpy()
                 d = {names[i]: round(float(t[i] - t[i - 1]) * 0.01, 2) for i in range(1, 8)}
-                print(json.dumps({"nt": nt, "case": name, "zero_off": zero_off, "wg": wg, "stage_us": d, "total_us": round(float(t[7] - t[0]) * 0.01, 2), "MHz": round(float(t[23] - t[16]) / (float(t[7] - t[0]) * 0.01), 1)}), flush=True)
+                print(json.dumps({"nt": nt, "case": name, "zero_off": zero_off, "wg": wg, "stage_us": d, "total_us": round(float(t[7] - t[0]) * 0.01, 2), "d_first_iter": {"rank": round(float(t[8]-t[6])*0.01,2), "decode+bbq": round(float(t[9]-t[8])*0.01,2), "jloop+store": round(float(t[10]-t[9])*0.01,2)}, "MHz": round(float(t[23] - t[16]) / (float(t[7] - t[0]) * 0.01), 1)}), flush=True)

@@ -1,4 +1,5 @@
 import os, sys, json, ctypes
+os.environ["MDT_BWD_TUNE"] = "1"
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from medicaldetectiontoolkit_amd import _lib
@@ -21,14 +22,13 @@ ind_train = torch.arange(N, dtype=torch.int32, device=dev) // 6
 g = torch.randn((N, C, 14, 14, 5), device=dev)
 _lib.lib()
 ts = torch.zeros(64 + 4 * 8192, dtype=torch.int64, device=dev)
-fn = ctypes.CDLL(_lib.LIB_PATH).mdt_debug_bwd_timestamps
-fn.argtypes = [ctypes.c_void_p]
-fn(ctypes.c_void_p(ts.data_ptr()))
+_lib.lib().mdt_debug_bwd_timestamps(ctypes.c_void_p(ts.data_ptr()))
 os.environ["MDT_BWD_DBG"] = "2"
 nscat = 288
-for nt, parts in (("512", "0"), ("512", "200"), ("512", "256"), ("1024", "0")):
+for nt, parts in (("512", "0"),):
     os.environ["MDT_BWD_THREADS"] = nt; os.environ["MDT_BWD_ZERO_WGS"] = parts
-    for name, (bx, ind) in {"train": (boxes_train, ind_train), "rand": (boxes, ind_rand)}.items():
+    ind_bal = torch.arange(N, dtype=torch.int32, device=dev) % B
+    for name, (bx, ind) in {"train": (boxes_train, ind_train), "balanced": (boxes, ind_bal)}.items():
         for _ in range(3):
             ts.zero_()
             _roi_align_impl.crop_backward(g, bx, ind, shape)

@@ -2,6 +2,8 @@
 exact-order kernel, then event timings over the launch-geometry knobs.  Prints JSON lines.
 Usage: python tools/bwd_tune.py [--iters 60]"""
 import argparse
+import os
+os.environ["MDT_BWD_TUNE"] = "1"   # honour the MDT_BWD_* launch-geometry knobs
 import itertools
 import json
 import os
@@ -71,8 +73,15 @@ def main():
     out = torch.empty(shape, device=dev)
     print(json.dumps({"case": "torch_zero_fill", "us": timeit(lambda: out.zero_(), args.iters)}), flush=True)
 
+    rec = {"cfg": "twophase(r1)"}
+    for name, (bx, ind) in cases.items():
+        us = timeit(lambda: _roi_align_impl.crop_backward(g, bx, ind, shape, mode="twophase"), args.iters)
+        rec[name] = us[0]
+        rec[name + "_frac"] = round(alg / (us[0] * 1e-6) / 8e12, 3)
+    print(json.dumps(rec), flush=True)
+
     def run(tag, env):
-        for k in ("MDT_BWD_PARTS", "MDT_BWD_SSPLIT", "MDT_BWD_T2_FLOATS", "MDT_BWD_THREADS", "MDT_BWD_ZERO_WGS", "MDT_BWD_KERNEL", "MDT_BWD_G", "MDT_BWD_LDS_CAP"):
+        for k in ("MDT_BWD_PARTS", "MDT_BWD_SSPLIT", "MDT_BWD_SEG", "MDT_BWD_THREADS", "MDT_BWD_ZERO_WGS", "MDT_BWD_KERNEL", "MDT_BWD_G", "MDT_BWD_LDS_CAP"):
             os.environ.pop(k, None)
         os.environ.update(env)
         rec = {"cfg": tag}
@@ -82,11 +91,10 @@ def main():
             rec[name + "_frac"] = round(alg / (us[0] * 1e-6) / 8e12, 3)
         print(json.dumps(rec), flush=True)
 
-    run("twophase(r1)", {"MDT_BWD_KERNEL": "twophase"})
     run("default", {})
     if not args.quick:
-        for nt, z in itertools.product((512, 1024), (160, 192, 224, 256, 320, 448)):
-            run("nt%d_z%d" % (nt, z), {"MDT_BWD_THREADS": str(nt), "MDT_BWD_ZERO_WGS": str(z)})
+        for seg in (32, 16, 8):
+            run("seg%d" % seg, {"MDT_BWD_SEG": str(seg)})
 
 
 if __name__ == "__main__":

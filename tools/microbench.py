@@ -74,6 +74,25 @@ def main():
             tag = "%s_N%d_%s" % (lvl, N, "x".join(map(str, crop)))
             report("roialign3d_bwd_fast_" + tag,
                    timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape), args.iters), bwd_bytes)
+            report("roialign3d_bwd_twophase_r1_" + tag,
+                   timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="twophase"), args.iters), bwd_bytes)
+            if N == 48:
+                # train-realistic placement: 6 sampled RoIs per batch element (train_rois_per_image), clustered around
+                # one object, sized as the level rule sends them to this level (box side ~ anchor scale of the level)
+                sc = {"P2": 8.0, "P3": 16.0, "P4": 32.0, "P5": 64.0}[lvl]
+                ctr = rng.uniform(0.25, 0.75, size=(B, 3))
+                tb = []
+                for b_ in range(B):
+                    for _ in range(6):
+                        c_ = ctr[b_] + rng.normal(0, 0.02, size=3)
+                        s_ = rng.uniform(0.75 * sc, 1.4 * sc, size=3) / 128.0
+                        tb.append([c_[0] - s_[0] / 2, c_[1] - s_[1] / 2, c_[0] + s_[0] / 2, c_[1] + s_[1] / 2, c_[2] - s_[2] / 2, c_[2] + s_[2] / 2])
+                tboxes = torch.tensor(np.clip(tb, 0, 1), dtype=torch.float32, device=dev)
+                tind = torch.arange(N, dtype=torch.int32, device=dev) // 6
+                report("roialign3d_bwd_fast_trainlike_" + tag,
+                       timeit(lambda: _roi_align_impl.crop_backward(g, tboxes, tind, shape), args.iters), bwd_bytes)
+                report("roialign3d_bwd_twophase_r1_trainlike_" + tag,
+                       timeit(lambda: _roi_align_impl.crop_backward(g, tboxes, tind, shape, mode="twophase"), args.iters), bwd_bytes)
             report("roialign3d_bwd_ordered_" + tag,
                    timeit(lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="ordered"), args.iters), bwd_bytes)
             if N <= 48:
