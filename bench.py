@@ -8,8 +8,10 @@ patches (LIDC-shape config 3), one process per GPU, plus the RoIAlign-3D-backwar
 A "step" = exec.py:68-74 of the reference: net.train_forward(batch) [incl. H2D of the batch], zero_grad,
 backward, (gradient all-reduce over RCCL when N > 1), Adam step; per-GPU batch = 8 patches (weak scaling).
 Rank 0 prints ONE JSON line.  `roofline` is the dominant custom kernel (RoIAlign-3D backward on the P2 level):
-algorithmic bytes / event-timed duration of the op inside the timed region.  `cpu_baseline` times a bounded
-sample of the same work on the host cores with the CPU oracle (native ops) and torch-CPU (conv path).
+algorithmic bytes / event-timed duration of the C-ABI op with 48 RoIs forced onto the level,
+measured after the timed training loop; `roofline.variants` also carries the op as it ran inside the steps.
+`cpu_baseline` times a bounded sample of the same work on the host cores with the CPU oracle (native ops) and
+torch-CPU (conv path).
 """
 import argparse
 import json
@@ -67,6 +69,73 @@ def cpu_baseline(cf, seconds_budget=25.0):
     return {"value": round(1.0 / total, 4), "unit": "patches/s", "cores": int(threads), "kind": "port",
             "sample": "1 patch %s: torch-CPU FPN+RPN fwd+bwd %.2fs + CPU oracle (NMS n=%d, RoIAlign-3D fwd 75 RoIs, fwd+bwd 6 RoIs "
                       "(7,7,3)+(14,14,5) on P2) %.2fs; wall %.1fs" % ("x".join(map(str, cf.patch_size)), t_conv, cf.pre_nms_limit, t_ops, time.time() - t_start)}
+
+
+def _time_op(fn, launches, warmup=10):
+    """event-bracketed launches on the current stream (the stream the kernels are launched on); seconds per launch"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) * 1e-3 for a, b in ev)
+    return float(np.mean(t)), float(t[len(t) // 2])
+
+
+def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
+    """Roofline of the dominant custom kernel: mdt_crop_and_resize_3d_backward on the P2 level:
+    grads_image 8x36x32x32x128, pool (14,14,5), N = 48 valid RoIs forced onto the level, event-timed launches of the
+    C-ABI op after the training loop.  Headline case = train-realistic placement (6 sampled RoIs per batch element,
+    P2-sized boxes, tests/helpers.trainlike_rois_3d); `variants` carries the SURVEY 8(d) random-box placement
+    (log-uniform 8..64 px boxes, box_ind ~ U{0..B-1}) and the op as it ran inside the timed training steps."""
+    from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
+    from tests.helpers import random_boxes_3d, trainlike_rois_3d
+    p2 = tuple(int(v) for v in cf.backbone_shapes[0])
+    shape = (batch, cf.end_filts) + p2
+    crop = tuple(cf.mask_pool_size)
+    n = cf.train_rois_per_image * batch
+    V, P = int(np.prod(p2)), int(np.prod(crop))
+    alg = 4.0 * batch * cf.end_filts * V + 4.0 * n * cf.end_filts * P + 28.0 * n
+    rng = np.random.default_rng(0)
+    g = torch.randn((n, cf.end_filts) + crop, device=dev)
+    tb, ti = trainlike_rois_3d(rng, batch, cf.train_rois_per_image, 8.0, float(cf.patch_size[0]))
+    rb, ri = random_boxes_3d(rng, n), rng.integers(0, batch, size=n).astype(np.int32)
+    traffic = {}
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc", "traffic.json")))
+    except Exception:
+        pass
+
+    def case(boxes, ind, key):
+        bx, bi = torch.from_numpy(boxes).to(dev), torch.from_numpy(ind).to(dev)
+        mean_s, med_s = _time_op(lambda: _roi_align_impl.crop_backward(g, bx, bi, shape), launches)
+        rec = {"achieved": round(alg / mean_s / 1e9, 1), "frac": round(alg / mean_s / HBM_PEAK_BPS, 4), "avg_us": round(mean_s * 1e6, 2),
+               "median_us": round(med_s * 1e6, 2), "launches": launches, "alg_bytes_per_launch": int(alg), "mean_rois_on_level": float(n)}
+        t = traffic.get(key)
+        rec["traffic"] = t["hbm_bytes"] if t else None
+        return rec
+
+    head = case(tb, ti, "trainlike_48_rois")
+    variants = {"survey_8d_random_boxes_random_box_ind": case(rb, ri, "random_48_rois")}
+    # the same op as it ran inside the timed steps (random-init proposals are large: the level rule routes none to P2)
+    recs = [(a.elapsed_time(b) * 1e-3, m) for a, b, m in (in_step_prof or []) if m["im_size"] == shape and m["crop"] == crop]
+    if recs:
+        byts = [4.0 * batch * cf.end_filts * V + 4.0 * int(m["n_valid"].item()) * cf.end_filts * P + 28.0 * m["n_rows"] for _, m in recs]
+        dur = float(np.mean([d for d, _ in recs]))
+        variants["in_training_step"] = {"achieved": round(float(np.mean(byts)) / dur / 1e9, 1), "frac": round(float(np.mean(byts)) / dur / HBM_PEAK_BPS, 4),
+                                        "avg_us": round(dur * 1e6, 2), "launches": len(recs),
+                                        "mean_rois_on_level": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
+    out = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": head["frac"], "traffic": head["traffic"],
+           "traffic_source": "profiles/r02_pmc/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this op, tools/gpu_pmc.sh)" if head["traffic"] else None,
+           "kernel": "crop_bwd_territory_kernel (mdt_crop_and_resize_3d_backward): P2 %s, pool %s, %d RoIs forced onto the level, "
+                     "train-realistic placement (%d per batch element)" % ("x".join(map(str, shape)), "x".join(map(str, crop)), n, cf.train_rois_per_image),
+           "alg_bytes_per_launch": head["alg_bytes_per_launch"], "avg_us": head["avg_us"], "median_us": head["median_us"], "launches": launches,
+           "mean_rois_on_level": head["mean_rois_on_level"], "variants": variants}
+    return out
 
 
 def main():
@@ -147,32 +216,7 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        # roofline of the dominant custom kernel: RoIAlign-3D backward on the largest (P2) gradient map
-        p2_shape = (args.batch, cf.end_filts) + tuple(int(s) for s in cf.backbone_shapes[0])
-        recs = [(a.elapsed_time(b) * 1e-3, m) for a, b, m in prof if m["im_size"] == p2_shape and m["crop"] == tuple(cf.mask_pool_size)]
-        roofline = None
-        if recs:
-            V = int(np.prod(p2_shape[2:]))
-            P = int(np.prod(cf.mask_pool_size))
-            byts = [4.0 * p2_shape[0] * p2_shape[1] * V + 4.0 * int(m["n_valid"].item()) * p2_shape[1] * P + 28.0 * m["n_rows"] for _, m in recs]
-            dur = [d for d, _ in recs]
-            achieved = float(np.mean(byts)) / float(np.mean(dur))
-            mean_rois = float(np.mean([int(m["n_valid"].item()) for _, m in recs]))
-            # HBM traffic per launch from rocprofv3 PMC passes of this very op (WRITE_SIZE + 2 x FETCH_SIZE, KB;
-            # profiles/r01_pmc/traffic.json, collected with tools/gpu_pmc.sh) -- counters cannot be read inside the bench
-            traffic, traffic_src = None, None
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc", "traffic.json")))
-                key = "no_rois_on_level" if mean_rois < 0.5 else "48_rois_on_level"
-                traffic, traffic_src = tj[key]["hbm_bytes"], "profiles/r01_pmc/traffic.json[%s]" % key
-            except Exception:
-                pass
-            roofline = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_BPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "kernel": "RoIAlign-3D backward, P2 %s, pool %s (expand||zero-fill + patch kernels, op-level)" % (
-                            "x".join(map(str, p2_shape)), "x".join(map(str, cf.mask_pool_size))),
-                        "alg_bytes_per_launch": int(np.mean(byts)), "avg_us": round(float(np.mean(dur)) * 1e6, 2), "launches": len(recs),
-                        "mean_rois_on_level": round(mean_rois, 2)}
+        roofline = roialign_bwd_roofline(cf, args.batch, dev, prof)
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.model == "mrcnn":
             try:

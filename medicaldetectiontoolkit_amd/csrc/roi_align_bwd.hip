@@ -49,7 +49,8 @@ namespace {
 typedef unsigned long long u64;
 
 constexpr int T_CAND = 64;         // RoIs scanned per chunk (N <= T_CAND: box table read once per workgroup)
-constexpr int T_GMAX = 8;          // RoIs staged per round (upper bound)
+constexpr int T_GMAX = 12;         // RoIs staged per round (upper bound)
+constexpr int T_SLOTS = 8;         // gradient blocks resident in LDS at a time (pass x runs per group of T_SLOTS)
 constexpr int T_HDR = 16;          // ints per staged RoI: bbq[4] (packed bounds, E offset), r, nuy, nux, nuz, aoff, boff, inv, line prefixes of passes 2 / 3
 constexpr int T_LDS_MAX = 80 * 1024;   // gfx950: 160 KB per CU, two workgroups of this kernel stay resident per CU
 constexpr int T_SEGLIST = 2048;         // territory segments listed in LDS (beyond: rank search per segment)
@@ -446,21 +447,21 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
         while (g0 < cnt) {
             int ng = min(p.G, cnt - g0);
             if (round > 0) lds_barrier();          // previous round's readers of the tables / blocks are done
-            // gradient blocks of the staged RoIs: global -> LDS (region A, slot j) by LDS-DMA, no staging registers;
-            // issued now, they stay in flight across the LDS-only barriers of (a)/(b) and are awaited before pass 1
-            {
-                int rj[T_GMAX];
+            // gradient blocks of RoIs [j0, j1) of the round: global -> LDS (region A, slot j - j0) by LDS-DMA, no staging
+            // registers.  The first T_SLOTS are issued now and stay in flight across the LDS-only barriers of (a)/(b)
+            auto issue_dma = [&](int j0, int j1) {
+                int rj[T_SLOTS];
 #pragma unroll
-                for (int j = 0; j < T_GMAX; ++j) rj[j] = (j < ng) ? list[g0 + j] : 0;
+                for (int j = 0; j < T_SLOTS; ++j) rj[j] = (j0 + j < j1) ? list[g0 + j0 + j] : 0;
                 const bool x4 = (P & 3) == 0;                       // 16-byte DMA when the blocks are 16-byte aligned
                 const int per = x4 ? 256 : 64;                      // floats per wave instruction
                 const int cpb = (P + per - 1) / per;                // chunks per block
-                for (int ci = wave; ci < ng * cpb; ci += NT / 64) {
+                for (int ci = wave; ci < (j1 - j0) * cpb; ci += NT / 64) {
                     const int j = ci / cpb;
                     const int k = ci - j * cpb;
                     int r = rj[0];
 #pragma unroll
-                    for (int jj = 1; jj < T_GMAX; ++jj) if (j == jj) r = rj[jj];
+                    for (int jj = 1; jj < T_SLOTS; ++jj) if (j == jj) r = rj[jj];
                     const float *blk = p.grads + ((long long)r * p.C + c) * P;
                     float *dstw = RA + j * p.P4 + k * per;          // wave-uniform; lane i lands at dstw + i * (4 | 16 bytes)
                     if (x4) {
@@ -475,7 +476,8 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                                                              (__attribute__((address_space(3))) void *)dstw, 4, 0, 0);
                     }
                 }
-            }
+            };
+            issue_dma(0, min(ng, T_SLOTS));
             // (a) sample tables of the staged RoIs (plo = voxel index for now); masks / flags cleared
             for (int t = tid; t < ng * psum; t += NT) {
                 const int j = t / psum;
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                 }
                 int ai = asz, bi = bsz;
 #pragma unroll
-                for (int d = 1; d < T_GMAX; d <<= 1) {
+                for (int d = 1; d < 16; d <<= 1) {
                     const int va = __shfl_up(ai, d), vb = __shfl_up(bi, d);
                     if (tid >= d) { ai += va; bi += vb; }
                 }
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                 if (!fits) { l2 = 0; l3 = 0; }
                 int l2i = l2, l3i = l3;
 #pragma unroll
-                for (int d = 1; d < T_GMAX; d <<= 1) {
+                for (int d = 1; d < 16; d <<= 1) {
                     const int v2 = __shfl_up(l2i, d), v3 = __shfl_up(l3i, d);
                     if (tid >= d) { l2i += v2; l3i += v3; }
                 }
@@ -578,15 +580,23 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
 
             // (c) streaming passes
             if (DIM == 3) {
-                {   // pass x: lines (j, py, pz): A[py][px][pz] -> B[py][ix][pz]
+                // pass x: lines (j, py, pz): A[py][px][pz] -> B[py][ix][pz], T_SLOTS RoIs at a time
+                for (int jg = 0; jg < ng; jg += T_SLOTS) {
+                    const int nj = min(T_SLOTS, ng - jg);
+                    if (jg > 0) {          // later groups: their blocks are fetched now (one exposed round trip)
+                        __syncthreads();
+                        issue_dma(jg, jg + nj);
+                        __syncthreads();
+                    }
                     const int lpr = p.ph * p.pd;                    // lines per RoI
-                    for (int t = tid; t < ng * lpr; t += NT) {
-                        const int j = t / lpr;
-                        const int l = t - j * lpr;
+                    for (int t = tid; t < nj * lpr; t += NT) {
+                        const int js = t / lpr;
+                        const int j = jg + js;
+                        const int l = t - js * lpr;
                         const int py = l / p.pd, pz = l - py * p.pd;
                         const int *h = hdr + j * T_HDR;
                         const int nux = h[6];
-                        stream_line(RA + j * p.P4 + py * p.pw * p.pd + pz, p.pd, RB + h[9] + py * nux * p.pd + pz, p.pd,
+                        stream_line(RA + js * p.P4 + py * p.pw * p.pd + pz, p.pd, RB + h[9] + py * nux * p.pd + pz, p.pd,
                                     tab + j * psum + p.ph, p.pw, nux, (h[10] & 2) != 0);
                     }
                 }
@@ -617,12 +627,21 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                     }
                 }
             } else {
-                // pass y: lines (j, px): A[py][px] -> B[iy][px]
-                for (int t = tid; t < ng * p.pw; t += NT) {
-                    const int j = t / p.pw;
-                    const int l = t - j * p.pw;
-                    const int *h = hdr + j * T_HDR;
-                    stream_line(RA + j * p.P4 + l, p.pw, RB + h[9] + l, p.pw, tab + j * psum, p.ph, h[5], (h[10] & 1) != 0);
+                // pass y: lines (j, px): A[py][px] -> B[iy][px], T_SLOTS RoIs at a time
+                for (int jg = 0; jg < ng; jg += T_SLOTS) {
+                    const int nj = min(T_SLOTS, ng - jg);
+                    if (jg > 0) {
+                        __syncthreads();
+                        issue_dma(jg, jg + nj);
+                        __syncthreads();
+                    }
+                    for (int t = tid; t < nj * p.pw; t += NT) {
+                        const int js = t / p.pw;
+                        const int j = jg + js;
+                        const int l = t - js * p.pw;
+                        const int *h = hdr + j * T_HDR;
+                        stream_line(RA + js * p.P4 + l, p.pw, RB + h[9] + l, p.pw, tab + j * psum, p.ph, h[5], (h[10] & 1) != 0);
+                    }
                 }
                 __syncthreads();
                 {   // pass x: lines (j, iy): B[iy][px] -> A[iy][ix]
@@ -677,20 +696,22 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                 const int seg = bit - row * p.nseg;
                 int y, x = 0;
                 if (DIM == 3) { y = row / p.W; x = row - y * p.W; } else { y = row; }
-                // bounding boxes of all staged RoIs from one batch of 16-byte reads
-                int4 bbq[T_GMAX];
-#pragma unroll
-                for (int j = 0; j < T_GMAX; ++j) bbq[j] = *reinterpret_cast<const int4 *>(hdr + ((j < ng) ? j : 0) * T_HDR);
                 if (s0 == split * SLOTS) TSTAMP(9);
                 if (QUAD) {
                     const int ci0 = seg * (4 * SL) + sl * 4;   // four consecutive indices along the contiguous axis
                     v4f *dst = reinterpret_cast<v4f *>(ovol + (long long)row * p.L + ci0);
                     v4f acc = {0.f, 0.f, 0.f, 0.f};
                     bool touched = false;
+                    for (int j0 = 0; j0 < ng; j0 += 4) {
+                    // bounding boxes of four staged RoIs from one batch of 16-byte reads
+                    int4 bbq[4];
 #pragma unroll
-                    for (int j = 0; j < T_GMAX; ++j) {
+                    for (int k = 0; k < 4; ++k) bbq[k] = *reinterpret_cast<const int4 *>(hdr + ((j0 + k < ng) ? j0 + k : 0) * T_HDR);
+#pragma unroll
+                    for (int jk = 0; jk < 4; ++jk) {
+                        const int j = j0 + jk;
                         if (j >= ng) break;
-                        const int4 bb = bbq[j];
+                        const int4 bb = bbq[jk];
                         if (y < (bb.x & 0xffff) || y > (bb.x >> 16)) continue;
                         const int *h = hdr + j * T_HDR;
                         const unsigned char *pj = pos + j * p.pos_stride;
@@ -718,6 +739,7 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                             if (pk != 255u) acc[k] = acc[k] + Ej[pk];
                         }
                     }
+                    }
                     if (round == 0 || touched) *dst = acc;
                     if (s0 == split * SLOTS) TSTAMP(10);
                 } else {
@@ -725,10 +747,8 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                         float *dst = ovol + (long long)row * p.L + ci;
                         float acc = 0.0f;
                         bool touched = false;
-#pragma unroll
-                        for (int j = 0; j < T_GMAX; ++j) {
-                            if (j >= ng) break;
-                            const int4 bb = bbq[j];
+                        for (int j = 0; j < ng; ++j) {
+                            const int4 bb = *reinterpret_cast<const int4 *>(hdr + j * T_HDR);
                             if (y < (bb.x & 0xffff) || y > (bb.x >> 16)) continue;
                             const int *h = hdr + j * T_HDR;
                             const unsigned char *pj = pos + j * p.pos_stride;
@@ -841,7 +861,7 @@ int territory_plan(int dim, int N, int B, int H, int W, int D, int ph, int pw, i
                             align16((size_t)G * p.mask_stride * sizeof(u64)) +
                             align16((size_t)G * T_HDR * sizeof(int)) + align16((size_t)p.bw * sizeof(u64)) +
                             align16((size_t)(p.bw + 1) * sizeof(int)) + (size_t)T_CAND * 7 * sizeof(int) + (size_t)T_SEGLIST * sizeof(unsigned short) + 16 * sizeof(int);
-        size_t a_fl = (size_t)G * p.P4;                      // all G gradient blocks resident
+        size_t a_fl = (size_t)((G < T_SLOTS) ? G : T_SLOTS) * p.P4;   // the resident gradient blocks
         if (a_fl < a_max) a_fl = a_max;
         if (rest + (a_fl + b_max) * sizeof(float) + 64 > lds_cap) continue;
         size_t b_fl = (lds_cap - rest) / sizeof(float) - 8 - a_fl;

@@ -39,3 +39,21 @@ def nms_boxes(rng, n, dim=3, patch=128.0, tie_free=True):
         b = np.stack([lo[:, 0], lo[:, 1], hi[:, 0], hi[:, 1]], 1)
     scores = rng.permutation(np.linspace(0.0, 1.0, n)) if tie_free else np.round(rng.uniform(0, 1, n), 1)
     return np.concatenate([b, scores[:, None]], 1).astype(np.float32)
+
+
+def trainlike_rois_3d(rng, batch, per_element=6, side=8.0, patch=128.0):
+    """RoIs as a training step hands them to one pyramid level (SURVEY.md 8(d) "train-realistic", forced onto one
+    level): `per_element` sampled RoIs per batch element (train_rois_per_image, lidc configs.py:258) scattered around
+    one object per element, box sides 0.75..1.4 x `side` px -- the sizes the level rule of mrcnn.py:403 routes to
+    the level whose anchor scale is `side` (8 px = P2).  Returns normalised boxes [batch*per_element, 6] f32 and
+    box_ind [batch*per_element] i32."""
+    ctr = rng.uniform(0.25, 0.75, size=(batch, 3))
+    rows = []
+    for b in range(batch):
+        for _ in range(per_element):
+            c = ctr[b] + rng.normal(0, 0.02, size=3)
+            s = rng.uniform(0.75 * side, 1.4 * side, size=3) / patch
+            rows.append([c[0] - s[0] / 2, c[1] - s[1] / 2, c[0] + s[0] / 2, c[1] + s[1] / 2, c[2] - s[2] / 2, c[2] + s[2] / 2])
+    boxes = np.clip(np.asarray(rows), 0.0, 1.0).astype(np.float32)
+    box_ind = (np.arange(batch * per_element) // per_element).astype(np.int32)
+    return boxes, box_ind

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from medicaldetectiontoolkit_amd import _lib  # noqa: E402
 from medicaldetectiontoolkit_amd.cuda_functions import _nms_impl, _roi_align_impl  # noqa: E402
-from tests.helpers import nms_boxes, random_boxes_3d  # noqa: E402
+from tests.helpers import nms_boxes, random_boxes_3d, trainlike_rois_3d  # noqa: E402
 
 HBM_PEAK = 8.0e12
 
@@ -79,16 +79,8 @@ def main():
             if N == 48:
                 # train-realistic placement: 6 sampled RoIs per batch element (train_rois_per_image), clustered around
                 # one object, sized as the level rule sends them to this level (box side ~ anchor scale of the level)
-                sc = {"P2": 8.0, "P3": 16.0, "P4": 32.0, "P5": 64.0}[lvl]
-                ctr = rng.uniform(0.25, 0.75, size=(B, 3))
-                tb = []
-                for b_ in range(B):
-                    for _ in range(6):
-                        c_ = ctr[b_] + rng.normal(0, 0.02, size=3)
-                        s_ = rng.uniform(0.75 * sc, 1.4 * sc, size=3) / 128.0
-                        tb.append([c_[0] - s_[0] / 2, c_[1] - s_[1] / 2, c_[0] + s_[0] / 2, c_[1] + s_[1] / 2, c_[2] - s_[2] / 2, c_[2] + s_[2] / 2])
-                tboxes = torch.tensor(np.clip(tb, 0, 1), dtype=torch.float32, device=dev)
-                tind = torch.arange(N, dtype=torch.int32, device=dev) // 6
+                tb, ti = trainlike_rois_3d(rng, B, 6, {"P2": 8.0, "P3": 16.0, "P4": 32.0, "P5": 64.0}[lvl])
+                tboxes, tind = torch.from_numpy(tb).to(dev), torch.from_numpy(ti).to(dev)
                 report("roialign3d_bwd_fast_trainlike_" + tag,
                        timeit(lambda: _roi_align_impl.crop_backward(g, tboxes, tind, shape), args.iters), bwd_bytes)
                 report("roialign3d_bwd_twophase_r1_trainlike_" + tag,

@@ -1,5 +1,6 @@
 """One case in a loop, for rocprofv3 --kernel-trace --stats.  Usage: profile_case.py <case> [iters]
-cases: bwd_fast | bwd_ordered | fwd | nms6000 | nms6000_keep75"""
+cases: bwd_fast | bwd_twophase | bwd_ordered | fwd | nms6000 | nms6000_keep75 | pmc_bwd
+env: MDT_N, MDT_CROP, MDT_ROIS=random|trainlike, MDT_INVALID=1"""
 import os
 import sys
 
@@ -9,7 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from medicaldetectiontoolkit_amd.cuda_functions import _nms_impl, _roi_align_impl  # noqa: E402
-from tests.helpers import nms_boxes, random_boxes_3d  # noqa: E402
+from tests.helpers import nms_boxes, random_boxes_3d, trainlike_rois_3d  # noqa: E402
 
 case = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -20,6 +21,9 @@ rng = np.random.default_rng(0)
 shape = (8, 36, 32, 32, 128)
 boxes = torch.from_numpy(random_boxes_3d(rng, N)).to(dev)
 box_ind = torch.from_numpy(rng.integers(0, 8, size=N).astype(np.int32)).to(dev)
+if os.environ.get("MDT_ROIS", "random") == "trainlike":   # 6 RoIs per element, P2-sized (tests/helpers.trainlike_rois_3d)
+    tb, ti = trainlike_rois_3d(rng, 8, N // 8, 8.0)
+    boxes, box_ind = torch.from_numpy(tb).to(dev), torch.from_numpy(ti).to(dev)
 if os.environ.get("MDT_INVALID"):        # all rows routed to other pyramid levels (what the random-init bench sees on P2)
     box_ind = torch.full_like(box_ind, -1)
 g = torch.randn((N, 36) + crop, device=dev)
@@ -28,6 +32,7 @@ dets = nms_boxes(rng, 6000)
 ds = torch.from_numpy(dets[np.argsort(-dets[:, -1].astype(np.float64), kind="stable")]).to(dev)
 fns = {
     "bwd_fast": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape),
+    "bwd_twophase": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="twophase"),
     "bwd_ordered": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="ordered"),
     "fwd": lambda: _roi_align_impl.crop_forward(image, boxes, box_ind, crop),
     "nms6000": lambda: _nms_impl.nms_sorted(ds, 0.7, 3),
