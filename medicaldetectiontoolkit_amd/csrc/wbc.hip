@@ -132,7 +132,9 @@ __global__ __launch_bounds__(WBC_THREADS) void wbc_kernel(
             const double cnt = tot[3];
             const double n_expected = n_ens * (tot[2] / cnt);           // n_ens * np.mean(match_n_ovs)
             double n_missing = n_expected - (double)u;                  // np.max((0, n_expected - n_unique))
-            if (!(n_missing > 0.0)) n_missing = 0.0;
+            // numpy's max propagates NaN (a member with an empty overlap slice has n_overlaps = NaN, predictor.py:434):
+            // the cluster score is then NaN and fails the `> 0.01` test below, exactly like the reference
+            if (n_missing == n_missing && !(n_missing > 0.0)) n_missing = 0.0;
             const double denom = tot[0] + n_missing * (tot[0] / cnt);   // + n_missing * np.mean(weights)
             const double avg_score = tot[1] / denom;
             if (avg_score > 0.01) {                                      // predictor.py:697

@@ -131,22 +131,26 @@ def collect_raw_boxes(net, data, cf, amp_dtype=None, rank_ix="0", test_aug=False
     dim = cf.dim
     assert dim == 3, "patch-tiled 3D prediction (2D slices go through merge_2D_to_3D_preds_per_patient)"
     dev = net.device_
+    # volumes smaller than the training patch are edge-padded to it, the surplus split low//2 | rest like
+    # dataloader_utils.pad_nd_image (experiments/lidc_exp/data_loader.py:346-349); like the reference, predictions
+    # stay in the PADDED frame (info["pad_below"] lets a caller shift them back)
+    pad_below = [0, 0, 0]
+    if any(data.shape[d + 1] < cf.patch_size[d] for d in range(3)):
+        diff = [max(cf.patch_size[d] - data.shape[d + 1], 0) for d in range(3)]
+        pad_below = [v // 2 for v in diff]
+        data = np.pad(data, [(0, 0)] + [(v // 2, v // 2 + v % 2) for v in diff], mode="edge")
     spatial = data.shape[1:]
     Y, X = spatial[0], spatial[1]
     coords = get_patch_crop_coords(np.zeros(spatial, dtype=np.uint8), cf.patch_size)
     n_patches = coords.shape[0]
-    overlap = np.zeros(spatial, dtype=np.uint8)
-    for pc in coords:
-        overlap[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += 1
     augs = [(False, False)] + ([(True, False), (False, True), (True, True)] if test_aug else [])
     items = [(a, p) for a in range(len(augs)) for p in range(n_patches)]
     mine = [items[i] for i in mdist.shard_indices(len(items))]
     rows = []
+    overlap0 = None
     seg_sum = np.zeros(spatial, dtype=np.float32) if with_seg else None
     for a, (fy, fx) in enumerate(augs):
         ids = [p for (aa, p) in mine if aa == a]
-        if not ids:
-            continue
         d = data
         c_a = coords.copy()
         if fy:      # mirrored image + mirrored crop coordinates (get_mirrored_patch_crops, predictor.py:777-816)
@@ -155,6 +159,12 @@ def collect_raw_boxes(net, data, cf, amp_dtype=None, rank_ix="0", test_aug=False
         if fx:
             d = d[:, :, ::-1]
             c_a[:, 2], c_a[:, 3] = X - coords[:, 3], X - coords[:, 2]
+        # patches covering each voxel, in the frame of THIS pass (spatial_tiling_forward builds it per call, :392-401)
+        overlap = np.zeros(spatial, dtype=np.uint8)
+        for pc in c_a:
+            overlap[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += 1
+        if a == 0:
+            overlap0 = overlap
         for i in range(0, len(ids), cf.batch_size):
             chunk = ids[i:i + cf.batch_size]
             res = _forward_patches(net, d, c_a, chunk, cf, amp_dtype, with_seg)
@@ -168,27 +178,30 @@ def collect_raw_boxes(net, data, cf, amp_dtype=None, rank_ix="0", test_aug=False
                     c = np.asarray(box["box_coords"], dtype=np.float64)
                     fac = box_patch_center_factor(c, cf.patch_size)
                     c = c + np.array([pc[0], pc[2], pc[0], pc[2], pc[4], pc[4]])
+                    # overlap count under the box, evaluated in the (possibly mirrored) frame of the pass BEFORE the box is
+                    # mirrored back.  The reference slices the y axis with the x coordinates and vice versa, lets numpy
+                    # wrap negative starts and takes np.mean of what is left -- NaN when the slice is empty, which happens
+                    # on non-square volumes (predictor.py:432-434).  Reproduced literally.
+                    ic = [int(np.floor(v)) if ix % 2 == 0 else int(np.ceil(v)) for ix, v in enumerate(c)]
+                    region = overlap[ic[1]:ic[3], ic[0]:ic[2], ic[4]:ic[5]]
+                    n_ov = float(np.mean(region)) if region.size else float("nan")
                     if fy:
                         c[0], c[2] = Y - c[2], Y - c[0]
                     if fx:
                         c[1], c[3] = X - c[3], X - c[1]
-                    rows.append(list(c) + [float(box["box_score"]), float(box["box_pred_class_id"]), fac, float(a * n_patches + p)])
-    local = torch.tensor(rows, dtype=torch.float64, device=dev).view(-1, 10)
+                    rows.append(list(c) + [float(box["box_score"]), float(box["box_pred_class_id"]), fac, float(a * n_patches + p), n_ov])
+    local = torch.tensor(rows, dtype=torch.float64, device=dev).view(-1, 11)
     allrows = mdist.gather_rows(local).cpu().numpy()
     raw = []
     for r in allrows:
-        # overlap count under the box; the reference slices the y axis with x coordinates and vice versa
-        # (predictor.py:434) -- reproduced
-        ic = [int(np.floor(v)) if ix % 2 == 0 else int(np.ceil(v)) for ix, v in enumerate(r[:6])]
-        region = overlap[max(ic[1], 0):ic[3], max(ic[0], 0):ic[2], max(ic[4], 0):ic[5]]
         q = int(r[9])
         raw.append({"box_type": "det", "box_coords": r[:6].copy(), "box_score": float(r[6]), "box_pred_class_id": int(r[7]),
                     "patch_id": "%s_%d_%d" % (rank_ix, q // n_patches, q % n_patches), "box_patch_center_factor": float(r[8]),
-                    "box_n_overlaps": float(np.mean(region)) if region.size else 0.0})
-    info = {"n_patches": n_patches, "n_passes": len(augs)}
+                    "box_n_overlaps": float(r[10])})
+    info = {"n_patches": n_patches, "n_passes": len(augs), "pad_below": pad_below, "padded_shape": tuple(spatial)}
     if with_seg:
-        m = overlap > 0
-        seg_sum[m] /= overlap[m]
+        m = overlap0 > 0
+        seg_sum[m] /= overlap0[m]
         info["seg_preds"] = seg_sum[None, None]
     return raw, info
 

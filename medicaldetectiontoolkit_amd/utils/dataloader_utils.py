@@ -1,33 +1,36 @@
-"""Mirror of the one hot-path function of the reference's utils/dataloader_utils.py."""
+"""Patch tiling of a patient volume -- the one hot-path function of the reference's utils/dataloader_utils.py
+(get_patch_crop_coords, :140-180; consumed by Predictor.spatial_tiling_forward, predictor.py:398-440)."""
 import numpy as np
 
 
+def _axis_intervals(extent, patch, min_overlap):
+    """[lo, hi) float bounds of the patches along one axis.  One patch spans the axis when it fits; otherwise the two
+    outer patches touch the borders and the rest are spread evenly, one extra patch being added when neighbours
+    would overlap by less than `min_overlap` (:151-165).  Centres are rounded with numpy's round-half-to-even."""
+    count = -(-int(extent) // int(patch))
+    if count == 1:
+        return np.zeros(1), np.full(1, float(extent))
+    stride = (extent - patch) / (count - 1)
+    if patch - stride < min_overlap:
+        count += 1
+        stride = (extent - patch) / (count - 1)
+    centres = np.round(patch / 2 + stride * np.arange(count))
+    return centres - patch / 2, centres + patch / 2
+
+
 def get_patch_crop_coords(img, patch_size, min_overlap=30):
-    """Patch tiling grid (utils/dataloader_utils.py:140-180).
-    img: array (or anything with .shape) of spatial shape (y, x, (z)); returns int [n_patches, 2*dim] rows
-    (y0, y1, x0, x1, (z0, z1))."""
-    shape = tuple(img.shape)
-    per_axis = []
-    for d in range(len(shape)):
-        n_patches = int(np.ceil(shape[d] / patch_size[d]))
-        if n_patches == 1:
-            per_axis.append([(0, shape[d])])
-            continue
-        center_dists = (shape[d] - patch_size[d]) / (n_patches - 1)
-        if (patch_size[d] - center_dists) < min_overlap:
-            n_patches += 1
-            center_dists = (shape[d] - patch_size[d]) / (n_patches - 1)
-        centers = np.round([(patch_size[d] / 2 + (center_dists * ii)) for ii in range(n_patches)])
-        per_axis.append([(c - patch_size[d] / 2, c + patch_size[d] / 2) for c in centers])
-    grid = []
-    for ymin, ymax in per_axis[0]:
-        for xmin, xmax in per_axis[1]:
-            if len(per_axis) == 3 and patch_size[2] > 1:
-                for zmin, zmax in per_axis[2]:
-                    grid.append([ymin, ymax, xmin, xmax, zmin, zmax])
-            elif len(per_axis) == 3 and patch_size[2] == 1:
-                for zmin in range(shape[2]):
-                    grid.append([ymin, ymax, xmin, xmax, zmin, zmin + 1])
-            else:
-                grid.append([ymin, ymax, xmin, xmax])
-    return np.array(grid).astype(int)
+    """img: anything with a spatial .shape (y, x[, z]).  Returns int [n_patches, 2*dim] rows (y0, y1, x0, x1[, z0, z1]),
+    y slowest and z fastest; with patch_size[2] == 1 every z slice is its own patch (2D models on 3D volumes)."""
+    shape = tuple(int(s) for s in img.shape)
+    bounds = []
+    for axis, extent in enumerate(shape):
+        if axis == 2 and patch_size[2] == 1:
+            lo = np.arange(extent, dtype=np.float64)
+            bounds.append((lo, lo + 1))
+        else:
+            bounds.append(_axis_intervals(extent, patch_size[axis], min_overlap))
+    pick = np.indices([len(lo) for lo, _ in bounds]).reshape(len(bounds), -1)      # C order: last axis fastest
+    cols = []
+    for axis, (lo, hi) in enumerate(bounds):
+        cols += [lo[pick[axis]], hi[pick[axis]]]
+    return np.stack(cols, axis=1).astype(int)

@@ -1,0 +1,61 @@
+"""Seeded inputs + a canned "network" for the prediction-pipeline parity case.
+Used by BOTH tests/golden/make_predictor_golden.py (drives the reference's Predictor.data_aug_forward /
+spatial_tiling_forward / apply_wbc_to_patient) and tests/test_predictor_parity_gpu.py (drives
+medicaldetectiontoolkit_amd.predictor.collect_raw_boxes / apply_wbc_to_patient).
+
+The patient volume is a position ramp, so a patch's content tells where it was cut and how it was mirrored; the
+canned net returns, for every patch, boxes that depend only on (mirror pass, patch origin) -- both pipelines therefore
+see identical per-patch "network outputs" no matter how they batch, order or mirror the patches."""
+import numpy as np
+
+VOLUME = (88, 120, 40)        # non-square xy: exercises the y/x swap of predictor.py:434
+PATCH = [32, 32, 16]
+
+
+def make_cf():
+    from medicaldetectiontoolkit_amd.configs import Configs
+    return Configs(dim=3, model="mrcnn", patch_size=PATCH, batch_size=8)
+
+
+def make_volume():
+    Y, X, Z = VOLUME
+    yy, xx, zz = np.meshgrid(np.arange(Y), np.arange(X), np.arange(Z), indexing="ij")
+    return (yy * X * Z + xx * Z + zz).astype(np.float32)[None]          # [1, Y, X, Z], exact in fp32
+
+
+class CannedNet(object):
+    """test_forward(batch) -> {'boxes': [[box dicts] per patch], 'seg_preds': zeros}: 0-3 detections per patch"""
+
+    def __init__(self, device=None):
+        self.device_ = device
+        self.calls = 0
+
+    @staticmethod
+    def _identify(patch):
+        """patch [1, py, px, pz] of the ramp -> (flip_y, flip_x, y0, x0, z0) of the un-mirrored crop"""
+        Y, X, Z = VOLUME
+        p = patch[0]
+        fy = bool(p[1, 0, 0] < p[0, 0, 0])
+        fx = bool(p[0, 1, 0] < p[0, 0, 0])
+        corner = p[-1 if fy else 0, -1 if fx else 0, 0]
+        v = int(round(float(corner)))
+        return fy, fx, v // (X * Z), (v // Z) % X, v % Z
+
+    def boxes_for(self, fy, fx, y0, x0, z0):
+        rng = np.random.default_rng([int(fy), int(fx), y0, x0, z0])
+        out = []
+        for _ in range(int(rng.integers(0, 4))):
+            c = rng.uniform([4, 4, 2], [28, 28, 14])
+            s = rng.uniform([3, 3, 2], [14, 14, 8])
+            lo = np.clip(np.round(c - s / 2), 0, PATCH)
+            hi = np.clip(np.round(c + s / 2), 0, PATCH)
+            hi = np.maximum(hi, lo + 1)
+            out.append({"box_coords": np.array([lo[0], lo[1], hi[0], hi[1], lo[2], hi[2]], dtype=np.int32), "box_type": "det",
+                        "box_score": float(rng.uniform(0.1, 0.99)), "box_pred_class_id": int(rng.integers(1, 3))})
+        return out
+
+    def test_forward(self, batch, **kwargs):
+        self.calls += 1
+        data = np.asarray(batch["data"])
+        boxes = [self.boxes_for(*self._identify(data[i])) for i in range(data.shape[0])]
+        return {"boxes": boxes, "seg_preds": np.zeros((data.shape[0], 1) + tuple(data.shape[2:]), dtype=np.uint8)}

@@ -1,0 +1,66 @@
+"""Prediction-pipeline parity: patch tiling, the 4 mirrored passes,
+un-mirroring, patch ids, box_patch_center_factor, box_n_overlaps (incl. the reference's y/x swap and its NaN on
+non-square volumes) and weighted box clustering, against the reference's own Predictor methods
+(tests/golden/predictor_reference.npz, made by tests/golden/make_predictor_golden.py)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from tests.golden import predictor_inputs as pi
+from tests.golden import wbc_inputs
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "predictor_reference.npz"))
+
+
+def test_patch_tiler_fuzz_vs_reference():
+    """get_patch_crop_coords (dataloader_utils.py:140-180) over 200 seeded shapes / patch sizes (CPU)"""
+    from medicaldetectiontoolkit_amd.utils.dataloader_utils import get_patch_crop_coords
+    h = hashlib.sha256()
+    for shape, ps in wbc_inputs.tiler_cases():
+        h.update(np.ascontiguousarray(get_patch_crop_coords(np.zeros(shape, np.uint8), ps).astype(np.int64)).tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), G["tiler_fuzz_sha256"])
+    assert np.array_equal(get_patch_crop_coords(np.zeros(pi.VOLUME, np.uint8), pi.PATCH), G["patch_crop_coords"])
+
+
+def _table(boxes):
+    rows = []
+    for b in boxes:
+        _, aug, pix = b["patch_id"].split("_")
+        rows.append(list(np.asarray(b["box_coords"], dtype=np.float64)) + [b["box_score"], b["box_pred_class_id"], float(aug), float(pix),
+                                                                           b["box_patch_center_factor"], b["box_n_overlaps"]])
+    a = np.asarray(rows, dtype=np.float64)
+    return a[np.lexsort((a[:, 6], a[:, 9], a[:, 8]))]
+
+
+@pytest.mark.gpu
+def test_collect_raw_boxes_and_wbc_vs_reference(cuda):
+    from medicaldetectiontoolkit_amd import predictor
+    cf = pi.make_cf()
+    net = pi.CannedNet(device=cuda)
+    raw, info = predictor.collect_raw_boxes(net, pi.make_volume(), cf, test_aug=True)
+    assert info["n_patches"] == G["patch_crop_coords"].shape[0] and info["n_passes"] == 4
+    got, want = _table(raw), G["raw_table"]
+    assert got.shape == want.shape
+    assert np.array_equal(got[:, :10], want[:, :10])                            # coords (un-mirrored), score, class, pass, patch
+    assert np.allclose(got[:, 10], want[:, 10], rtol=1e-12, atol=0)             # box_patch_center_factor
+    assert np.array_equal(np.isnan(got[:, 11]), np.isnan(want[:, 11]))          # the reference's empty-slice NaNs
+    ok = ~np.isnan(want[:, 11])
+    assert np.allclose(got[ok, 11], want[ok, 11], rtol=1e-12, atol=0)           # box_n_overlaps
+    wbc = predictor.apply_wbc_to_patient(raw, cf, 4, device=cuda)
+    t = np.array([list(np.asarray(b["box_coords"], dtype=np.float64)) + [b["box_score"], b["box_pred_class_id"]] for b in wbc])
+    t = t[np.lexsort((t[:, 6], t[:, 7]))]
+    assert t.shape == G["wbc_table"].shape
+    assert np.allclose(t, G["wbc_table"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_wbc_full_config5_size_vs_reference(cuda):
+    """weighted_box_clustering at n = 45 000 (75 patches x 30 dets x 4 TTA x 5 epochs, BASELINE config 5)"""
+    from medicaldetectiontoolkit_amd import predictor
+    dets, pid = wbc_inputs.wbc_case(45000, 20, seed=5)
+    ks, kc = predictor.weighted_box_clustering(dets, pid, 1e-5, 20, device=cuda)
+    assert len(ks) == G["wbc45000_scores"].shape[0]
+    assert np.allclose(np.array(ks), G["wbc45000_scores"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(np.array(kc), G["wbc45000_coords"], rtol=1e-9, atol=1e-9)
