@@ -10,10 +10,10 @@ CACHE_DIR = os.path.join(HERE, "miopen_cache")
 
 def setup(cache_dir=None):
     d = cache_dir or os.environ.get("MDT_MIOPEN_CACHE", CACHE_DIR)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and cache_dir is None and "MDT_MIOPEN_CACHE" not in os.environ:
-        # one process per GPU: every rank works on its own copy of the in-tree cache, so N ranks never write the
-        # same find-db / kernel-cache files concurrently
+    if cache_dir is None and "MDT_MIOPEN_CACHE" not in os.environ and not os.environ.get("MDT_MIOPEN_CACHE_INPLACE"):
+        # every process works on its OWN copy of the in-tree cache (seeded from it): N ranks never write the same
+        # find-db / kernel-cache files concurrently, and a run never dirties the committed files.
+        # MDT_MIOPEN_CACHE_INPLACE=1 writes into the tree (to refresh the committed cache after a new find).
         import shutil
         import tempfile
         rank = os.environ.get("RANK", "0")

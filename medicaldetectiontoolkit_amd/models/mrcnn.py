@@ -48,6 +48,20 @@ class RPN(nn.Module):
         return [rpn_class_logits, rpn_probs, rpn_bbox]
 
 
+def _forward_valid_rows(fn, feature_maps, rois):
+    """The glue keeps fixed-size tensors whose padding rows carry batch_ix = -1 and pool to all-zero features.  With
+    cf.norm == 'batch_norm' those rows would enter the heads' batch statistics (the reference only ever forwards real
+    samples, mrcnn.py:1075-1076), so in that configuration the heads run on the valid rows only and the outputs are
+    scattered back -- at the price of one host sync (nonzero); norm=None / instance_norm never take this path."""
+    keep = torch.nonzero(rois[:, -1] >= 0)[:, 0]
+    outs = fn(feature_maps, rois[keep])
+    full = []
+    for o in outs:
+        z = torch.zeros((rois.shape[0],) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
+        full.append(z.index_copy(0, keep, o))
+    return full
+
+
 class Classifier(nn.Module):
     """Classification + box-refinement head (mrcnn.py:89-127)."""
 
@@ -62,8 +76,14 @@ class Classifier(nn.Module):
         self.conv2 = conv(cf.end_filts * 4, cf.end_filts * 4, ks=1, stride=1, norm=norm, relu=cf.relu)
         self.linear_class = nn.Linear(cf.end_filts * 4, cf.head_classes)
         self.linear_bbox = nn.Linear(cf.end_filts * 4, cf.head_classes * 2 * self.dim)
+        self.compact_rows = norm == "batch_norm"
 
     def forward(self, x, rois):
+        if self.compact_rows:
+            return _forward_valid_rows(self._forward, x, rois)
+        return self._forward(x, rois)
+
+    def _forward(self, x, rois):
         x = pyramid_roi_align(x, rois, self.pool_size, self.pyramid_levels, self.dim)
         x = self.conv2(self.conv1(x))
         x = x.view(-1, self.in_channels * 4)
@@ -89,8 +109,14 @@ class Mask(nn.Module):
         self.relu = nn.ReLU(inplace=True) if cf.relu == "relu" else nn.LeakyReLU(inplace=True)
         self.conv5 = conv(cf.end_filts, cf.head_classes, ks=1, stride=1, relu=None)
         self.sigmoid = nn.Sigmoid()
+        self.compact_rows = cf.norm == "batch_norm"
 
     def forward(self, x, rois):
+        if self.compact_rows:
+            return _forward_valid_rows(lambda a, b: [self._forward(a, b)], x, rois)[0]
+        return self._forward(x, rois)
+
+    def _forward(self, x, rois):
         x = pyramid_roi_align(x, rois, self.pool_size, self.pyramid_levels, self.dim)
         x = self.conv4(self.conv3(self.conv2(self.conv1(x))))
         x = self.relu(self.deconv(x))

@@ -247,6 +247,7 @@ def predict_test_set(net, patients, cf, checkpoint_paths=None, out_dir=None, tes
     from .utils import exp_utils
     test_aug = cf.test_aug if test_aug is None else test_aug
     members = list(checkpoint_paths) if checkpoint_paths else [None]
+    patients = list(patients)                       # iterated once per ensemble member
     raw_per_patient = {}
     order = []
     n_passes = 1

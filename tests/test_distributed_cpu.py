@@ -42,10 +42,13 @@ def _worker(rank, world, port, out):
     net = Tiny()
     torch.manual_seed(100 + rank)
     x = torch.randn(5, 4)
+    sync = training.FlatGradAllReduce(net, n_buckets=3)
+    sync.zero()
     loss = net(x, use_second=(rank == 0))
-    loss.backward()
-    training.FlatGradAllReduce(net)()
+    loss.backward()                      # bucket all-reduces start from the gradient hooks, in bucket order
+    sync.finish()
     grads = {n: p.grad.clone() for n, p in net.named_parameters()}
+    assert all(p.grad.untyped_storage().data_ptr() == sync.flat.untyped_storage().data_ptr() for p in net.parameters())
     # inference exchange: rank r contributes r + 1 rows
     rows = torch.full((rank + 1, 3), float(rank))
     gathered = mdist.gather_rows(rows)
@@ -84,7 +87,9 @@ def test_single_process_helpers_are_identity():
     t = torch.arange(6.0).view(2, 3)
     assert mdist.gather_rows(t) is t
     assert mdist.shard_indices(5) == [0, 1, 2, 3, 4]
-    training.FlatGradAllReduce(Tiny())()   # no process group: no-op
+    sync = training.FlatGradAllReduce(Tiny())
+    sync.zero()
+    sync.finish()   # no process group: no-op
 
 
 def test_checkpoint_roundtrip_reference_format(tmp_path):
@@ -109,3 +114,33 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     net3 = Tiny()
     start3, _ = exp_utils.load_checkpoint(str(tmp_path / "7_best_checkpoint"), net3)
     assert start3 == 1 and all(torch.equal(a, b) for a, b in zip(net.parameters(), net3.parameters()))
+
+
+def _predict_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from medicaldetectiontoolkit_amd import predictor
+    from tests.golden import predictor_inputs as pi
+    net = pi.CannedNet(device=torch.device("cpu"))
+    raw, info = predictor.collect_raw_boxes(net, pi.make_volume(), pi.make_cf(), test_aug=True)
+    if rank == 0:
+        torch.save({"raw": raw, "calls": net.calls, "info": info}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collect_raw_boxes_two_ranks_equals_reference(tmp_path):
+    """config-5 inference sharding: the patch x mirror-pass work list split round-robin over 2 ranks and
+    exchanged with the padded all_gather gives exactly the raw-box table of the reference's single-process pipeline"""
+    import numpy as np
+    from tests.test_predictor_parity_gpu import G, _table
+    out = str(tmp_path / "pred.pt")
+    mp.spawn(_predict_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    t, want = _table(got["raw"]), G["raw_table"]
+    assert t.shape == want.shape and np.array_equal(t[:, :10], want[:, :10])
+    assert np.array_equal(np.isnan(t[:, 11]), np.isnan(want[:, 11]))
+    ok = ~np.isnan(want[:, 11])
+    assert np.allclose(t[ok, 10:], want[ok, 10:], rtol=1e-12, atol=0)
+    assert got["calls"] < 4 * 80 // 8 + 8          # rank 0 forwarded only its share of the 320 patches

@@ -45,6 +45,32 @@ def test_mrcnn_train_and_test_forward(dim, patch, cuda):
     assert res["seg_preds"].shape == (B, 1) + tuple(patch)
 
 
+def test_mrcnn_batch_norm_heads_see_only_real_samples(cuda):
+    """cf.norm = 'batch_norm': the RoI heads must not normalise over the padding slots of the fixed-size glue -- their
+    running statistics after a training step equal those of a forward over the valid rows alone"""
+    patch, B = [64, 64, 32], 2
+    cf = Configs(dim=3, model="mrcnn", patch_size=patch, batch_size=B, norm="batch_norm")
+    torch.manual_seed(0)
+    net = mrcnn.net(cf, device=cuda)
+    assert net.classifier.compact_rows and net.mask.compact_rows
+    opt = training.build_optimizer(net, cf)
+    r = training.train_step(net, opt, make_batch(patch, B, seed=0), monitor=False)
+    assert torch.isfinite(r["torch_loss"]).all()
+    # direct check on the mask head: padding rows (batch_ix = -1) leave outputs zero and do not touch the statistics
+    fm = [torch.randn(B, cf.end_filts, *[int(v) for v in s], device=cuda) for s in cf.backbone_shapes]
+    rois = torch.tensor([[0.1, 0.1, 0.4, 0.4, 0.1, 0.6, 0.0], [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0],
+                         [0.3, 0.2, 0.8, 0.7, 0.2, 0.9, 1.0], [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, -1.0]], device=cuda)
+    net.train()
+    bn = [m for m in net.mask.modules() if isinstance(m, torch.nn.BatchNorm3d)][0]
+    before = bn.running_mean.clone()
+    out_all = net.mask(fm, rois)
+    after_all = bn.running_mean.clone()
+    bn.running_mean.copy_(before)
+    out_valid = net.mask(fm, rois[[0, 2]])
+    assert torch.allclose(after_all, bn.running_mean, atol=1e-6)
+    assert torch.allclose(out_all[[0, 2]], out_valid, atol=1e-5) and float(out_all[[1, 3]].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("model,dim,patch", [("retina_unet", 3, [64, 64, 32]), ("retina_net", 2, [64, 64])])
 def test_retina_train_and_test_forward(model, dim, patch, cuda):
     B = 2

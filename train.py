@@ -64,13 +64,14 @@ def main():
     sync = training.FlatGradAllReduce(net) if world > 1 else None
     fold_dir = os.path.join(args.exp_dir, "fold_0")
     start_epoch = 1
+    loaded_metrics = None
     if args.resume and os.path.exists(os.path.join(fold_dir, "last_checkpoint", "params.pth")):
-        start_epoch, _ = exp_utils.load_checkpoint(os.path.join(fold_dir, "last_checkpoint"), net, opt, map_location=dev)
+        start_epoch, loaded_metrics = exp_utils.load_checkpoint(os.path.join(fold_dir, "last_checkpoint"), net, opt, map_location=dev)
         if rank == 0:
             print("resumed to checkpoint at epoch {}".format(start_epoch), flush=True)
     torch.manual_seed(1000 + rank)
 
-    metrics = {"train": {"loss": [None]}}
+    metrics = loaded_metrics if loaded_metrics else {"train": {"loss": [None]}}     # exec.py continues the loaded dict
     for epoch in range(start_epoch, cf.num_epochs + 1):
         for g in opt.param_groups:                       # exec.py:59-60: per-epoch learning-rate list
             g["lr"] = cf.learning_rate[min(epoch - 1, len(cf.learning_rate) - 1)]
