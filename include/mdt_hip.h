@@ -60,6 +60,19 @@ int mdt_crop_and_resize_3d_forward(
     int crop_height, int crop_width, int crop_zdepth, int depth,
     float extrapolation_value, float *crops, void *stream);
 
+/* bf16-input forms of the two forward entry points (SURVEY.md 8a precision note (iii), BASELINE config 5: bf16 autocast
+ * inference): `image` holds bfloat16 values (raw 16-bit patterns), every load is widened exactly to fp32 and the
+ * interpolation and the output stay fp32 -- results equal the fp32 entry point on the widened tensor bit for bit,
+ * with half the gathered bytes and without a conversion pass over the feature map.  Forward only. */
+int mdt_crop_and_resize_3d_forward_bf16(
+    const uint16_t *image, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
+    int crop_height, int crop_width, int crop_zdepth, int depth, float *crops, void *stream);
+int mdt_crop_and_resize_2d_forward_bf16(
+    const uint16_t *image, const float *boxes, const int *box_ind,
+    int num_boxes, int batch, int image_height, int image_width,
+    int crop_height, int crop_width, int depth, float *crops, void *stream);
+
 /*
  * Replaces CropAndResizeBackpropImageLaucher (3D)
  *   crop_and_resize_kernel.h:14-18 (kernel: crop_and_resize_kernel.cu:154-304)

@@ -20,6 +20,8 @@ _SIGNATURES = {
     "mdt_version": (c_char_p, []),
     "mdt_error_string": (c_char_p, [c_int]),
     "mdt_crop_and_resize_3d_forward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_float, c_void_p, c_void_p]),
+    "mdt_crop_and_resize_3d_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
+    "mdt_crop_and_resize_2d_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
     "mdt_crop_and_resize_backward_workspace_bytes": (c_size_t, [c_int] * 9),
     "mdt_crop_and_resize_3d_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_crop_and_resize_backward_twophase_workspace_bytes": (c_size_t, [c_int] * 9),

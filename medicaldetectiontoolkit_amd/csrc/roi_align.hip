@@ -24,6 +24,7 @@
 // HBM-bound gather/scatter work: no MFMA.  Algorithmic bytes:
 //   bwd: 4*B*C*V (grad_image written once) + 4*N*C*P (grads read once) + 28*N.
 
+#include <type_traits>
 #include "roi_align_common.h"
 
 using namespace mdt_ra;
@@ -39,9 +40,15 @@ constexpr int FWD_SLAB = FWD_THREADS * FWD_PER_THREAD;
 
 // DIM == 3: image [B,C,H,W,D], boxes [N,6], crops [N,C,ch,cw,cd]
 // DIM == 2: image [B,C,H,W],   boxes [N,4], crops [N,C,ch,cw]      (D = cd = 1)
-template <int DIM>
+// input element: fp32, or bf16 (raw 16-bit pattern, widened exactly to fp32 on load -- the interpolation itself is
+// always fp32; used by the autocast inference path, where it halves the gathered bytes)
+struct bf16raw { unsigned short v; };
+__device__ __forceinline__ float ld(const float *p, long long i) { return p[i]; }
+__device__ __forceinline__ float ld(const bf16raw *p, long long i) { return __uint_as_float(((unsigned int)p[i].v) << 16); }
+
+template <int DIM, typename TIN>
 __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_kernel(
-    const float *__restrict__ image, const float *__restrict__ boxes,
+    const TIN *__restrict__ image, const float *__restrict__ boxes,
     const int *__restrict__ box_ind, int B, int H, int W, int D,
     int ch, int cw, int cd, int C, float *__restrict__ crops)
 {
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_kernel(
         const AxisEntry ex = tab[ch + x];
         const int top = ey.lo, bottom = entry_hi(ey);
         const int left = ex.lo, right = entry_hi(ex);
-        const float *pimage = image + ((long long)b_in * C + c) * vol;
+        const TIN *pimage = image + ((long long)b_in * C + c) * vol;
 
         if (DIM == 3) {
             const AxisEntry ez = tab[ch + cw + z];
@@ -104,10 +111,10 @@ __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_kernel(
             const long long rt_r = (long long)D * (right + (long long)W * top);
             const long long rb_l = (long long)D * (left + (long long)W * bottom);
             const long long rb_r = (long long)D * (right + (long long)W * bottom);
-            const float tlf = pimage[front + rt_l], trf = pimage[front + rt_r];
-            const float blf = pimage[front + rb_l], brf = pimage[front + rb_r];
-            const float tlb = pimage[back + rt_l], trb = pimage[back + rt_r];
-            const float blb = pimage[back + rb_l], brb = pimage[back + rb_r];
+            const float tlf = ld(pimage, front + rt_l), trf = ld(pimage, front + rt_r);
+            const float blf = ld(pimage, front + rb_l), brf = ld(pimage, front + rb_r);
+            const float tlb = ld(pimage, back + rt_l), trb = ld(pimage, back + rt_r);
+            const float blb = ld(pimage, back + rb_l), brb = ld(pimage, back + rb_r);
             const float top_front = tlf + (trf - tlf) * ex.lerp;
             const float bottom_front = blf + (brf - blf) * ex.lerp;
             const float top_back = tlb + (trb - tlb) * ex.lerp;
@@ -116,10 +123,10 @@ __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_kernel(
             const float backv = top_back + (bottom_back - top_back) * ey.lerp;
             out[e] = frontv + (backv - frontv) * ez.lerp;
         } else {
-            const float tl = pimage[(long long)top * W + left];
-            const float tr = pimage[(long long)top * W + right];
-            const float bl = pimage[(long long)bottom * W + left];
-            const float br = pimage[(long long)bottom * W + right];
+            const float tl = ld(pimage, (long long)top * W + left);
+            const float tr = ld(pimage, (long long)top * W + right);
+            const float bl = ld(pimage, (long long)bottom * W + left);
+            const float br = ld(pimage, (long long)bottom * W + right);
             const float topv = tl + (tr - tl) * ex.lerp;
             const float bottomv = bl + (br - bl) * ex.lerp;
             out[e] = topv + (bottomv - topv) * ey.lerp;
@@ -1023,8 +1030,8 @@ __global__ __launch_bounds__(FWDS_THREADS) void crop_fwd_staged_kernel(
     }
 }
 
-template <int DIM>
-int launch_fwd(const float *image, const float *boxes, const int *box_ind, int N, int B,
+template <int DIM, typename TIN>
+int launch_fwd(const TIN *image, const float *boxes, const int *box_ind, int N, int B,
                int H, int W, int D, int ch, int cw, int cd, int C, float *crops, hipStream_t s)
 {
     if (N < 0 || B <= 0 || H <= 0 || W <= 0 || D <= 0 || ch <= 0 || cw <= 0 || cd <= 0 || C <= 0)
@@ -1038,7 +1045,7 @@ int launch_fwd(const float *image, const float *boxes, const int *box_ind, int N
     // (N=600 (7,7,3): 35 vs 58 us; N=240 (14,14,5): 56 vs 73 us) -- L1/L2 absorb the corner re-reads and the staged
     // form pays two barriers per channel -- so direct is the default; MDT_FWD_KERNEL=staged selects the other.
     const char *force = getenv("MDT_FWD_KERNEL");
-    const bool direct = !(force && force[0] == 's');
+    const bool direct = !(force && force[0] == 's') || !std::is_same<TIN, float>::value;
     if (!direct) {
         // channels per workgroup: enough workgroups to fill the chip, but amortise the table build
         int cpw = (int)(((long long)N * C + 4095) / 4096);
@@ -1049,7 +1056,7 @@ int launch_fwd(const float *image, const float *boxes, const int *box_ind, int N
             const size_t lds = (size_t)FWDS_BOX_FLOATS * sizeof(float) + tab_bytes;
             (void)hipGetLastError();
             hipLaunchKernelGGL(crop_fwd_staged_kernel<DIM>, dim3((unsigned)N, (unsigned)gy), dim3(FWDS_THREADS), lds, s,
-                               image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, cpw, crops);
+                               reinterpret_cast<const float *>(image), boxes, box_ind, B, H, W, D, ch, cw, cd, C, cpw, crops);
             return check_launch();
         }
     }
@@ -1057,7 +1064,7 @@ int launch_fwd(const float *image, const float *boxes, const int *box_ind, int N
     if (slabs > 65535) return MDT_ERR_UNSUPPORTED;
     dim3 grid((unsigned)N, (unsigned)slabs);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(crop_fwd_kernel<DIM>, grid, dim3(FWD_THREADS), tab_bytes, s,
+    hipLaunchKernelGGL((crop_fwd_kernel<DIM, TIN>), grid, dim3(FWD_THREADS), tab_bytes, s,
                        image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, crops);
     return check_launch();
 }
@@ -1220,8 +1227,24 @@ int mdt_crop_and_resize_3d_forward(const float *image, const float *boxes, const
                                    float extrapolation_value, float *crops, void *stream)
 {
     (void)extrapolation_value;
-    return launch_fwd<3>(image, boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth, crops,
-                         (hipStream_t)stream);
+    return launch_fwd<3, float>(image, boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth, crops,
+                                (hipStream_t)stream);
+}
+
+int mdt_crop_and_resize_3d_forward_bf16(const uint16_t *image, const float *boxes, const int *box_ind,
+                                        int num_boxes, int batch, int H, int W, int D,
+                                        int ch, int cw, int cd, int depth, float *crops, void *stream)
+{
+    return launch_fwd<3, bf16raw>(reinterpret_cast<const bf16raw *>(image), boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth,
+                                  crops, (hipStream_t)stream);
+}
+
+int mdt_crop_and_resize_2d_forward_bf16(const uint16_t *image, const float *boxes, const int *box_ind,
+                                        int num_boxes, int batch, int H, int W,
+                                        int ch, int cw, int depth, float *crops, void *stream)
+{
+    return launch_fwd<2, bf16raw>(reinterpret_cast<const bf16raw *>(image), boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth,
+                                  crops, (hipStream_t)stream);
 }
 
 int mdt_crop_and_resize_2d_forward(const float *image, const float *boxes, const int *box_ind,
@@ -1230,8 +1253,8 @@ int mdt_crop_and_resize_2d_forward(const float *image, const float *boxes, const
                                    float extrapolation_value, float *crops, void *stream)
 {
     (void)extrapolation_value;
-    return launch_fwd<2>(image, boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth, crops,
-                         (hipStream_t)stream);
+    return launch_fwd<2, float>(image, boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth, crops,
+                                (hipStream_t)stream);
 }
 
 size_t mdt_crop_and_resize_backward_workspace_bytes(int dim, int num_boxes, int depth,

@@ -31,7 +31,9 @@ def _prep(image, boxes, box_ind, dim):
         raise ValueError("box_ind must be [N]")
     # the reference's C glue never checks dtype / contiguity (crop_and_resize_gpu.c); do it here
     image = image.contiguous()
-    if image.dtype != torch.float32:
+    # bf16 feature maps (autocast inference, BASELINE config 5) go to the bf16-input kernel as they are when no gradient
+    # is needed; everything else is interpolated from fp32
+    if image.dtype != torch.float32 and not (image.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and image.requires_grad)):
         image = image.float()
     boxes = boxes.detach().to(device=image.device, dtype=torch.float32).contiguous()
     box_ind = box_ind.detach().to(device=image.device, dtype=torch.int32).contiguous()
@@ -48,7 +50,16 @@ def crop_forward(image, boxes, box_ind, crop, extrapolation_value=0.0):
         return crops
     with torch.cuda.device(image.device):
         s = _lib.current_stream_ptr()
-        if dim == 3:
+        if image.dtype == torch.bfloat16:
+            if dim == 3:
+                rc = L.mdt_crop_and_resize_3d_forward_bf16(
+                    _lib.ptr(image), _lib.ptr(boxes), _lib.ptr(box_ind), n, B, image.size(2), image.size(3), image.size(4),
+                    crop[0], crop[1], crop[2], C, _lib.ptr(crops), s)
+            else:
+                rc = L.mdt_crop_and_resize_2d_forward_bf16(
+                    _lib.ptr(image), _lib.ptr(boxes), _lib.ptr(box_ind), n, B, image.size(2), image.size(3),
+                    crop[0], crop[1], C, _lib.ptr(crops), s)
+        elif dim == 3:
             rc = L.mdt_crop_and_resize_3d_forward(
                 _lib.ptr(image), _lib.ptr(boxes), _lib.ptr(box_ind), n, B, image.size(2), image.size(3), image.size(4),
                 crop[0], crop[1], crop[2], C, ctypes.c_float(extrapolation_value), _lib.ptr(crops), s)

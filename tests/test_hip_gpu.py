@@ -150,6 +150,23 @@ def test_roialign3d_backward_deterministic_and_full_size(cuda):
     assert abs(lhs - rhs) < 1e-6 * max(1.0, mag)
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_roialign_forward_bf16_input_equals_fp32_on_widened(dim, cuda):
+    """bf16-in / fp32-interpolate forward (config 5, autocast inference): bit-identical to the fp32 kernel applied to the
+    widened tensor, i.e. to the oracle on the bf16-rounded feature map"""
+    rng = np.random.default_rng(5)
+    shape = (3, 8, 16, 16, 32) if dim == 3 else (3, 8, 40, 40)
+    crop = (7, 7, 3) if dim == 3 else (7, 7)
+    img = torch.from_numpy(rng.normal(size=shape).astype(np.float32)).to(cuda).to(torch.bfloat16)
+    boxes = random_boxes_3d(rng, 50, spill=True) if dim == 3 else random_boxes_2d(rng, 50, patch=64.0, size=(4, 60), spill=True)
+    ind = rng.integers(-1, 4, size=50).astype(np.int32)
+    with torch.no_grad():
+        got = _roi_align_impl.crop_forward(*_roi_align_impl._prep(img, _t(boxes, cuda), _t(ind, cuda), dim), crop)
+    assert got.dtype == torch.float32
+    want = oracle.crop_and_resize_forward(img.float().cpu().numpy(), boxes, ind, crop)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 def test_roialign_empty_and_quirks(cuda):
     img = torch.randn(2, 3, 8, 8, 8, device=cuda)
     out = ra3D(7, 7, 3, 0)(img, torch.zeros(0, 6, device=cuda), torch.zeros(0, dtype=torch.int32, device=cuda))
