@@ -160,6 +160,27 @@ int mdt_crop_and_resize_2d_backward_ordered(
     float *grads_image, void *stream);
 
 /* ------------------------------------------------------------------------- */
+/* Fused convolution epilogues (FPN / ResNet conv path)                       */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * y = act(x + bias[c] (+ residual)) in one pass; y may alias x.  The convolutions stay on MIOpen (torch); this
+ * replaces what torch runs around every one of them in the reference's graph: the broadcast bias add, the residual add
+ * of ResBlock.forward (models/backbone.py:203-205) / the top-down add of FPN.forward (:147-153), and the ReLU of
+ * NDConvGenerator's Sequential (utils/model_utils.py:770-779).
+ * n elements, channel(i) = (i / inner) % channels: inner = 1 for channels_last(_3d) storage, prod(spatial) for NC(D)HW.
+ */
+int mdt_bias_act_forward(float *y, const float *x, const float *bias, const float *residual /* or NULL */,
+                         long long n, int channels, long long inner, int relu, void *stream);
+
+/* gx = gy * (relu ? y > 0 : 1), gbias[c] = sum of gx over channel c -- one pass plus a small second stage, no atomics,
+ * fixed summation order (run-to-run deterministic).  y (the forward output) is only read when relu != 0. */
+size_t mdt_bias_act_backward_workspace_bytes(long long n, int channels, long long inner);
+int mdt_bias_act_backward(float *gx, const float *gy, const float *y, float *gbias,
+                          long long n, int channels, long long inner, int relu,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- */
 /* Non-maximum suppression                                                    */
 /* ------------------------------------------------------------------------- */
 

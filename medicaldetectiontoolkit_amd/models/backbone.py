@@ -5,6 +5,16 @@ the convolutions run on MIOpen through torch (the north star leaves the conv pat
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..utils.fused_epilogue import ConvBias
+
+
+def _lateral(conv, x, top_down):
+    """P_conv1(x) + upsampled coarser level (backbone.py:147-153): the add rides the conv's fused epilogue"""
+    if isinstance(conv, ConvBias):
+        return conv(x, residual=top_down)
+    return conv(x) + top_down
+
+
 
 class ResBlock(nn.Module):
     def __init__(self, start_filts, planes, conv, stride=1, downsample=None, norm=None, relu="relu"):
@@ -20,11 +30,12 @@ class ResBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        residual = x
-        out = self.conv3(self.conv2(self.conv1(x)))
-        if self.downsample is not None:
-            residual = self.downsample(x)
-        out = out + residual
+        residual = x if self.downsample is None else self.downsample(x)
+        out = self.conv2(self.conv1(x))
+        if isinstance(self.conv3, ConvBias) and isinstance(self.relu, nn.ReLU):
+            # bias + residual + ReLU of backbone.py:203-205 in one pass
+            return self.conv3(out, residual=residual, relu=True)
+        out = self.conv3(out) + residual
         return self.relu(out)
 
 
@@ -106,17 +117,17 @@ class FPN(nn.Module):
         if self.sixth_pooling:
             c6_out = self.C6(c5_out)
             p6_pre_out = self.P6_conv1(c6_out)
-            p5_pre_out = self.P5_conv1(c5_out) + F.interpolate(p6_pre_out, scale_factor=2)
+            p5_pre_out = _lateral(self.P5_conv1, c5_out, F.interpolate(p6_pre_out, scale_factor=2))
         else:
             p5_pre_out = self.P5_conv1(c5_out)
-        p4_pre_out = self.P4_conv1(c4_out) + F.interpolate(p5_pre_out, scale_factor=2)
-        p3_pre_out = self.P3_conv1(c3_out) + F.interpolate(p4_pre_out, scale_factor=2)
-        p2_pre_out = self.P2_conv1(c2_out) + F.interpolate(p3_pre_out, scale_factor=2)
+        p4_pre_out = _lateral(self.P4_conv1, c4_out, F.interpolate(p5_pre_out, scale_factor=2))
+        p3_pre_out = _lateral(self.P3_conv1, c3_out, F.interpolate(p4_pre_out, scale_factor=2))
+        p2_pre_out = _lateral(self.P2_conv1, c2_out, F.interpolate(p3_pre_out, scale_factor=2))
         out_list = [self.P2_conv2(p2_pre_out), self.P3_conv2(p3_pre_out), self.P4_conv2(p4_pre_out), self.P5_conv2(p5_pre_out)]
         if self.sixth_pooling:
             out_list.append(self.P6_conv2(p6_pre_out))
         if self.operate_stride1:
-            p1_pre_out = self.P1_conv1(c1_out) + self.P2_upsample(p2_pre_out)
-            p0_pre_out = self.P0_conv1(c0_out) + self.P1_upsample(p1_pre_out)
+            p1_pre_out = _lateral(self.P1_conv1, c1_out, self.P2_upsample(p2_pre_out))
+            p0_pre_out = _lateral(self.P0_conv1, c0_out, self.P1_upsample(p1_pre_out))
             out_list = [self.P0_conv2(p0_pre_out)] + out_list
         return out_list

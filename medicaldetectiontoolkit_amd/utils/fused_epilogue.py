@@ -1,0 +1,121 @@
+"""Fused convolution epilogues (csrc/epilogue.hip): y = act(conv(x) + bias (+ residual)) with the bias add, the
+residual / top-down add and the ReLU in ONE pass over the activation, and a backward that applies the ReLU mask and
+reduces the bias gradient in one pass (deterministic).  The convolution itself stays on MIOpen (torch, bias=None).
+
+The modules keep the reference's Sequential layout so state_dict keys are unchanged
+(utils/model_utils.py:732-781: `conv` -> Sequential(conv[, norm][, relu]) or a bare conv when relu is None)."""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from .. import _lib
+
+ENABLED = True      # module switch (A/B measurements: bench.py --fused-epilogue 0)
+
+
+def _layout(x):
+    """(inner, memory_format) of a dense activation, or None when it is neither contiguous nor channels-last"""
+    if x.is_contiguous():
+        inner = 1
+        for s in x.shape[2:]:
+            inner *= int(s)
+        return inner, torch.contiguous_format
+    mf = torch.channels_last_3d if x.dim() == 5 else torch.channels_last if x.dim() == 4 else None
+    if mf is not None and x.is_contiguous(memory_format=mf):
+        return 1, mf
+    return None
+
+
+_WS = {}       # per-device workspace of the backward's partial sums, grown on demand (stream-ordered reuse)
+
+
+def _workspace(nbytes, device):
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[device] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
+    return ws
+
+
+def _on_current_device(t):
+    return t.device.index is None or t.device.index == torch.cuda.current_device()
+
+
+class _BiasAct(Function):
+    """the per-call host work is kept minimal: these epilogues run ~150 times per training step"""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, relu, inner, mf):
+        if residual is not None and residual.stride() != x.stride():
+            residual = residual.contiguous(memory_format=mf)
+        if not _on_current_device(x):
+            raise RuntimeError("fused epilogue: tensor is not on the current device (one process per GPU)")
+        rc = _lib.lib().mdt_bias_act_forward(x.data_ptr(), x.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                             x.numel(), x.shape[1], inner, 1 if relu else 0, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "mdt_bias_act_forward")
+        ctx.mark_dirty(x)
+        ctx.relu, ctx.inner, ctx.mf, ctx.has_res = relu, inner, mf, residual is not None
+        if relu:
+            ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, gy):
+        y = ctx.saved_tensors[0] if ctx.relu else None
+        if not gy.is_contiguous(memory_format=ctx.mf):
+            gy = gy.contiguous(memory_format=ctx.mf)
+        L = _lib.lib()
+        n, C = gy.numel(), gy.shape[1]
+        gx = torch.empty_like(gy)
+        gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
+        wsb = (4096 * C * 4 + 256) if ctx.inner == 1 else L.mdt_bias_act_backward_workspace_bytes(n, C, ctx.inner)
+        ws = _workspace(wsb, gy.device)
+        rc = L.mdt_bias_act_backward(gx.data_ptr(), gy.data_ptr(), y.data_ptr() if y is not None else None, gbias.data_ptr(), n, C, ctx.inner,
+                                     1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "mdt_bias_act_backward")
+        return gx, gbias, (gx if ctx.has_res else None), None, None, None
+
+
+def bias_act(x, bias, residual=None, relu=False):
+    """x: fresh fp32 conv output on the GPU (modified in place); falls back to torch ops otherwise"""
+    if ENABLED and x.is_cuda and x.dtype == torch.float32 and bias is not None and bias.dtype == torch.float32 \
+            and (residual is None or (residual.dtype == torch.float32 and residual.shape == x.shape)):
+        lay = _layout(x)
+        if lay is not None:
+            return _BiasAct.apply(x, bias, residual, relu, lay[0], lay[1])
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    y = x + bias.view(shape).to(x.dtype) if bias is not None else x
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def _conv(conv, x):
+    fn = F.conv3d if isinstance(conv, nn.Conv3d) else F.conv2d
+    return fn(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+class ConvBias(object):
+    """mixin for the bare-conv form (relu=None in the reference's generator): forward(x, residual=None, relu=False)"""
+
+    def forward(self, x, residual=None, relu=False):
+        return bias_act(_conv(self, x), self.bias, residual, relu)
+
+
+class ConvBias2d(ConvBias, nn.Conv2d):
+    pass
+
+
+class ConvBias3d(ConvBias, nn.Conv3d):
+    pass
+
+
+class ConvBiasReLU(nn.Sequential):
+    """Sequential(conv, ReLU) of the reference's generator with the fused epilogue; keys '0.weight' / '0.bias'"""
+
+    def forward(self, x, residual=None):
+        return bias_act(_conv(self[0], x), self[0].bias, residual, True)

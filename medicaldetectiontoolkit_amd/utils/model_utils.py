@@ -258,6 +258,12 @@ class NDConvGenerator(object):
 
     def __call__(self, c_in, c_out, ks, pad=0, stride=1, norm=None, relu="relu"):
         import torch.nn as nn
+        from . import fused_epilogue as fe
+        if norm is None and relu in (None, "relu"):
+            # no normalisation layer between conv and activation: bias add (+ residual) + ReLU run as one fused
+            # epilogue pass (csrc/epilogue.hip); same Sequential layout / state-dict keys as the reference
+            conv = (fe.ConvBias2d if self.dim == 2 else fe.ConvBias3d)(c_in, c_out, kernel_size=ks, padding=pad, stride=stride)
+            return conv if relu is None else fe.ConvBiasReLU(conv, nn.ReLU(inplace=True))
         Conv = nn.Conv2d if self.dim == 2 else nn.Conv3d
         conv = Conv(c_in, c_out, kernel_size=ks, padding=pad, stride=stride)
         if norm is not None:
