@@ -116,6 +116,26 @@ int mdt_crop_and_resize_2d_backward_twophase(
     int crop_height, int crop_width, int depth,
     float *grads_image, void *workspace, size_t workspace_bytes, void *stream);
 
+/* All pyramid levels in ONE launch: replaces the per-level loop of mrcnn.py:373-457 (pyramid_roi_align: level rule :403,
+ * one CropAndResizeFunction call per level :431-437, torch.cat + sort back :440-455).
+ *   images[l]        device pointer of level l's map [batch, depth, H[l], W[l](, D[l])], fp32 (bf16 = 0) or bf16 (bf16 = 1)
+ *   boxes [N, 2*dim] normalised (y1, x1, y2, x2[, z1, z2]); batch_ix [N] (outside [0, batch): the row is skipped);
+ *   level [N]        index into images of the level the RoI is pooled on (outside [0, n_levels): the row is skipped)
+ *   crops [N, depth, ch, cw(, cd)]: row n is RoI n pooled on its level, i.e. already in the input order; skipped rows = 0.
+ * H, W, D, images, grads_images are HOST arrays of n_levels entries (D ignored for dim == 2).  n_levels <= 5.
+ * forward: bit-exact vs crop_and_resize_kernel.cu:7-118 per RoI.  backward: grads_images[l] (fp32, fully written) gets
+ * the scatter of the RoIs with level == l; same numerics contract as mdt_crop_and_resize_*_backward.  Returns
+ * MDT_ERR_UNSUPPORTED when a level does not fit the single-launch kernel (contiguous extent not a multiple of 8, map
+ * not 16-byte aligned, num_boxes > 128, pool beyond the LDS budget): call mdt_crop_and_resize_*_backward per level then. */
+int mdt_pyramid_roi_align_forward(int dim, int n_levels, const void *const *images, int bf16, const int *H, const int *W,
+                                  const int *D, const float *boxes, const int *batch_ix, const int *level, int num_boxes,
+                                  int batch, int depth, int crop_height, int crop_width, int crop_zdepth, float *crops,
+                                  void *stream);
+int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix,
+                                   const int *level, int num_boxes, int batch, int depth, const int *H, const int *W,
+                                   const int *D, int crop_height, int crop_width, int crop_zdepth,
+                                   float *const *grads_images, void *stream);
+
 /* Tuning hook of the default backward (tools/bwd_stage_probe.py, tools/bwd_trace_probe.py): when set to a device buffer of
  * >= 64 + 4 * grid int64 entries the kernel records per-stage / per-workgroup wall-clock stamps there; NULL (default)
  * turns it off.  Not part of the reference's interface. */

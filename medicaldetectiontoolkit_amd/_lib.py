@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmdt_hip.so")
 
 MDT_OK = 0
+MDT_ERR_UNSUPPORTED = -4
 NMS_RULE_GT = 0  # GPU rule, IoU >  thresh (nms_kernel.cu:71)
 NMS_RULE_GE = 1  # CPU rule, IoU >= thresh (nms.c:64)
 
@@ -27,6 +28,8 @@ _SIGNATURES = {
     "mdt_crop_and_resize_backward_twophase_workspace_bytes": (c_size_t, [c_int] * 9),
     "mdt_crop_and_resize_3d_backward_twophase": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_crop_and_resize_2d_backward_twophase": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_pyramid_roi_align_forward": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "mdt_pyramid_roi_align_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mdt_debug_bwd_timestamps": (None, [c_void_p]),
     "mdt_crop_and_resize_3d_backward_ordered": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
     "mdt_crop_and_resize_3d_backward_atomic": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),

@@ -47,7 +47,7 @@ __device__ __forceinline__ float ld(const float *p, long long i) { return p[i]; 
 __device__ __forceinline__ float ld(const bf16raw *p, long long i) { return __uint_as_float(((unsigned int)p[i].v) << 16); }
 
 template <int DIM, typename TIN>
-__global__ __launch_bounds__(FWD_THREADS) void crop_fwd_kernel(
+__device__ __forceinline__ void crop_fwd_body(
     const TIN *__restrict__ image, const float *__restrict__ boxes,
     const int *__restrict__ box_ind, int B, int H, int W, int D,
     int ch, int cw, int cd, int C, float *__restrict__ crops)
@@ -132,6 +132,36 @@ __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_kernel(
             out[e] = topv + (bottomv - topv) * ey.lerp;
         }
     }
+}
+
+template <int DIM, typename TIN>
+__global__ __launch_bounds__(FWD_THREADS) void crop_fwd_kernel(
+    const TIN *__restrict__ image, const float *__restrict__ boxes,
+    const int *__restrict__ box_ind, int B, int H, int W, int D,
+    int ch, int cw, int cd, int C, float *__restrict__ crops)
+{
+    crop_fwd_body<DIM, TIN>(image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, crops);
+}
+
+// All pyramid levels in one launch (mrcnn.py:373-457 pools every RoI on exactly one level and restores the order:
+// here the RoI's workgroups read their level's map directly and write the RoI's row, so the order never changes).
+constexpr int PYR_MAX_LEVELS = 5;
+struct PyramidMaps {
+    const void *image[PYR_MAX_LEVELS];
+    int H[PYR_MAX_LEVELS], W[PYR_MAX_LEVELS], D[PYR_MAX_LEVELS];
+    int n_levels;
+};
+
+template <int DIM, typename TIN>
+__global__ __launch_bounds__(FWD_THREADS) void crop_fwd_pyramid_kernel(
+    PyramidMaps maps, const float *__restrict__ boxes, const int *__restrict__ box_ind, const int *__restrict__ level,
+    int B, int ch, int cw, int cd, int C, float *__restrict__ crops)
+{
+    int l = level[blockIdx.x];
+    int b_limit = B;
+    if (l < 0 || l >= maps.n_levels) { l = 0; b_limit = 0; }      // no level: the row is zero-filled like a skipped RoI
+    crop_fwd_body<DIM, TIN>(reinterpret_cast<const TIN *>(maps.image[l]), boxes, box_ind, b_limit,
+                            maps.H[l], maps.W[l], maps.D[l], ch, cw, cd, C, crops);
 }
 
 // ---------------------------------------------------------------------------
@@ -1069,6 +1099,32 @@ int launch_fwd(const TIN *image, const float *boxes, const int *box_ind, int N, 
     return check_launch();
 }
 
+template <int DIM, typename TIN>
+int launch_fwd_pyramid(int n_levels, const void *const *images, const int *H, const int *W, const int *D,
+                       const float *boxes, const int *box_ind, const int *level, int N, int B,
+                       int ch, int cw, int cd, int C, float *crops, hipStream_t s)
+{
+    if (n_levels < 1 || n_levels > PYR_MAX_LEVELS || N < 0 || B <= 0 || ch <= 0 || cw <= 0 || cd <= 0 || C <= 0)
+        return MDT_ERR_INVALID_ARGUMENT;
+    PyramidMaps maps;
+    maps.n_levels = n_levels;
+    for (int l = 0; l < n_levels; ++l) {
+        const int Dl = (DIM == 3) ? D[l] : 1;
+        if (H[l] <= 0 || W[l] <= 0 || Dl <= 0 || images[l] == nullptr) return MDT_ERR_INVALID_ARGUMENT;
+        maps.image[l] = images[l]; maps.H[l] = H[l]; maps.W[l] = W[l]; maps.D[l] = Dl;
+    }
+    const long long per_roi = (long long)C * ch * cw * cd;
+    if (N == 0) return MDT_OK;
+    if (per_roi > 0x7fffffffLL) return MDT_ERR_UNSUPPORTED;
+    const size_t tab_bytes = (size_t)(ch + cw + cd) * sizeof(AxisEntry);
+    const long long slabs = (per_roi + FWD_SLAB - 1) / FWD_SLAB;
+    if (tab_bytes > 24 * 1024 || slabs > 65535) return MDT_ERR_UNSUPPORTED;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((crop_fwd_pyramid_kernel<DIM, TIN>), dim3((unsigned)N, (unsigned)slabs), dim3(FWD_THREADS), tab_bytes, s,
+                       maps, boxes, box_ind, level, B, ch, cw, cd, C, crops);
+    return check_launch();
+}
+
 template <int DIM>
 int launch_bwd(const float *grads, const float *boxes, const int *box_ind, int N, int B,
                int H, int W, int D, int ph, int pw, int pd, int C, float *out, hipStream_t s)
@@ -1383,6 +1439,33 @@ int mdt_crop_and_resize_3d_backward_atomic(const float *grads, const float *boxe
                            grads, boxes, box_ind, total, batch, H, W, D, ch, cw, cd, depth, grads_image);
     }
     return check_launch();
+}
+
+// ---- all pyramid levels in one launch -------------------------------------------------------------------------
+int mdt_pyramid_roi_align_forward(int dim, int n_levels, const void *const *images, int bf16, const int *H, const int *W,
+                                  const int *D, const float *boxes, const int *batch_ix, const int *level, int num_boxes,
+                                  int batch, int depth, int ch, int cw, int cd, float *crops, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dim != 2 && dim != 3) return MDT_ERR_INVALID_ARGUMENT;
+    if (dim == 2) cd = 1;
+    if (dim == 3) return bf16 ? launch_fwd_pyramid<3, bf16raw>(n_levels, images, H, W, D, boxes, batch_ix, level, num_boxes, batch, ch, cw, cd, depth, crops, s)
+                              : launch_fwd_pyramid<3, float>(n_levels, images, H, W, D, boxes, batch_ix, level, num_boxes, batch, ch, cw, cd, depth, crops, s);
+    return bf16 ? launch_fwd_pyramid<2, bf16raw>(n_levels, images, H, W, D, boxes, batch_ix, level, num_boxes, batch, ch, cw, cd, depth, crops, s)
+                : launch_fwd_pyramid<2, float>(n_levels, images, H, W, D, boxes, batch_ix, level, num_boxes, batch, ch, cw, cd, depth, crops, s);
+}
+
+int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix,
+                                   const int *level, int num_boxes, int batch, int depth, const int *H, const int *W,
+                                   const int *D, int ch, int cw, int cd, float *const *grads_images, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dim != 2 && dim != 3) return MDT_ERR_INVALID_ARGUMENT;
+    if (num_boxes < 0 || batch <= 0 || depth <= 0 || ch <= 0 || cw <= 0 || (dim == 3 && cd <= 0)) return MDT_ERR_INVALID_ARGUMENT;
+    if (dim == 2) cd = 1;
+    if (num_boxes > BWD_TERRITORY_MAX_BOXES) return MDT_ERR_UNSUPPORTED;
+    return launch_bwd_territory_multi(dim, n_levels, grads, boxes, batch_ix, level, num_boxes, batch, depth, H, W, D, ch, cw, cd,
+                                      grads_images, s);
 }
 
 }  // extern "C"

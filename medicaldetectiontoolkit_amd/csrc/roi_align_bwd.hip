@@ -64,6 +64,8 @@ struct TParams {
     const float *grads;
     const float *boxes;
     const int *box_ind;
+    const int *level;             // optional per-RoI pyramid level; only RoIs with level[r] == level_id belong to this map
+    int level_id;
     float *out;
     int N, B, C;
     int H, W, D;                   // D == 1 for 2D
@@ -84,6 +86,7 @@ struct TParams {
     int H4, W4, D4, pos_stride;    // per-RoI index->position table: y | x | z, each padded to 4 bytes
     int wy, wx, wz, mask_stride;   // per-RoI touched-index bit masks (u64 words): y | x | z
     int dbg_wg;
+    int scatter_base, zero_base;   // multi-level launch: first scatter / zero block index of this level in the grid
     long long *ts;                 // tuning only: wall-clock stamps (or null)
     int dbg;                       // tuning only: bit0 zero role exits at once; bit1 per-workgroup trace; bits 4.. scatter role stops after stage k
     // LDS byte offsets (region A at 0)
@@ -133,6 +136,7 @@ __device__ __forceinline__ int build_bitmap(const TParams &p, int b, u64 *bm, sh
             r = rb + tid;
             if (r < p.N) {     // box_ind and the box itself in one round trip (no dependent second load)
                 bi = p.box_ind[r];
+                if (p.level != nullptr && p.level[r] != p.level_id) bi = -1;
                 const float *src = p.boxes + (long long)r * (2 * DIM);
 #pragma unroll
                 for (int k = 0; k < 2 * DIM; ++k) bx[k] = src[k];
@@ -230,7 +234,7 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-#define TSTAMP(k) do { if (p.ts && blockIdx.x == (unsigned)p.dbg_wg && threadIdx.x == 0) { p.ts[k] = (long long)wall_clock64(); p.ts[16 + k] = (long long)clock64(); } } while (0)
+#define TSTAMP(k) do { if (p.ts && !zero_role && bid == (unsigned)p.dbg_wg && threadIdx.x == 0) { p.ts[k] = (long long)wall_clock64(); p.ts[16 + k] = (long long)clock64(); } } while (0)
 
 // One streaming pass along one line: n samples in[q * istride] (q ascending, or descending for an inverted box, so
 // that the compact positions ascend), sample q adding (1 - lerp) * v to position plo(q) and lerp * v to plo(q) + 1.
@@ -269,7 +273,7 @@ __device__ __forceinline__ void stream_line(const float *in, int istride, float 
 // SL > 0: segments of S = 4 * SL floats and 16-byte stores -> one lane per four consecutive voxels in stage (d), SL lanes
 // per segment; SL == 0: scalar stage (d), 32 lanes per segment (any S)
 template <int DIM, int VEC, int SL, int NT>
-__global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParams p)
+__device__ __forceinline__ void territory_body(const TParams &p, const bool zero_role, const unsigned bid)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *RA = reinterpret_cast<float *>(smem_raw);                              // [a_floats]  (bitmap build: cand scratch; zero role: all bitmaps)
@@ -288,7 +292,6 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
     short *cand = reinterpret_cast<short *>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_scatter = p.B * p.C * p.ssplit;
     struct WgTrace {     // tuning only (dbg bit 1): start / end wall clock and placement of every workgroup
         long long *slot;
         __device__ WgTrace(const TParams &p) : slot(nullptr) {
@@ -304,11 +307,11 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
         __device__ ~WgTrace() { if (slot) slot[1] = (long long)wall_clock64(); }
     } wg_trace(p);
 
-    if ((int)blockIdx.x >= n_scatter) {
+    if (zero_role) {
         // ------------------------------------------------------------- zero role
         // one contiguous run of rows of the whole [B*C*R] row space per workgroup; the grid holds as many zero
         // workgroups as stay resident next to the scatter workgroups, so each pays the bitmap prologue once
-        const long long zi = (long long)blockIdx.x - n_scatter;
+        const long long zi = (long long)bid;
         u64 *bm_all = reinterpret_cast<u64 *>(smem_raw + T_CAND * 8 * sizeof(short));   // regions A/B are unused here
         if (p.zero_per_vol > 0) {
             const int vol = (int)(zi / p.zero_per_vol);
@@ -340,8 +343,8 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
 
     // ----------------------------------------------------------------- scatter role
     __builtin_amdgcn_s_setprio(3);      // latency-critical: win instruction issue against the streaming zero-role waves
-    const int vol = blockIdx.x / p.ssplit;
-    const int split = blockIdx.x - vol * p.ssplit;
+    const int vol = bid / p.ssplit;
+    const int split = bid - vol * p.ssplit;
     const int b = vol / p.C;
     const int c = vol - b * p.C;
     const int dbg_stop = p.dbg >> 4;
@@ -417,6 +420,7 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
                 int bi = -1;
                 if (rr < p.N) {
                     bi = p.box_ind[rr];
+                    if (p.level != nullptr && p.level[rr] != p.level_id) bi = -1;
                     const float *src = p.boxes + (long long)rr * (2 * DIM);
 #pragma unroll
                     for (int k = 0; k < 2 * DIM; ++k) bx[k] = src[k];
@@ -778,6 +782,34 @@ __global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParam
     }
 }
 
+template <int DIM, int VEC, int SL, int NT>
+__global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_kernel(TParams p)
+{
+    const unsigned n_scatter = (unsigned)(p.B * p.C * p.ssplit);
+    const bool zero_role = blockIdx.x >= n_scatter;
+    territory_body<DIM, VEC, SL, NT>(p, zero_role, zero_role ? blockIdx.x - n_scatter : blockIdx.x);
+}
+
+// Multi-level form: one launch for all pyramid levels (mrcnn.py:373-457 routes every RoI to one level).  Block order:
+// level 0 scatter, level 0 zero, level 1 scatter, ... -- the finest level (the 151 MB fill) starts first.
+constexpr int T_MAX_LEVELS = 5;
+struct TMulti {
+    TParams lev[T_MAX_LEVELS];
+    int n_levels;
+    unsigned end[2 * T_MAX_LEVELS];         // exclusive block-index ends of: level 0 scatter, level 0 zero, level 1 scatter, ...
+};
+
+template <int DIM, int VEC, int SL, int NT>
+__global__ __launch_bounds__(NT, NT / 128) void crop_bwd_territory_multi_kernel(TMulti m)
+{
+    const unsigned b = blockIdx.x;
+    int r = 0;
+    unsigned base = 0u;
+    for (int k = 0; k < 2 * m.n_levels - 1; ++k)
+        if (b >= m.end[k]) { r = k + 1; base = m.end[k]; }
+    territory_body<DIM, VEC, SL, NT>(m.lev[r >> 1], (r & 1) != 0, b - base);
+}
+
 inline int ilog2_exact(int v)
 {
     if (v <= 0 || (v & (v - 1))) return -1;
@@ -912,55 +944,6 @@ inline int cu_count()
     return n;
 }
 
-template <int DIM, int VEC, int SL, int NT>
-void launch_variant(TParams &p, size_t lds, hipStream_t s)
-{
-    auto kernel = crop_bwd_territory_kernel<DIM, VEC, SL, NT>;
-    static bool optin = false;
-    if (!optin) {   // more than 64 KB of dynamic LDS needs the explicit opt-in
-        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_MAX);
-        (void)hipGetLastError();
-        optin = true;
-    }
-    const long long nvol = (long long)p.B * p.C;
-    const long long n_scatter = nvol * p.ssplit;
-    if (p.parts != 0) {
-        // zero workgroups: the slots left beside the scatter workgroups (each then pays its prologue once)
-        int z = env_int("MDT_BWD_ZERO_WGS", 0);
-        if (z <= 0) {
-            const int cus = cu_count();
-            const long long slots = (long long)resident_per_cu(kernel, NT, lds) * cus;
-            z = (int)(slots - n_scatter);
-            if (z < cus / 2) z = cus;
-        }
-        const long long total_rows = nvol * p.R;
-        if (z > total_rows) z = (int)total_rows;
-        if (p.zero_per_vol > 0) {
-            int k = (int)((z + nvol / 2) / nvol);
-            if (k < 1) k = 1;
-            if (k > p.R) k = p.R;
-            p.rows_per_part = (p.R + k - 1) / k;
-            p.zero_per_vol = (p.R + p.rows_per_part - 1) / p.rows_per_part;
-            p.parts = (int)(nvol * p.zero_per_vol);
-        } else {
-            p.rows_per_part = (int)((total_rows + z - 1) / z);
-            p.parts = (int)((total_rows + p.rows_per_part - 1) / p.rows_per_part);
-        }
-    }
-    const long long grid = n_scatter + p.parts;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds, s, p);
-}
-
-template <int DIM, int NT>
-void launch_nt(TParams &p, size_t lds, int vec, hipStream_t s)
-{
-    if (vec == 4 && p.S == 32) launch_variant<DIM, 4, 8, NT>(p, lds, s);
-    else if (vec == 4 && p.S == 16) launch_variant<DIM, 4, 4, NT>(p, lds, s);
-    else if (vec == 4 && p.S == 8) launch_variant<DIM, 4, 2, NT>(p, lds, s);
-    else if (vec == 4) launch_variant<DIM, 4, 0, NT>(p, lds, s);
-    else launch_variant<DIM, 1, 0, NT>(p, lds, s);
-}
-
 long long *g_bwd_ts = nullptr;
 
 }  // namespace
@@ -976,6 +959,84 @@ bool bwd_territory_supported(int dim, int N, int B, int H, int W, int D, int ph,
     return territory_plan(dim, N, B, H, W, D, ph, pw, pd, C, 1, p, lds) == MDT_OK;
 }
 
+// role geometry of one level (everything of TParams the plan did not fill); `zero_budget`: zero workgroups this level may use
+static void territory_geometry(TParams &p, long long vol_floats, int zero_budget)
+{
+    const long long nvol = (long long)p.B * p.C;
+    const long long vol_bytes = vol_floats * 4;
+    int ssplit = env_int("MDT_BWD_SSPLIT", 1);
+    if (ssplit < 1) ssplit = 1;
+    p.ssplit = ssplit;
+    p.dbg = env_int("MDT_BWD_DBG", 0);
+    p.dbg_wg = env_int("MDT_BWD_DBG_WG", 0);
+    p.ts = g_bwd_ts;
+    p.scatter_base = 0; p.zero_base = 0;
+    p.parts = 0;
+    p.rows_per_part = p.R;
+    if (vol_bytes > 32 * 1024) {
+        int z = env_int("MDT_BWD_ZERO_WGS", 0);
+        if (z <= 0) z = zero_budget;
+        const long long total_rows = nvol * p.R;
+        if (z > total_rows) z = (int)total_rows;
+        if (z < 1) z = 1;
+        if (p.zero_per_vol > 0) {
+            int k = (int)((z + nvol / 2) / nvol);
+            if (k < 1) k = 1;
+            if (k > p.R) k = p.R;
+            p.rows_per_part = (p.R + k - 1) / k;
+            p.zero_per_vol = (p.R + p.rows_per_part - 1) / p.rows_per_part;
+            p.parts = (int)(nvol * p.zero_per_vol);
+        } else {
+            p.rows_per_part = (int)((total_rows + z - 1) / z);
+            p.parts = (int)((total_rows + p.rows_per_part - 1) / p.rows_per_part);
+        }
+    } else {
+        p.zero_per_vol = 0;
+    }
+}
+
+template <typename K>
+static int zero_budget_for(K kernel, int nt, size_t lds, long long n_scatter)
+{
+    const int cus = cu_count();
+    const long long slots = (long long)resident_per_cu(kernel, nt, lds) * cus;
+    long long z = slots - n_scatter;
+    if (z < cus / 2) z = cus;
+    return (int)z;
+}
+
+template <typename K>
+static void optin_lds(K kernel)
+{
+    static bool done = false;
+    if (!done) {   // more than 64 KB of dynamic LDS needs the explicit opt-in
+        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_MAX);
+        (void)hipGetLastError();
+        done = true;
+    }
+}
+
+template <int DIM, int VEC, int SL, int NT>
+static void launch_single(TParams &p, size_t lds, long long vol_floats, hipStream_t s)
+{
+    auto kernel = crop_bwd_territory_kernel<DIM, VEC, SL, NT>;
+    optin_lds(kernel);
+    const long long n_scatter = (long long)p.B * p.C * env_int("MDT_BWD_SSPLIT", 1);
+    territory_geometry(p, vol_floats, vol_floats * 4 > 32 * 1024 ? zero_budget_for(kernel, NT, lds, n_scatter) : 0);
+    const long long grid = (long long)p.B * p.C * p.ssplit + p.parts;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds, s, p);
+}
+
+template <int DIM, int NT>
+static void launch_nt(TParams &p, size_t lds, int vec, long long vol_floats, hipStream_t s)
+{
+    if (vec == 4 && p.S == 32) launch_single<DIM, 4, 8, NT>(p, lds, vol_floats, s);
+    else if (vec == 4 && p.S == 16) launch_single<DIM, 4, 4, NT>(p, lds, vol_floats, s);
+    else if (vec == 4 && p.S == 8) launch_single<DIM, 4, 2, NT>(p, lds, vol_floats, s);
+    else if (vec == 4) launch_single<DIM, 4, 0, NT>(p, lds, vol_floats, s);
+    else launch_single<DIM, 1, 0, NT>(p, lds, vol_floats, s);
+}
+
 int launch_bwd_territory(int dim, const float *grads, const float *boxes, const int *box_ind, int N, int B,
                          int H, int W, int D, int ph, int pw, int pd, int C, float *out, hipStream_t s)
 {
@@ -986,33 +1047,66 @@ int launch_bwd_territory(int dim, const float *grads, const float *boxes, const 
     const int prc = territory_plan(dim, N, B, H, W, D, ph, pw, pd, C, vec, p, lds);
     if (prc != MDT_OK) return prc;
     p.grads = grads; p.boxes = boxes; p.box_ind = box_ind; p.out = out;
+    p.level = nullptr; p.level_id = 0;
     const long long vol_floats = (long long)H * W * D;
-
-    // role geometry
-    const long long nvol = (long long)B * C;
-    const long long vol_bytes = vol_floats * 4;
+    if ((long long)B * C * 8 > 0x3fffffffLL) return MDT_ERR_UNSUPPORTED;
     int nt = env_int("MDT_BWD_THREADS", 512);
     if (nt != 256 && nt != 512) nt = 512;
-    if (vol_bytes <= 32 * 1024) nt = 256;
-    p.parts = (vol_bytes > 32 * 1024) ? 1 : 0;      // > 0: zero role exists (count fixed in launch_variant)
-    p.rows_per_part = p.R;
-    int ssplit = env_int("MDT_BWD_SSPLIT", 1);
-    if (ssplit < 1) ssplit = 1;
-    p.ssplit = ssplit;
-    p.dbg = env_int("MDT_BWD_DBG", 0);
-    p.dbg_wg = env_int("MDT_BWD_DBG_WG", 0);
-    p.ts = g_bwd_ts;
-    if (nvol * ssplit > 0x3fffffffLL) return MDT_ERR_UNSUPPORTED;
+    if (vol_floats * 4 <= 32 * 1024) nt = 256;
     (void)hipGetLastError();
-    if (dim == 3) {
-        if (nt == 256) launch_nt<3, 256>(p, lds, vec, s);
-        else if (nt == 512) launch_nt<3, 512>(p, lds, vec, s);
-        else launch_nt<3, 512>(p, lds, vec, s);
-    } else {
-        if (nt == 256) launch_nt<2, 256>(p, lds, vec, s);
-        else if (nt == 512) launch_nt<2, 512>(p, lds, vec, s);
-        else launch_nt<2, 512>(p, lds, vec, s);
+    if (dim == 3) { if (nt == 256) launch_nt<3, 256>(p, lds, vec, vol_floats, s); else launch_nt<3, 512>(p, lds, vec, vol_floats, s); }
+    else { if (nt == 256) launch_nt<2, 256>(p, lds, vec, vol_floats, s); else launch_nt<2, 512>(p, lds, vec, vol_floats, s); }
+    return check_launch();
+}
+
+// All pyramid levels in ONE launch.  Needs every level on the 8-float-segment, 16-byte-store variant (contiguous extent a
+// multiple of 8, 16-byte aligned maps); otherwise MDT_ERR_UNSUPPORTED and the caller launches level by level.
+int launch_bwd_territory_multi(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
+                               int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
+                               float *const *outs, hipStream_t s)
+{
+    if (n_levels < 1 || n_levels > T_MAX_LEVELS) return MDT_ERR_INVALID_ARGUMENT;
+    TMulti m;
+    m.n_levels = n_levels;
+    size_t lds = 0;
+    long long vols[T_MAX_LEVELS];
+    for (int l = 0; l < n_levels; ++l) {
+        const int Dl = (dim == 3) ? D[l] : 1;
+        const int L_ = (dim == 3) ? Dl : W[l];
+        if (L_ % 8 != 0 || (((uintptr_t)outs[l]) & 15) != 0) return MDT_ERR_UNSUPPORTED;
+        size_t lds_l = 0;
+        const int prc = territory_plan(dim, N, B, H[l], W[l], Dl, ph, pw, pd, C, 4, m.lev[l], lds_l);
+        if (prc != MDT_OK) return prc;
+        if (m.lev[l].S != 8) return MDT_ERR_UNSUPPORTED;
+        if (lds_l > lds) lds = lds_l;
+        m.lev[l].grads = grads; m.lev[l].boxes = boxes; m.lev[l].box_ind = batch_ix; m.lev[l].out = outs[l];
+        m.lev[l].level = level; m.lev[l].level_id = l;
+        vols[l] = (long long)H[l] * W[l] * Dl;
     }
+    constexpr int NT = 512;
+    (void)hipGetLastError();
+    const long long nvol = (long long)B * C;
+    unsigned run = 0;
+    auto finish = [&](auto kernel) {
+        optin_lds(kernel);
+        // zero workgroups: what stays resident beside the first level's scatter workgroups goes to the levels that have
+        // a zero role, in proportion to their bytes (the finest level takes nearly all of it)
+        const int budget = zero_budget_for(kernel, NT, lds, nvol);
+        long long big_bytes = 0;
+        for (int l = 0; l < n_levels; ++l) if (vols[l] * 4 > 32 * 1024) big_bytes += vols[l];
+        for (int l = 0; l < n_levels; ++l) {
+            int zb = 0;
+            if (vols[l] * 4 > 32 * 1024) { zb = (int)((double)budget * (double)vols[l] / (double)big_bytes); if (zb < 16) zb = 16; }
+            territory_geometry(m.lev[l], vols[l], zb);
+            run += (unsigned)(nvol * m.lev[l].ssplit);
+            m.end[2 * l] = run;
+            run += (unsigned)m.lev[l].parts;
+            m.end[2 * l + 1] = run;
+        }
+        hipLaunchKernelGGL(kernel, dim3(run), dim3(NT), lds, s, m);
+    };
+    if (dim == 3) finish(crop_bwd_territory_multi_kernel<3, 4, 2, NT>);
+    else finish(crop_bwd_territory_multi_kernel<2, 4, 2, NT>);
     return check_launch();
 }
 

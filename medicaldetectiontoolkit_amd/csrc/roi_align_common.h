@@ -71,6 +71,10 @@ bool bwd_territory_supported(int dim, int N, int B, int H, int W, int D, int ph,
 int launch_bwd_territory(int dim, const float *grads, const float *boxes, const int *box_ind, int N, int B,
                          int H, int W, int D, int ph, int pw, int pd, int C, float *out, hipStream_t s);
 
+int launch_bwd_territory_multi(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
+                               int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
+                               float *const *outs, hipStream_t s);
+
 }  // namespace mdt_ra
 
 #endif

@@ -183,3 +183,107 @@ class CropAndResizeFunctionBase(object):
     # legacy spelling used by some callers of the reference
     def forward(self, image, boxes, box_ind):
         return self(image, boxes, box_ind)
+
+
+# ---------------------------------------------------------------------------------------------- all levels, one launch
+def _int_array(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[_lib.ptr(t) for t in tensors])
+
+
+def _level_dims(shapes, dim):
+    H = _int_array([s[2] for s in shapes])
+    W = _int_array([s[3] for s in shapes])
+    D = _int_array([s[4] if dim == 3 else 1 for s in shapes])
+    return H, W, D
+
+
+def pyramid_forward(maps, boxes, batch_ix, level, crop):
+    """maps: list of [B, C, *spatial_l] (all fp32 or all bf16, contiguous); one launch for all levels"""
+    dim = len(crop)
+    L = _lib.lib()
+    n, B, C = boxes.size(0), maps[0].size(0), maps[0].size(1)
+    crops = torch.empty((n, C) + tuple(crop), dtype=torch.float32, device=maps[0].device)
+    if n == 0 or C == 0:
+        return crops
+    H, W, D = _level_dims([m.shape for m in maps], dim)
+    with torch.cuda.device(maps[0].device):
+        rc = L.mdt_pyramid_roi_align_forward(dim, len(maps), _ptr_array(maps), int(maps[0].dtype == torch.bfloat16), H, W, D,
+                                             _lib.ptr(boxes), _lib.ptr(batch_ix), _lib.ptr(level), n, B, C,
+                                             crop[0], crop[1], crop[2] if dim == 3 else 1, _lib.ptr(crops),
+                                             _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_pyramid_roi_align_forward")
+    return crops
+
+
+def pyramid_backward(grads, boxes, batch_ix, level, shapes):
+    """grads [N, C, *crop] -> list of grad maps (one per level, fully written).  One launch when every level fits the
+    single-launch kernel, else one default backward per level (box_ind = -1 off-level)."""
+    dim = len(shapes[0]) - 2
+    L = _lib.lib()
+    grads = grads.contiguous()
+    if grads.dtype != torch.float32:
+        grads = grads.float()
+    dev = grads.device
+    outs = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    crop = tuple(grads.shape[2:])
+    n = grads.size(0)
+    H, W, D = _level_dims(shapes, dim)
+    prof = PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_valid = ((batch_ix >= 0) & (batch_ix < shapes[0][0]) & (level == 0)).sum()
+        ev0.record()
+    with torch.cuda.device(dev):
+        rc = L.mdt_pyramid_roi_align_backward(dim, len(shapes), _lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(batch_ix),
+                                              _lib.ptr(level), n, shapes[0][0], shapes[0][1], H, W, D,
+                                              crop[0], crop[1], crop[2] if dim == 3 else 1, _ptr_array(outs),
+                                              _lib.current_stream_ptr())
+    if prof is not None:
+        ev1.record()
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        for l, s in enumerate(shapes):
+            ind = torch.where(level == l, batch_ix, torch.full_like(batch_ix, -1))
+            outs[l] = crop_backward(grads, boxes, ind, tuple(s))
+        return outs
+    if prof is not None:
+        prof.append((ev0, ev1, {"im_size": tuple(shapes[0]), "crop": crop, "n_rows": n, "n_valid": n_valid, "mode": "pyramid",
+                                "levels": [tuple(s) for s in shapes]}))
+    _lib.check(rc, "mdt_pyramid_roi_align_backward")
+    return outs
+
+
+class _PyramidRoIAlign(Function):
+    @staticmethod
+    def forward(ctx, boxes, batch_ix, level, crop, *maps):
+        dim = len(crop)
+        for m in maps:
+            _lib.require_cuda(m, "feature map")
+        need_grad = torch.is_grad_enabled() and any(m.requires_grad for m in maps)
+        bf16 = all(m.dtype == torch.bfloat16 for m in maps) and not need_grad
+        maps_c = [m.contiguous() if (m.dtype == torch.float32 or bf16) else m.float().contiguous() for m in maps]
+        boxes = boxes.detach().to(device=maps_c[0].device, dtype=torch.float32).contiguous()
+        batch_ix = batch_ix.detach().to(device=maps_c[0].device, dtype=torch.int32).contiguous()
+        level = level.detach().to(device=maps_c[0].device, dtype=torch.int32).contiguous()
+        if boxes.dim() != 2 or boxes.size(1) != 2 * dim:
+            raise ValueError("boxes must be [N, %d], got %s" % (2 * dim, tuple(boxes.shape)))
+        crops = pyramid_forward(maps_c, boxes, batch_ix, level, crop)
+        ctx.shapes = [tuple(m.shape) for m in maps_c]
+        ctx.dtypes = [m.dtype for m in maps]
+        ctx.save_for_backward(boxes, batch_ix, level)
+        return crops
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        boxes, batch_ix, level = ctx.saved_tensors
+        outs = pyramid_backward(grad_outputs, boxes, batch_ix, level, ctx.shapes)
+        outs = [o if o.dtype == dt else o.to(dt) for o, dt in zip(outs, ctx.dtypes)]
+        return (None, None, None, None) + tuple(outs)
+
+
+def pyramid_crop_and_resize(maps, boxes, batch_ix, level, crop):
+    """RoIAlign of every RoI on ITS pyramid level (level[n] indexes `maps`), rows in input order; gradients to the maps."""
+    return _PyramidRoIAlign.apply(boxes, batch_ix, level, tuple(int(c) for c in crop), *maps)

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from .. import _lib
 from ..cuda_functions import _nms_impl
+from ..cuda_functions._roi_align_impl import pyramid_crop_and_resize
 from ..cuda_functions.roi_align_2D.roi_align.crop_and_resize import CropAndResizeFunction as ra2D
 from ..cuda_functions.roi_align_3D.roi_align.crop_and_resize import CropAndResizeFunction as ra3D
 from ..utils import model_utils as mutils
@@ -170,9 +171,9 @@ def proposal_layer(rpn_pred_probs, rpn_pred_deltas, proposal_count, anchors, cf)
 
 def pyramid_roi_align(feature_maps, rois, pool_size, pyramid_levels, dim):
     """mrcnn.py:373-457.  rois [n, 2*dim + 1] (normalised box, batch_ix; batch_ix < 0 marks a padding row).
-    Level rule :403 (h*w of the normalised box only).  Each level is pooled over ALL rois with
-    box_ind = batch_ix where the roi belongs to the level and -1 elsewhere: the kernel writes zero rows for
-    -1, so the per-level outputs simply add up -- no nonzero()/gather/sort-back and no host sync."""
+    Level rule :403 (h*w of the normalised box only).  All levels are pooled by ONE kernel launch (and one backward
+    launch): every RoI reads its own level's map and writes its own output row, so there is no per-level loop, no
+    nonzero()/gather/sort-back and no host sync."""
     boxes = rois[:, :dim * 2].detach()
     batch_ixs = rois[:, dim * 2]
     h = boxes[:, 2] - boxes[:, 0]
@@ -180,17 +181,8 @@ def pyramid_roi_align(feature_maps, rois, pool_size, pyramid_levels, dim):
     roi_level = (4 + mutils.log2(torch.sqrt(h * w))).round().int().clamp(pyramid_levels[0], pyramid_levels[-1])
     if len(pyramid_levels) == 5:
         roi_level = torch.where(h * w > 0.65, torch.full_like(roi_level, 5), roi_level)
-    ind_all = batch_ixs.to(torch.int32)
-    boxes = boxes.contiguous()
-    pooled = None
-    for level_ix, level in enumerate(pyramid_levels):
-        ind = torch.where(roi_level == level, ind_all, torch.full_like(ind_all, -1))
-        if len(pool_size) == 2:
-            p = ra2D(pool_size[0], pool_size[1], 0)(feature_maps[level_ix], boxes, ind)
-        else:
-            p = ra3D(pool_size[0], pool_size[1], pool_size[2], 0)(feature_maps[level_ix], boxes, ind)
-        pooled = p if pooled is None else pooled + p
-    return pooled
+    return pyramid_crop_and_resize(list(feature_maps), boxes, batch_ixs.to(torch.int32), roi_level - int(pyramid_levels[0]),
+                                   pool_size)
 
 
 def _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev):

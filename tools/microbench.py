@@ -118,6 +118,33 @@ def main():
                         vp(torch.cuda.current_stream().cuda_stream))
                 report("REF_cuda_kernel_roialign3d_fwd_" + tag, timeit(ref_fwd, args.iters), fwd_bytes)
 
+    # all pyramid levels in one launch vs one launch per level (train-like: 48 sampled RoIs routed by the level rule)
+    for crop in ((7, 7, 3), (14, 14, 5)):
+        shapes = [(B, C) + levels[k] for k in ("P2", "P3", "P4", "P5")]
+        per = []
+        for li, side in enumerate((8.0, 16.0, 32.0, 64.0)):
+            tb, ti = trainlike_rois_3d(rng, B, 6, side)
+            keep = rng.permutation(len(tb))[:{0: 24, 1: 12, 2: 8, 3: 4}[li]]
+            per.append((tb[keep], ti[keep], np.full(len(keep), li, dtype=np.int32)))
+        pb = torch.from_numpy(np.concatenate([x[0] for x in per])).to(dev)
+        pi = torch.from_numpy(np.concatenate([x[1] for x in per])).to(dev)
+        pl = torch.from_numpy(np.concatenate([x[2] for x in per])).to(dev)
+        maps = [torch.randn(sh, device=dev) for sh in shapes]
+        g = torch.randn((48, C) + crop, device=dev)
+        P = crop[0] * crop[1] * crop[2]
+        nbytes = 4 * 48 * C * P + sum(4 * int(np.prod(sh)) for sh in shapes) + 36 * 48
+        inds = [torch.where(pl == li, pi, torch.full_like(pi, -1)) for li in range(4)]
+        tag = "N48_" + "x".join(map(str, crop))
+        report("pyramid_roialign3d_bwd_one_launch_" + tag,
+               timeit(lambda: _roi_align_impl.pyramid_backward(g, pb, pi, pl, shapes), args.iters), nbytes)
+        report("pyramid_roialign3d_bwd_four_launches_" + tag,
+               timeit(lambda: [_roi_align_impl.crop_backward(g, pb, inds[li], shapes[li]) for li in range(4)], args.iters), nbytes)
+        report("pyramid_roialign3d_fwd_one_launch_" + tag,
+               timeit(lambda: _roi_align_impl.pyramid_forward(maps, pb, pi, pl, crop), args.iters), 4 * 48 * C * P)
+        report("pyramid_roialign3d_fwd_four_launches_" + tag,
+               timeit(lambda: [_roi_align_impl.crop_forward(maps[li], pb, inds[li], crop) for li in range(4)], args.iters),
+               4 * 48 * C * P * 4)
+
     # fill-only ceiling for the P2 gradient map (what a perfect bwd could reach)
     out = torch.empty((B, C, 32, 32, 128), device=dev)
     report("torch_zero_fill_151MB", timeit(lambda: out.zero_(), args.iters), out.numel() * 4)
