@@ -121,14 +121,17 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
 
     head = case(tb, ti, "trainlike_48_rois")
     variants = {"survey_8d_random_boxes_random_box_ind": case(rb, ri, "random_48_rois")}
-    # the same op as it ran inside the timed steps (random-init proposals are large: the level rule routes none to P2)
-    recs = [(a.elapsed_time(b) * 1e-3, m) for a, b, m in (in_step_prof or []) if m["im_size"] == shape and m["crop"] == crop]
+    # the op as it ran inside the timed steps: ONE launch for all four pyramid levels (mdt_pyramid_roi_align_backward), so
+    # the algorithmic bytes are the four gradient maps + the pooled gradients of the RoIs the level rule kept
+    recs = [(a.elapsed_time(b) * 1e-3, m) for a, b, m in (in_step_prof or []) if m.get("mode") == "pyramid" and m["crop"] == crop]
     if recs:
-        byts = [4.0 * batch * cf.end_filts * V + 4.0 * int(m["n_valid"].item()) * cf.end_filts * P + 28.0 * m["n_rows"] for _, m in recs]
+        maps_bytes = 4.0 * sum(int(np.prod(sh)) for sh in recs[0][1]["levels"])
+        byts = [maps_bytes + 4.0 * int(m["n_valid"].item()) * cf.end_filts * P + 36.0 * m["n_rows"] for _, m in recs]
         dur = float(np.mean([d for d, _ in recs]))
-        variants["in_training_step"] = {"achieved": round(float(np.mean(byts)) / dur / 1e9, 1), "frac": round(float(np.mean(byts)) / dur / HBM_PEAK_BPS, 4),
-                                        "avg_us": round(dur * 1e6, 2), "launches": len(recs),
-                                        "mean_rois_on_level": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
+        variants["in_training_step_all_levels_one_launch"] = {
+            "achieved": round(float(np.mean(byts)) / dur / 1e9, 1), "frac": round(float(np.mean(byts)) / dur / HBM_PEAK_BPS, 4),
+            "avg_us": round(dur * 1e6, 2), "launches": len(recs), "alg_bytes_per_launch": int(np.mean(byts)),
+            "mean_rois": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
     out = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": head["frac"], "traffic": head["traffic"],
            "traffic_source": "profiles/r02_pmc/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this op, tools/gpu_pmc.sh)" if head["traffic"] else None,
            "kernel": "crop_bwd_territory_kernel (mdt_crop_and_resize_3d_backward): P2 %s, pool %s, %d RoIs forced onto the level, "

@@ -235,7 +235,7 @@ def pyramid_backward(grads, boxes, batch_ix, level, shapes):
     prof = PROFILE
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_valid = ((batch_ix >= 0) & (batch_ix < shapes[0][0]) & (level == 0)).sum()
+        n_valid = ((batch_ix >= 0) & (batch_ix < shapes[0][0]) & (level >= 0) & (level < len(shapes))).sum()
         ev0.record()
     with torch.cuda.device(dev):
         rc = L.mdt_pyramid_roi_align_backward(dim, len(shapes), _lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(batch_ix),

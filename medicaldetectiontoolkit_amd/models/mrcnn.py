@@ -164,7 +164,7 @@ def proposal_layer(rpn_pred_probs, rpn_pred_deltas, proposal_count, anchors, cf)
     valid = keep >= 0                                            # rows beyond num_out are -1: zero-padded (:352-358)
     gathered = torch.gather(dets, 1, keep.clamp(min=0).unsqueeze(-1).expand(-1, -1, 2 * dim + 1))
     batch_out_proposals = gathered * valid.unsqueeze(-1).to(gathered.dtype)
-    norm = torch.as_tensor(np.asarray(cf.scale, dtype=np.float32), device=dev)
+    norm = mutils.const_tensor(cf.scale, torch.float32, dev)
     batch_normalized_boxes = batch_out_proposals[:, :, :2 * dim] / norm
     return batch_normalized_boxes, batch_out_proposals
 
@@ -185,31 +185,51 @@ def pyramid_roi_align(feature_maps, rois, pool_size, pyramid_levels, dim):
                                    pool_size)
 
 
-def _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev):
-    """lists over batch elements -> padded device tensors [B, Gmax, ...] + validity mask + global gt index."""
-    B = len(batch_gt_boxes)
-    counts = [0 if (g is None or len(g) == 0 or not np.any(np.asarray(c) > 0)) else len(g)
-              for g, c in zip(batch_gt_boxes, batch_gt_class_ids)]
-    gmax = max(1, max(counts))
-    boxes = np.zeros((B, gmax, 2 * dim), dtype=np.float32)
-    cls = np.zeros((B, gmax), dtype=np.int64)
-    valid = np.zeros((B, gmax), dtype=bool)
-    gidx = np.full((B, gmax), -1, dtype=np.int32)
-    run = 0
-    for b in range(B):
-        n_all = 0 if batch_gt_boxes[b] is None else len(batch_gt_boxes[b])
-        if counts[b] > 0:
-            boxes[b, :counts[b]] = np.asarray(batch_gt_boxes[b], dtype=np.float32)
-            cls[b, :counts[b]] = np.asarray(batch_gt_class_ids[b])
-            valid[b, :counts[b]] = True
-            gidx[b, :counts[b]] = run + np.arange(counts[b])
-        run += n_all
-    t = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
-    return t(boxes) / scale, t(cls), t(valid), t(gidx), counts
+class GtOnDevice(object):
+    """GT boxes / class ids of a batch on the device, sent with ONE pinned, asynchronous upload at the start of the step.
+    (Every separate upload from pageable numpy memory waits for the stream: the per-element uploads of the matching and
+    target code used to drain the launch queue a dozen times per step.)
+      px     [B, Gmax, 2*dim] f64 pixel boxes of ALL objects (anchor matching, RPN delta targets)
+      cls    [B, Gmax] i64 class ids of all objects
+      valid  [B, Gmax] bool, gidx [B, Gmax] i32 (index into the stacked GT masks): set for elements with at least one
+             foreground class id, like the target layer expects (mrcnn.py:487)
+      n_all  python list: objects per element;  counts: 0 for elements without a foreground class id else n_all"""
+
+    def __init__(self, batch_gt_boxes, batch_gt_class_ids, dim, dev):
+        B = len(batch_gt_boxes)
+        self.n_all = [0 if g is None else len(g) for g in batch_gt_boxes]
+        self.counts = [0 if (self.n_all[b] == 0 or not np.any(np.asarray(batch_gt_class_ids[b]) > 0)) else self.n_all[b]
+                       for b in range(B)]
+        gmax = max(1, max(self.n_all))
+        stage = torch.zeros((B, gmax, 2 * dim + 3), dtype=torch.float64, pin_memory=(torch.device(dev).type == "cuda"))
+        a = stage.numpy()
+        a[:, :, 2 * dim + 2] = -1.0
+        run = 0
+        for b in range(B):
+            n = self.n_all[b]
+            if n:
+                a[b, :n, :2 * dim] = np.asarray(batch_gt_boxes[b], dtype=np.float64)
+                a[b, :n, 2 * dim] = np.asarray(batch_gt_class_ids[b])
+            if self.counts[b]:
+                a[b, :n, 2 * dim + 1] = 1.0
+                a[b, :n, 2 * dim + 2] = run + np.arange(n)
+            run += n
+        d = stage.to(dev, non_blocking=True)
+        self.px = d[:, :, :2 * dim].contiguous()
+        self.cls = d[:, :, 2 * dim].long()
+        self.cls_i32 = d[:, :, 2 * dim].int()
+        self.valid = d[:, :, 2 * dim + 1] > 0
+        self.gidx = d[:, :, 2 * dim + 2].int()
+
+
+def _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev, gt_dev=None):
+    """padded device tensors [B, Gmax, ...] of the target layer: normalised fp32 boxes, class ids, validity, mask index"""
+    g = gt_dev if gt_dev is not None else GtOnDevice(batch_gt_boxes, batch_gt_class_ids, dim, dev)
+    return g.px.float() / scale, g.cls, g.valid, g.gidx, g.counts
 
 
 def detection_target_layer(batch_proposals, batch_mrcnn_class_scores, batch_gt_class_ids, batch_gt_boxes,
-                           batch_gt_masks, cf, B, generator=None):
+                           batch_gt_masks, cf, B, generator=None, gt_dev=None):
     """mrcnn.py:461-613 on fixed-size masked tensors.
     batch_proposals [B*pc, 2*dim+1]; batch_gt_masks: device float/uint8 tensor [sum_G, 1, Y, X, (Z)] with the GT
     masks of all batch elements stacked in order (the reference gathers per-RoI copies, :551).
@@ -218,8 +238,8 @@ def detection_target_layer(batch_proposals, batch_mrcnn_class_scores, batch_gt_c
     dev = batch_proposals.device
     dim = cf.dim
     pc = batch_proposals.shape[0] // B
-    scale = torch.as_tensor(np.asarray(cf.scale, dtype=np.float32), device=dev)
-    gt_boxes, gt_cls, gt_valid, gt_gidx, counts = _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev)
+    scale = mutils.const_tensor(cf.scale, torch.float32, dev)
+    gt_boxes, gt_cls, gt_valid, gt_gidx, counts = _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev, gt_dev)
     proposals = batch_proposals[:, :2 * dim].detach().view(B, pc, 2 * dim)
     has_gt = gt_valid.any(1)                                                          # [B]
 
@@ -256,10 +276,10 @@ def detection_target_layer(batch_proposals, batch_mrcnn_class_scores, batch_gt_c
     pos_assign = torch.gather(roi_gt_assign, 1, pidx)                                 # [B, P]
     pos_gt_boxes = torch.gather(gt_boxes, 1, pos_assign.unsqueeze(-1).expand(-1, -1, 2 * dim))
     pos_cls = torch.gather(gt_cls, 1, pos_assign)
-    dummy = torch.tensor([0., 0., 1., 1., 0., 1.] if dim == 3 else [0., 0., 1., 1.], device=dev)   # keeps log() finite
+    dummy = mutils.const_tensor([0., 0., 1., 1., 0., 1.] if dim == 3 else [0., 0., 1., 1.], torch.float32, dev)   # keeps log() finite
     safe_rois = torch.where(pvalid.unsqueeze(-1), pos_rois, dummy.expand_as(pos_rois))
     safe_gt = torch.where(pvalid.unsqueeze(-1), pos_gt_boxes, safe_rois)
-    std = torch.as_tensor(np.asarray(cf.bbox_std_dev, dtype=np.float32), device=dev)
+    std = mutils.const_tensor(cf.bbox_std_dev, torch.float32, dev)
     deltas = mutils.box_refinement(safe_rois.view(-1, 2 * dim), safe_gt.view(-1, 2 * dim)) / std   # [B*P, 2dim]
     # mask targets (:551-563): crop the assigned GT mask with the positive RoI, threshold at 0.5
     P = pidx.shape[1]
@@ -298,7 +318,7 @@ def refine_detections(rois, probs, deltas, batch_ixs, cf, B):
     pc = n // B
     fg = cf.head_classes - 1
     std = np.asarray(cf.rpn_bbox_std_dev, dtype=np.float32)       # quirk 8: rpn_bbox_std_dev, not bbox_std_dev (:650)
-    scale = torch.as_tensor(np.asarray(cf.scale, dtype=np.float32), device=dev)
+    scale = mutils.const_tensor(cf.scale, torch.float32, dev)
     win = [float(v) for v in cf.window]
     no_clip = [-3e38, -3e38, 3e38, 3e38] + ([-3e38, 3e38] if dim == 3 else [])
     groups_boxes, groups_scores = [], []
@@ -343,7 +363,7 @@ def refine_detections(rois, probs, deltas, batch_ixs, cf, B):
 #  Loss functions (masked, fixed-size)
 ############################################################
 def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, anchors_f64, gt_boxes_list, cf, generator=None,
-                       shem_poolsize=None):
+                       shem_poolsize=None, gt_dev=None):
     """compute_rpn_class_loss (mrcnn.py:176-214) + compute_rpn_bbox_loss (:217-240), batched over B; with K-class
     logits and class-id matches it is also retina_unet.compute_class_loss / compute_bbox_loss (retina_unet.py:126-189).
     rpn_match [B, A] int32 (-1 / 0 / >0) as returned by the matching kernel BEFORE sub-sampling; the
@@ -381,12 +401,15 @@ def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas,
     class_loss = ((pos_loss + neg_loss) / 2).mean()                           # mean over batch == sum(loss_b / B)
 
     # bbox: smooth-L1 between predicted deltas of the kept positives and their targets
-    gmax = max(1, max(len(g) for g in gt_boxes_list))
-    gt_pad = np.zeros((B, gmax, 2 * dim), dtype=np.float64)
-    for b, g in enumerate(gt_boxes_list):
-        if len(g) > 0:
-            gt_pad[b, :len(g)] = np.asarray(g, dtype=np.float64)
-    gt_pad = torch.from_numpy(gt_pad).to(dev, non_blocking=True)
+    if gt_dev is not None:
+        gt_pad = gt_dev.px
+    else:
+        gmax = max(1, max(len(g) for g in gt_boxes_list))
+        gt_pad = np.zeros((B, gmax, 2 * dim), dtype=np.float64)
+        for b, g in enumerate(gt_boxes_list):
+            if len(g) > 0:
+                gt_pad[b, :len(g)] = np.asarray(g, dtype=np.float64)
+        gt_pad = torch.from_numpy(gt_pad).to(dev, non_blocking=True)
     a_pos = anchors_f64[pidx.view(-1)]                                        # [B*n, 2dim] f64
     g_assign = torch.gather(rpn_argmax.long(), 1, pidx)
     g_pos = torch.gather(gt_pad, 1, g_assign.unsqueeze(-1).expand(-1, -1, 2 * dim)).view(-1, 2 * dim)
@@ -532,7 +555,7 @@ class net(nn.Module):
         self.batch_mrcnn_class_scores = F.softmax(batch_mrcnn_class_logits, dim=1)
         detections, det_valid = refine_detections(rpn_rois, self.batch_mrcnn_class_scores, batch_mrcnn_bbox, batch_ixs, cf, B)
         dim = cf.dim
-        scale = torch.as_tensor(np.asarray(list(cf.scale) + [1], dtype=np.float32), device=img.device)
+        scale = mutils.const_tensor(list(cf.scale) + [1], torch.float32, img.device)
         detection_boxes = detections[:, :dim * 2 + 1] / scale
         detection_boxes = torch.cat([detection_boxes[:, :dim * 2],
                                      torch.where(det_valid, detection_boxes[:, dim * 2], torch.full_like(detection_boxes[:, dim * 2], -1.0)).unsqueeze(1)], 1)
@@ -540,10 +563,11 @@ class net(nn.Module):
             detection_masks = self.mask(self.mrcnn_feature_maps, detection_boxes)
         return [rpn_pred_logits, rpn_pred_deltas, batch_proposal_boxes, detections, det_valid, detection_masks]
 
-    def loss_samples_forward(self, batch_gt_class_ids, batch_gt_boxes, batch_gt_masks, B):
+    def loss_samples_forward(self, batch_gt_class_ids, batch_gt_boxes, batch_gt_masks, B, gt_dev=None):
         """mrcnn.py:1052-1082."""
         sample_ix, valid, is_pos, tcls, tdeltas, tmasks = detection_target_layer(
-            self.rpn_rois_batch_info, self.batch_mrcnn_class_scores, batch_gt_class_ids, batch_gt_boxes, batch_gt_masks, self.cf, B)
+            self.rpn_rois_batch_info, self.batch_mrcnn_class_scores, batch_gt_class_ids, batch_gt_boxes, batch_gt_masks, self.cf, B,
+            gt_dev=gt_dev)
         sample_proposals = self.rpn_rois_batch_info[sample_ix]
         dim = self.cf.dim
         sample_proposals = torch.cat([sample_proposals[:, :2 * dim],
@@ -569,23 +593,26 @@ class net(nn.Module):
             masks_list = [torch.as_tensor(np.ascontiguousarray(m)) for m in batch["roi_masks"] if len(m) > 0]
             gt_masks = torch.cat(masks_list, 0).to(dev, non_blocking=True) if masks_list else None
 
+        # all GT boxes / class ids go up in one pinned async copy BEFORE the backbone is launched: nothing in the step
+        # waits for the stream afterwards, so the host keeps running ahead of the GPU through the glue
+        gt_dev = GtOnDevice(gt_boxes, gt_class_ids, cf.dim, dev)
+
         rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(img)
         (mrcnn_class_logits, mrcnn_pred_deltas, mrcnn_pred_mask, target_class_ids, mrcnn_target_deltas, target_mask,
-         sample_proposals, s_valid, s_pos) = self.loss_samples_forward(gt_class_ids, gt_boxes, gt_masks, B)
+         sample_proposals, s_valid, s_pos) = self.loss_samples_forward(gt_class_ids, gt_boxes, gt_masks, B, gt_dev=gt_dev)
 
         # anchor matching per element on the device (the reference: numpy on one host core, mrcnn.py:894)
         matches, argmaxes = [], []
         neg_thr = 0.1 if cf.dim == 2 else 0.01
         for b in range(B):
-            g = gt_boxes[b]
-            gt_t = torch.from_numpy(np.asarray(g, dtype=np.float64)).to(dev, non_blocking=True) if len(g) > 0 else None
+            gt_t = gt_dev.px[b, :gt_dev.n_all[b]] if gt_dev.n_all[b] > 0 else None
             m, am, _, _ = mutils.anchor_match_labels(self.anchors_f64, gt_t, None, neg_thr, float(cf.anchor_matching_iou))
             matches.append(m)
             argmaxes.append(am)
         rpn_match = torch.stack(matches)
         rpn_argmax = torch.stack(argmaxes)
         batch_rpn_class_loss, batch_rpn_bbox_loss, rpn_samples = compute_rpn_losses(
-            rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, self.anchors_f64, gt_boxes, cf)
+            rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, self.anchors_f64, gt_boxes, cf, gt_dev=gt_dev)
 
         mrcnn_class_loss = compute_mrcnn_class_loss(target_class_ids, mrcnn_class_logits, s_valid)
         mrcnn_bbox_loss = compute_mrcnn_bbox_loss(mrcnn_target_deltas, mrcnn_pred_deltas, target_class_ids, s_pos)

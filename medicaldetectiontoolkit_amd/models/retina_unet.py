@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from ..cuda_functions import _nms_impl
 from ..utils import model_utils as mutils
 from . import backbone as backbone_module
-from .mrcnn import compute_rpn_losses
+from .mrcnn import GtOnDevice, compute_rpn_losses
 
 GROUP_SHIFT = 4096.0
 
@@ -85,7 +85,7 @@ def refine_detections(anchors, probs, deltas, B, cf):
     row = torch.div(keep_ix, fg, rounding_mode="floor")
     cls = keep_ix % fg + 1
     bix = torch.div(row, A, rounding_mode="floor")
-    scale = torch.as_tensor(np.asarray(cf.scale, dtype=np.float32), device=dev)
+    scale = mutils.const_tensor(cf.scale, torch.float32, dev)
     no_clip = [-3e38, -3e38, 3e38, 3e38] + ([-3e38, 3e38] if dim == 3 else [])
     dec = mutils.decode_clip_boxes((anchors[row % A] / scale).contiguous(), deltas[row].contiguous(),
                                    np.asarray(cf.rpn_bbox_std_dev, dtype=np.float32), no_clip) * scale      # :226-228
@@ -193,21 +193,22 @@ class net(nn.Module):
             if not torch.is_tensor(batch["data"]) else batch["data"].to(dev).float()
         gt_class_ids, gt_boxes = batch["roi_labels"], batch["bb_target"]
         B = img.shape[0]
+        gt_dev = GtOnDevice(gt_boxes, gt_class_ids, cf.dim, dev)      # one pinned async upload, before the backbone launch
         detections, det_valid, class_logits, pred_deltas, seg_logits = self.forward(img)
         matches, argmaxes = [], []
         neg_thr = 0.1 if cf.dim == 2 else 0.01
         for b in range(B):
-            g = gt_boxes[b]
-            if len(g) > 0:
-                gt_t = torch.from_numpy(np.asarray(g, dtype=np.float64)).to(dev, non_blocking=True)
-                cls_t = torch.from_numpy(np.asarray(gt_class_ids[b]).astype(np.int32)).to(dev, non_blocking=True)
+            n_b = gt_dev.n_all[b]
+            if n_b > 0:
+                gt_t, cls_t = gt_dev.px[b, :n_b], gt_dev.cls_i32[b, :n_b]
             else:
                 gt_t, cls_t = None, None
             m, am, _, _ = mutils.anchor_match_labels(self.anchors_f64, gt_t, cls_t, neg_thr, float(cf.anchor_matching_iou))
             matches.append(m)
             argmaxes.append(am)
         batch_class_loss, batch_bbox_loss, samples = compute_rpn_losses(
-            torch.stack(matches), torch.stack(argmaxes), class_logits, pred_deltas, self.anchors_f64, gt_boxes, cf, shem_poolsize=20)
+            torch.stack(matches), torch.stack(argmaxes), class_logits, pred_deltas, self.anchors_f64, gt_boxes, cf, shem_poolsize=20,
+            gt_dev=gt_dev)
         loss = batch_class_loss + batch_bbox_loss
         seg_dice = seg_ce = None
         if seg_logits is not None:

@@ -68,6 +68,21 @@ def generate_pyramid_anchors(logger, cf, device=None, return_f32=False):
 
 
 # --------------------------------------------------------------------------- anchor <-> GT matching
+_CONST = {}
+
+
+def const_tensor(values, dtype, device):
+    """Small constants (scales, std devs, clip windows) live on the device, uploaded ONCE per (values, dtype, device).
+    A host->device copy from pageable memory waits for the stream, so re-creating them inside a step drains the launch
+    queue every time (torch.tensor(..., device=) / torch.as_tensor(numpy, device=) are such copies).  Read-only."""
+    flat = np.asarray(values, dtype=np.float64).reshape(-1)
+    key = (tuple(flat.tolist()), np.asarray(values).shape, dtype, str(device))
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.as_tensor(np.asarray(values, dtype=np.float64), dtype=dtype, device=device)
+    return t
+
+
 def anchor_match_labels(anchors, gt_boxes, gt_class_ids, neg_thresh, pos_thresh):
     """Steps 1-3 of gt_anchor_matching (utils/model_utils.py:505-563) on the device.
     anchors [A, 2*dim] f64, gt_boxes [G, 2*dim] f64, gt_class_ids [G] i32 or None.
@@ -109,7 +124,7 @@ def anchor_delta_targets(anchors, gt_boxes, std_dev):
         cols += [(g_cz - a_cz) / a_d, torch.log(g_h / a_h), torch.log(g_w / a_w), torch.log(g_d / a_d)]
     else:
         cols += [torch.log(g_h / a_h), torch.log(g_w / a_w)]
-    std = torch.as_tensor(np.asarray(std_dev, dtype=np.float64), device=a.device)
+    std = const_tensor(std_dev, torch.float64, a.device)
     return torch.stack(cols, 1) / std
 
 
@@ -186,8 +201,8 @@ def clip_boxes(boxes, window):
     """clip_boxes_{2D,3D} / clip_to_window (utils/model_utils.py:374-398, 623-637)."""
     dim = boxes.size(1) // 2
     w = [float(v) for v in window]
-    lo = torch.tensor([w[0], w[1], w[0], w[1]] + ([w[4], w[4]] if dim == 3 else []), device=boxes.device)
-    hi = torch.tensor([w[2], w[3], w[2], w[3]] + ([w[5], w[5]] if dim == 3 else []), device=boxes.device)
+    lo = const_tensor([w[0], w[1], w[0], w[1]] + ([w[4], w[4]] if dim == 3 else []), torch.float32, boxes.device)
+    hi = const_tensor([w[2], w[3], w[2], w[3]] + ([w[5], w[5]] if dim == 3 else []), torch.float32, boxes.device)
     return torch.min(torch.max(boxes, lo), hi)
 
 
@@ -246,7 +261,11 @@ def shem(roi_probs_neg, negative_count, ohem_poolsize, generator=None):
 
 def log2(x):
     """utils/model_utils.py:658-663: log(x) / log(2) in the tensor's dtype."""
-    return torch.log(x) / torch.log(torch.tensor(2.0, dtype=x.dtype, device=x.device))
+    key = ("log2", x.dtype, str(x.device))
+    d = _CONST.get(key)
+    if d is None:        # log(2) as the device computes it, once (see const_tensor)
+        d = _CONST[key] = torch.log(torch.tensor(2.0, dtype=x.dtype, device=x.device))
+    return torch.log(x) / d
 
 
 class NDConvGenerator(object):

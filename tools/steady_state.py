@@ -1,0 +1,90 @@
+"""Steady-state kernel breakdown of the timed training steps from a rocprofv3 --kernel-trace csv of bench.py.
+
+usage: python tools/steady_state.py <*_kernel_trace.csv> <steps> <ms_per_step> [out.csv]
+The window ends at the first single-level crop_bwd_territory_kernel launch (bench.py's roofline measurement starts there:
+the training step itself only uses the multi-level kernel) and spans steps * ms_per_step before it."""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def category(n):
+    if "crop_" in n or "nms_" in n or "bias_act" in n or "bias_grad" in n or "anchor" in n or "decode" in n or "wbc" in n:
+        return "mdt_hip (this repo)"
+    if n.startswith("_ZN2ck") or "ck::" in n or "miopen" in n.lower() or "Cijk" in n or "gemm" in n.lower() or "batched_transpose" in n \
+            or "naive_conv" in n or "SubTensor" in n or "Im2" in n or "Col2" in n or "igemm" in n:
+        return "MIOpen / CK / GEMM convolutions"
+    if "max_pool" in n or "upsample" in n:
+        return "torch pooling / upsampling"
+    if "fillBuffer" in n or "copyBuffer" in n:
+        return "fills / copies (runtime)"
+    if "at::native" in n or "at_cuda" in n or "cub" in n or "rocprim" in n:
+        return "torch elementwise / reduce / sort"
+    return "other"
+
+
+def short(n):
+    n = re.sub(r"^void ", "", n)
+    if n.startswith("_ZN2ck"):
+        kind = "bwd_weight" if "bwd_weight" in n else ("fwd" if "fwd" in n else "ck")
+        return "ck::" + kind + " (mangled) ..." + n[-24:]
+    return re.sub(r"<.*", "", n)[:90]
+
+
+def main():
+    path, steps, ms = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+    rows = list(csv.DictReader(open(path)))
+    ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
+    ends = [s for s, e, n in ks if "crop_bwd_territory_kernel" in n]
+    if not ends:
+        raise SystemExit("no crop_bwd_territory_kernel launch in the trace")
+    t1 = ends[0]
+    # the last training kernel before the roofline section
+    t1 = max(e for s, e, n in ks if e <= t1)
+    t0 = t1 - int(steps * ms * 1e6)
+    win = [(s, e, n) for s, e, n in ks if s >= t0 and e <= t1]
+    busy, cur_s, cur_e = 0, None, None
+    for s, e, _ in win:
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    busy += (cur_e - cur_s) if cur_e else 0
+    span = t1 - t0
+    # idle gaps between consecutive kernels (single in-order stream)
+    gaps = []
+    for (s0, e0, n0), (s1, e1, n1) in zip(win[:-1], win[1:]):
+        if s1 > e0:
+            gaps.append((s1 - e0, short(n0), short(n1), (e0 - t0) / 1e6))
+    bins = [(0, 5), (5, 20), (20, 100), (100, 1000), (1000, 1e9)]
+    gap_lines = ["# idle gaps: " + "; ".join("%g-%g us: n=%d, %.2f ms/step" % (
+        lo, hi, sum(1 for g in gaps if lo * 1e3 <= g[0] < hi * 1e3), sum(g[0] for g in gaps if lo * 1e3 <= g[0] < hi * 1e3) / 1e6 / steps)
+        for lo, hi in bins)]
+    for g in sorted(gaps, reverse=True)[:14]:
+        gap_lines.append("# gap %7.1f us at +%7.2f ms  after %-50s before %s" % (g[0] / 1e3, g[3], g[1][:50], g[2][:50]))
+    cat, per = defaultdict(float), defaultdict(lambda: [0, 0.0])
+    for s, e, n in win:
+        cat[category(n)] += e - s
+        k = short(n)
+        per[k][0] += 1
+        per[k][1] += e - s
+    tot = sum(cat.values())
+    lines = ["# window: last %d timed steps = %.1f ms; kernels %d; GPU busy %.1f ms (%.1f %%); summed kernel time %.1f ms"
+             % (steps, span / 1e6, len(win), busy / 1e6, 100.0 * busy / span, tot / 1e6)]
+    for c, v in sorted(cat.items(), key=lambda x: -x[1]):
+        lines.append("# %-40s %8.2f ms/step  %5.1f %% of kernel time" % (c, v / 1e6 / steps, 100.0 * v / tot))
+    lines += gap_lines
+    lines.append("Name,Calls,TotalDurationNs,AverageNs,Percentage")
+    for k, (c, v) in sorted(per.items(), key=lambda x: -x[1][1]):
+        lines.append('"%s",%d,%d,%d,%.3f' % (k, c, v, v / c, 100.0 * v / tot))
+    text = "\n".join(lines) + "\n"
+    if len(sys.argv) > 4:
+        open(sys.argv[4], "w").write(text)
+    print("\n".join(lines[:60]))
+
+
+if __name__ == "__main__":
+    main()
