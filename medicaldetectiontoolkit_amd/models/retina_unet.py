@@ -98,7 +98,7 @@ def refine_detections(anchors, probs, deltas, B, cf):
     dets = torch.cat([shifted, flat_probs.unsqueeze(1)], 1).contiguous()               # already sorted by score
     keep, num = _nms_impl.nms_sorted(dets, float(cf.detection_nms_threshold), dim)
     kept = torch.zeros(n_pre + 1, dtype=torch.bool, device=dev)
-    kept[torch.where(keep >= 0, keep, torch.full_like(keep, n_pre))] = True
+    kept.scatter_(0, torch.where(keep >= 0, keep, torch.full_like(keep, n_pre)), True)      # (indexed assignment would sync)
     kept = kept[:n_pre]
     # top model_max_instances_per_batch_element per batch element (:261-263)
     M = cf.model_max_instances_per_batch_element
