@@ -33,19 +33,25 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_BPS = 8.0e12   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(cf, seconds_budget=25.0):
-    """Bounded CPU sample of one step's worth of work for ONE patch: torch-CPU fp32 forward+backward of the
-    FPN+RPN conv path (the part the reference runs through torch on the CPU) plus the CPU oracle for the native
-    ops that patch causes (RPN NMS over 6000 boxes, RoIAlign fwd 75 x (7,7,3), fwd/bwd of 6 sampled RoIs with
-    (7,7,3) and (14,14,5) on P2).  Reported as patches/s."""
+def cpu_baseline(cf, anchors, seconds_budget=25.0):
+    """Bounded CPU sample of one training step's work for ONE patch, timed on this box's host cores:
+      * torch-CPU fp32 forward+backward of the FPN + RPN convolutions (what the reference runs through torch on the CPU),
+      * the CPU oracle for the native ops the patch causes: RPN NMS over pre_nms_limit boxes, RoIAlign-3D forward of the
+        75 detection RoIs with both pools, forward+backward of the 6 sampled RoIs with (7,7,3) and (14,14,5) on P2,
+      * the numpy anchor matching of the reference (gt_anchor_matching over all 449 280 anchors, 3 GT boxes;
+        oracle/host_numpy.py) -- done on one host core per batch element in the reference (mrcnn.py:894),
+      * torch-CPU classifier + mask heads: forward on the 75 detection RoIs, forward+backward on the 6 sampled RoIs.
+    Reported as patches/s (a baseline, not a target: the roofline fraction is the quality figure)."""
     from medicaldetectiontoolkit_amd.models import backbone as bb
-    from medicaldetectiontoolkit_amd.models.mrcnn import RPN
+    from medicaldetectiontoolkit_amd.models.mrcnn import RPN, Classifier, Mask
     from medicaldetectiontoolkit_amd.utils.model_utils import NDConvGenerator
-    from oracle import oracle
+    from oracle import host_numpy, oracle
+    from tests.helpers import nms_boxes, random_boxes_3d
     threads = torch.get_num_threads()
     t_start = time.time()
     conv = NDConvGenerator(cf.dim)
     fpn, rpn = bb.FPN(cf, conv), RPN(cf, conv)
+    cls_head, mask_head = Classifier(cf, conv), Mask(cf, conv)
     x = torch.randn([1, 1] + list(cf.patch_size))
     t0 = time.time()
     outs = fpn(x)
@@ -53,22 +59,49 @@ def cpu_baseline(cf, seconds_budget=25.0):
     loss.backward()
     t_conv = time.time() - t0
     rng = np.random.default_rng(0)
-    from tests.helpers import nms_boxes, random_boxes_3d
     t0 = time.time()
     dets = nms_boxes(rng, cf.pre_nms_limit, dim=3, patch=float(cf.patch_size[0]))
     oracle.gpu_nms(dets, cf.rpn_nms_threshold, True)
     p2 = outs[0].detach().numpy()
     boxes = random_boxes_3d(rng, 75)
     ind = np.zeros(75, np.int32)
-    oracle.crop_and_resize_forward(p2, boxes, ind, tuple(cf.pool_size))
+    det_cls = oracle.crop_and_resize_forward(p2, boxes, ind, tuple(cf.pool_size))
+    det_mask = oracle.crop_and_resize_forward(p2, boxes, ind, tuple(cf.mask_pool_size))
+    sampled = {}
     for crop in (tuple(cf.pool_size), tuple(cf.mask_pool_size)):
         c = oracle.crop_and_resize_forward(p2, boxes[:6], ind[:6], crop)
         oracle.crop_and_resize_backward(c, boxes[:6], ind[:6], p2.shape)
+        sampled[crop] = c
     t_ops = time.time() - t0
-    total = t_conv + t_ops
+    # anchor matching (numpy, float64) over the full anchor table of this patch size
+    # (`anchors`: the float64 table the model built on the device, copied back once outside the timed parts)
+    ps = np.asarray(cf.patch_size, dtype=np.float64)
+    ctr = rng.uniform(0.3, 0.7, size=(3, 3)) * ps
+    half = rng.uniform(4, 12, size=(3, 3))
+    gt = np.stack([ctr[:, 0] - half[:, 0], ctr[:, 1] - half[:, 1], ctr[:, 0] + half[:, 0], ctr[:, 1] + half[:, 1],
+                   ctr[:, 2] - half[:, 2], ctr[:, 2] + half[:, 2]], 1)
+    t0 = time.time()
+    host_numpy.anchor_matching(anchors, gt, None, cf.anchor_matching_iou, cf.rpn_train_anchors_per_image, cf.rpn_bbox_std_dev, rng=rng)
+    t_match = time.time() - t0
+    # heads on the pooled features
+    t0 = time.time()
+    with torch.no_grad():
+        h = cls_head.conv2(cls_head.conv1(torch.from_numpy(det_cls)))
+        cls_head.linear_class(h.view(75, -1)), cls_head.linear_bbox(h.view(75, -1))
+        m = mask_head.conv4(mask_head.conv3(mask_head.conv2(mask_head.conv1(torch.from_numpy(det_mask)))))
+        mask_head.conv5(mask_head.relu(mask_head.deconv(m)))
+    xc = torch.from_numpy(sampled[tuple(cf.pool_size)]).requires_grad_(True)
+    xm = torch.from_numpy(sampled[tuple(cf.mask_pool_size)]).requires_grad_(True)
+    h = cls_head.conv2(cls_head.conv1(xc)).view(6, -1)
+    m = mask_head.conv4(mask_head.conv3(mask_head.conv2(mask_head.conv1(xm))))
+    m = mask_head.sigmoid(mask_head.conv5(mask_head.relu(mask_head.deconv(m))))
+    (cls_head.linear_class(h).mean() + cls_head.linear_bbox(h).mean() + m.mean()).backward()
+    t_heads = time.time() - t0
+    total = t_conv + t_ops + t_match + t_heads
     return {"value": round(1.0 / total, 4), "unit": "patches/s", "cores": int(threads), "kind": "port",
-            "sample": "1 patch %s: torch-CPU FPN+RPN fwd+bwd %.2fs + CPU oracle (NMS n=%d, RoIAlign-3D fwd 75 RoIs, fwd+bwd 6 RoIs "
-                      "(7,7,3)+(14,14,5) on P2) %.2fs; wall %.1fs" % ("x".join(map(str, cf.patch_size)), t_conv, cf.pre_nms_limit, t_ops, time.time() - t_start)}
+            "sample": "1 patch %s: torch-CPU FPN+RPN fwd+bwd %.2fs + CPU oracle (NMS n=%d, RoIAlign-3D fwd 75 RoIs x2 pools, fwd+bwd 6 RoIs "
+                      "(7,7,3)+(14,14,5) on P2) %.2fs + numpy anchor matching (%d anchors, 3 GT) %.2fs + torch-CPU heads %.2fs; wall %.1fs"
+                      % ("x".join(map(str, cf.patch_size)), t_conv, cf.pre_nms_limit, t_ops, anchors.shape[0], t_match, t_heads, time.time() - t_start)}
 
 
 def _time_op(fn, launches, warmup=10):
@@ -216,6 +249,21 @@ def main():
     elapsed = time.time() - t0
     prof, _roi_align_impl.PROFILE = _roi_align_impl.PROFILE, None
 
+    # the same steps fed from host numpy batches (the reference uploads inside train_forward, mrcnn.py:869): reported
+    # beside `value`, never as `value`
+    h2d = None
+    if world == 1 and not args.host_batches:
+        host_pool = [make_batch(patch, args.batch, seed=i) for i in range(2)]
+        n_h2d = max(2, min(args.steps, 5))
+        training.train_step(net, opt, host_pool[0], grad_sync=sync, monitor=False)
+        barrier()
+        th = time.time()
+        for i in range(n_h2d):
+            training.train_step(net, opt, host_pool[i % 2], grad_sync=sync, monitor=False)
+        barrier()
+        h2d = {"value": round(args.batch * n_h2d / (time.time() - th), 3), "unit": "patches/s", "steps": n_h2d,
+               "note": "same step with the batch handed over as host numpy arrays (image, GT masks, seg uploaded inside train_forward)"}
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -226,7 +274,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.model == "mrcnn":
             try:
-                cpu = cpu_baseline(cf)
+                cpu = cpu_baseline(cf, net.anchors_f64.cpu().numpy())
             except Exception as e:  # the baseline must never take the bench line down
                 cpu = {"value": None, "unit": "patches/s", "cores": int(torch.get_num_threads()), "kind": "port", "sample": "failed: %r" % (e,)}
         patches = args.batch * world * args.steps
@@ -239,7 +287,7 @@ def main():
                            "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),
                        "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over %s)" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "global_batch": args.batch * world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "h2d_inclusive": h2d,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

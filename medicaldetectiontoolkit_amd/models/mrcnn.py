@@ -536,7 +536,9 @@ class net(nn.Module):
             img = img.contiguous(memory_format=self.memory_format)
         fpn_outs = self.fpn(img)
         rpn_feature_maps = [fpn_outs[i] for i in cf.pyramid_levels]
-        self.mrcnn_feature_maps = rpn_feature_maps
+        # the RoIAlign kernels read [B, C, spatial] row-major maps: convert a channels-last map ONCE per forward (every head
+        # call would otherwise re-copy all levels, and the heads' gradients would meet in mixed layouts)
+        self.mrcnn_feature_maps = [m.contiguous() for m in rpn_feature_maps]
         layer_outputs = [self.rpn(p) for p in rpn_feature_maps]
         rpn_pred_logits, rpn_pred_probs, rpn_pred_deltas = [torch.cat(list(o), dim=1) for o in zip(*layer_outputs)]
         proposal_count = cf.post_nms_rois_training if is_training else cf.post_nms_rois_inference

@@ -152,3 +152,47 @@ def test_gpu_rule_vs_cpu_rule_differ_only_at_equality():
 
 def test_oracle_nms_empty():
     assert oracle.gpu_nms(np.zeros((0, 7), np.float32), 0.5).shape == (0,)
+
+
+# ---------------------------------------------------------------- host-side anchor matching (oracle/host_numpy.py)
+_MATCH_CFGS = {
+    "a3_mrcnn_small": dict(dim=3, model="mrcnn", patch_size=[64, 64, 32]),
+    "a3_retina_small": dict(dim=3, model="retina_unet", patch_size=[64, 64, 32]),
+    "a2_mrcnn_small": dict(dim=2, model="mrcnn", patch_size=[64, 64]),
+    "a2_retina_toy": dict(dim=2, model="retina_net", patch_size=[64, 64]),
+}
+
+
+@pytest.mark.parametrize("name,ng", [("a3_mrcnn_small", 1), ("a3_mrcnn_small", 3), ("a3_retina_small", 8),
+                                     ("a2_mrcnn_small", 3), ("a2_retina_toy", 2)])
+def test_oracle_anchor_matching_equals_reference_golden(name, ng):
+    """the numpy restatement against the outputs of the reference's gt_anchor_matching / compute_overlaps
+    (utils/model_utils.py:505-619, :83-111) stored by tests/golden/make_golden.py: float64 IoU bit for bit, labels equal,
+    delta targets to 1e-12"""
+    import os
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from oracle import host_numpy
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_python.npz"))
+    cf = Configs(**_MATCH_CFGS[name])
+    key = "match_%s_G%d" % (name, ng)
+    anchors, gt, cls = G[name], G[key + "_gt"], G[key + "_cls"]
+    iou = host_numpy.overlaps(anchors, gt)
+    assert np.array_equal(iou.max(1), G[key + "_iou_max"])
+    assert np.array_equal(iou.argmax(1), G[key + "_iou_argmax"])
+    assert np.array_equal(iou.argmax(0), G[key + "_gt_best"])
+    m, d = host_numpy.anchor_matching(anchors, gt, cls if cls.size else None, cf.anchor_matching_iou, 10 ** 6, cf.rpn_bbox_std_dev)
+    assert np.array_equal(m, G[key + "_matches"])
+    n_pos = G[key + "_deltas"].shape[0]
+    assert n_pos == int((m > 0).sum())
+    assert np.allclose(d[:n_pos], G[key + "_deltas"], rtol=1e-12, atol=1e-12)
+
+
+def test_oracle_anchor_matching_no_gt_and_subsampling():
+    from oracle import host_numpy
+    rng = np.random.default_rng(0)
+    anchors = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [2, 2, 12, 12], [40, 40, 50, 50]], dtype=np.float64)
+    m, d = host_numpy.anchor_matching(anchors, None, None, 0.7, 4, [0.1, 0.1, 0.2, 0.2])
+    assert (m == -1).all() and d.shape == (4, 4) and (d == 0).all()
+    gt = np.array([[1, 1, 11, 11]], dtype=np.float64)
+    m, d = host_numpy.anchor_matching(anchors, gt, None, 0.5, 2, [0.1, 0.1, 0.2, 0.2], rng=rng)
+    assert (m > 0).sum() == 1 and m[3] == -1            # 3 anchors above 0.5, all but rpn_train_anchors // 2 reset to neutral
