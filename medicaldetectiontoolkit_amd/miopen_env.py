@@ -29,6 +29,11 @@ def setup(cache_dir=None):
         os.makedirs(os.path.join(d, "kernels"), exist_ok=True)
     except OSError:
         return None
+    if os.environ.get("MDT_MIOPEN_SKIP_NAIVE"):
+        # leave the naive direct solvers out of the find: they are never the fastest for these shapes but take seconds
+        # per trial on 128^3 maps (Retina U-Net at batch 8: find > 20 min with them, ~1 min without)
+        for k in ("FWD", "BWD", "WRW"):
+            os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + k, "0")
     os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(d, "db"))
     os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(d, "kernels"))
     return d

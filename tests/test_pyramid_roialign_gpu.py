@@ -96,3 +96,36 @@ def test_pyramid_bf16_maps(cuda):
         got = impl.pyramid_crop_and_resize(maps_bf, t(boxes), t(bix), t(level), pool)
         want = impl.pyramid_crop_and_resize([m.float() for m in maps_bf], t(boxes), t(bix), t(level), pool)
     assert torch.equal(got, want)
+
+
+def test_pyramid_full_size_adjoint_and_single_level_equivalence(cuda):
+    """BASELINE config 3 shapes (128^3 patch, batch 8, 36 channels: maps 32x32x128 .. 4x4x16, 48 sampled RoIs, pool
+    (14,14,5)) through size-independent properties: <forward(x), g> == <x, backward(g)> (the backward is the exact
+    adjoint of the forward), and every level's gradient map equals what the single-level entry point writes."""
+    from tests.helpers import trainlike_rois_3d
+    rng = np.random.default_rng(11)
+    B, C, pool = 8, 36, (14, 14, 5)
+    shapes = [(B, C, 32, 32, 128), (B, C, 16, 16, 64), (B, C, 8, 8, 32), (B, C, 4, 4, 16)]
+    per = []
+    for li, (side, n) in enumerate(((8.0, 24), (16.0, 12), (32.0, 8), (64.0, 4))):
+        tb, ti = trainlike_rois_3d(rng, B, 6, side)
+        keep = rng.permutation(len(tb))[:n]
+        per.append((tb[keep], ti[keep], np.full(n, li, dtype=np.int32)))
+    order = rng.permutation(48)
+    boxes = torch.from_numpy(np.concatenate([p[0] for p in per])[order]).to(cuda)
+    bix = torch.from_numpy(np.concatenate([p[1] for p in per])[order]).to(cuda)
+    level = torch.from_numpy(np.concatenate([p[2] for p in per])[order]).to(cuda)
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    maps = [torch.randn(s, device=cuda, generator=gen) for s in shapes]
+    g = torch.randn((48, C) + pool, device=cuda, generator=gen)
+    out = impl.pyramid_forward(maps, boxes, bix, level, pool)
+    grads = impl.pyramid_backward(g, boxes, bix, level, shapes)
+    lhs = (out.double() * g.double()).sum().item()
+    rhs = sum((m.double() * gm.double()).sum().item() for m, gm in zip(maps, grads))
+    scale = sum((m.double().abs() * gm.double().abs()).sum().item() for m, gm in zip(maps, grads))
+    assert abs(lhs - rhs) <= 2e-6 * scale
+    for l, s in enumerate(shapes):
+        ind = torch.where(level == l, bix, torch.full_like(bix, -1))
+        single = impl.crop_backward(g, boxes, ind, s)
+        mag = impl.crop_backward(g.abs(), boxes, ind, s)
+        assert torch.all((grads[l] - single).abs() <= 4e-6 * mag + 1e-30)
