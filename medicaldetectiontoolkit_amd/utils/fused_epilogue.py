@@ -94,7 +94,50 @@ def bias_act(x, bias, residual=None, relu=False):
     return F.relu(y) if relu else y
 
 
+BWD_DATA_AS_FWD = True   # module switch (A/B: bench.py --conv-bwd-as-fwd 0)
+
+
+class _ConvStride1(Function):
+    """Unit-stride convolution whose input gradient is computed as a FORWARD convolution of the output gradient with the
+    flipped, transposed filter (the textbook identity; same arithmetic up to fp32 summation order).  MIOpen's forward
+    solvers for this backbone's 18..144-channel 3D layers are 1.3-2.4x faster than its backward-data solvers on gfx950
+    (tools/conv_bwd_probe.py: 36->128 3x3x3 on 8x32x32x128: 5.1 ms -> 3.8 ms; 18->18: 1.25 -> 0.86 ms; 144->144 on
+    4x4x16: 214 -> 88 us).  Used for the size-preserving layers (2*pad + 1 == kernel); the weight gradient stays on MIOpen's
+    backward-weights path."""
+
+    @staticmethod
+    def forward(ctx, x, w, padding):
+        ctx.save_for_backward(x, w)
+        ctx.padding = padding
+        return (F.conv3d if w.dim() == 5 else F.conv2d)(x, w, None, 1, padding)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        nd = w.dim() - 2
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            mf = torch.contiguous_format if gy.is_contiguous() else (torch.channels_last_3d if nd == 3 else torch.channels_last)
+            wt = w.transpose(0, 1)
+            if w.shape[2:].numel() > 1:
+                wt = wt.flip(*range(2, 2 + nd))
+            pad_t = tuple(int(k) - 1 - int(p) for k, p in zip(w.shape[2:], ctx.padding))
+            gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wt.contiguous(memory_format=mf), None, 1, pad_t)
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1] * nd, list(ctx.padding), [1] * nd, False, [0] * nd, 1,
+                                                     [False, True, False])[1]
+        return gx, gw, None
+
+
+def _unit(t):
+    return all(int(v) == 1 for v in t)
+
+
 def _conv(conv, x):
+    if BWD_DATA_AS_FWD and x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and _unit(conv.stride) and _unit(conv.dilation) \
+            and not isinstance(conv.padding, str) and all(2 * int(p) + 1 == int(k) for p, k in zip(conv.padding, conv.kernel_size)) \
+            and torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return _ConvStride1.apply(x, conv.weight, tuple(int(p) for p in conv.padding))
     fn = F.conv3d if isinstance(conv, nn.Conv3d) else F.conv2d
     return fn(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
