@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--model", type=str, default="mrcnn", choices=["mrcnn", "retina_unet"],
                     help="mrcnn = BASELINE config 3 (headline); retina_unet = config 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra host-batch steps after the timed loop (profiling runs)")
     ap.add_argument("--fused-adam", type=int, default=0)
     ap.add_argument("--fused-epilogue", type=int, default=1, help="1 (default): fused bias/residual/ReLU conv epilogues (csrc/epilogue.hip); 0: torch ops (A/B)")
     ap.add_argument("--conv-bwd-as-fwd", type=int, default=1, help="1 (default): input gradients of unit-stride convolutions as forward convolutions (utils/fused_epilogue._ConvStride1); 0: MIOpen backward-data (A/B)")
@@ -256,7 +257,7 @@ def main():
     # the same steps fed from host numpy batches (the reference uploads inside train_forward, mrcnn.py:869): reported
     # beside `value`, never as `value`
     h2d = None
-    if world == 1 and not args.host_batches:
+    if world == 1 and not args.host_batches and not args.no_h2d_leg:
         host_pool = [make_batch(patch, args.batch, seed=i) for i in range(2)]
         n_h2d = max(2, min(args.steps, 5))
         training.train_step(net, opt, host_pool[0], grad_sync=sync, monitor=False)

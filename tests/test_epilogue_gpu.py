@@ -60,3 +60,52 @@ def test_fused_modules_keep_reference_state_dict_layout(cuda):
     assert torch.allclose(a(x), want_a, atol=1e-5)
     r = torch.randn(2, 8, 6, 6, 6, device=cuda)
     assert torch.allclose(b(x, residual=r, relu=True), F.relu(F.conv3d(x, b.weight, b.bias) + r), atol=1e-5)
+
+
+@pytest.mark.parametrize("dim,cin,cout,ks,shape", [(3, 18, 18, 3, (2, 12, 10, 16)), (3, 36, 128, 3, (1, 8, 8, 16)), (3, 18, 72, 1, (2, 8, 8, 8)),
+                                                   (2, 24, 48, 3, (2, 20, 24)), (3, 5, 7, 3, (1, 5, 6, 7))])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_conv_input_gradient_as_forward_conv(dim, cin, cout, ks, shape, channels_last, cuda):
+    """utils/fused_epilogue._ConvStride1: output identical (same MIOpen forward call); input gradient = forward convolution
+    of the output gradient with the flipped/transposed filter, equal to MIOpen's backward-data to fp32 summation order;
+    weight gradient is the same MIOpen call"""
+    g = torch.Generator(device=cuda).manual_seed(cin * 131 + cout)
+    mf = (torch.channels_last_3d if dim == 3 else torch.channels_last) if channels_last else torch.contiguous_format
+    conv_fn = F.conv3d if dim == 3 else F.conv2d
+    x0 = torch.randn((shape[0], cin) + shape[1:], device=cuda, generator=g).contiguous(memory_format=mf)
+    w0 = (torch.randn((cout, cin) + (ks,) * dim, device=cuda, generator=g) * 0.1).contiguous(memory_format=mf)
+    gy = torch.randn((shape[0], cout) + shape[1:], device=cuda, generator=g).contiguous(memory_format=mf)
+    pad = (ks // 2,) * dim
+    x1, w1 = x0.clone(memory_format=torch.preserve_format).requires_grad_(True), w0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    x2, w2 = x0.clone(memory_format=torch.preserve_format).requires_grad_(True), w0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    y1 = fe._ConvStride1.apply(x1, w1, pad)
+    y2 = conv_fn(x2, w2, None, 1, pad)
+    assert torch.equal(y1, y2)
+    y1.backward(gy)
+    y2.backward(gy)
+    scale = conv_fn(gy.abs(), w0.abs().flip(*range(2, 2 + dim)).transpose(0, 1).contiguous(), None, 1, pad)       # sum |terms| per input element
+    assert torch.all((x1.grad - x2.grad).abs() <= 2e-6 * scale + 1e-30)
+    assert torch.allclose(w1.grad, w2.grad, rtol=1e-4, atol=1e-4 * w2.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,k", [(1, 7), (2, 3), (1, 5)])
+def test_stem_space_to_depth_equals_strided_conv(cin, k, cuda):
+    """utils/fused_epilogue._ConvStem221 (stride (2, 2, 1), pad k // 2): forward equal to the strided convolution to fp32
+    summation order; weight gradient is the strided problem's own MIOpen call"""
+    g = torch.Generator(device=cuda).manual_seed(7 * cin + k)
+    x0 = torch.randn((2, cin, 32, 24, 20), device=cuda, generator=g)
+    w0 = torch.randn((18, cin, k, k, k), device=cuda, generator=g) * 0.05
+    x1, w1 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    x2, w2 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    y1 = fe._ConvStem221.apply(x1, w1)
+    y2 = F.conv3d(x2, w2, None, (2, 2, 1), k // 2)
+    assert y1.shape == y2.shape
+    scale = F.conv3d(x0.abs(), w0.abs(), None, (2, 2, 1), k // 2)
+    assert torch.all((y1 - y2).abs() <= 2e-6 * scale + 1e-30)
+    gy = torch.randn(y2.shape, device=cuda, generator=g)
+    y1.backward(gy)
+    y2.backward(gy)
+    assert torch.allclose(w1.grad, w2.grad, rtol=1e-4, atol=1e-4 * w2.grad.abs().max().item())
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-4 * x2.grad.abs().max().item())
+    conv = torch.nn.Conv3d(cin, 18, k, stride=(2, 2, 1), padding=k // 2).to(cuda)
+    assert fe._is_stem221(conv, x0) and not fe._is_stem221(conv, x0[:, :, :31])
