@@ -183,6 +183,24 @@ int mdt_crop_and_resize_2d_backward_ordered(
 /* Fused convolution epilogues (FPN / ResNet conv path)                       */
 /* ------------------------------------------------------------------------- */
 
+/* Channels-last max pooling of the ResNet stem: MaxPool3d(kernel 3, stride (2, 2, 1), padding 1), models/backbone.py:77-79
+ * (torch.nn.functional.max_pool3d semantics: floor mode, first maximum in (y, x, z) scan order, NaN wins).
+ *   x      [batch, Y, X, Z, channels] fp32 -- i.e. the channels_last_3d storage of a [batch, channels, Y, X, Z] tensor
+ *   y      [batch, OY, OX, Z, channels], OY = (Y - 1) / 2 + 1, OX = (X - 1) / 2 + 1
+ *   argmax [same as y] uint8: window tap 0..26 (dy * 9 + dx * 3 + dz) of the maximum, consumed by the backward
+ * backward: gx [batch, Y, X, Z, channels] fully written; gather over the windows containing a voxel: no atomics, fixed
+ * summation order (torch's kernel uses atomics).  Not part of the reference's native interface: it replaces the torch op
+ * around the MIOpen convolutions, like the epilogues below. */
+int mdt_maxpool3d_k3s221_cl_forward(const float *x, float *y, unsigned char *argmax, int batch, int Y, int X, int Z, int channels,
+                                    void *stream);
+int mdt_maxpool3d_k3s221_cl_backward(const float *gy, const unsigned char *argmax, float *gx, int batch, int Y, int X, int Z,
+                                     int channels, void *stream);
+
+/* out[ci][co][taps - 1 - t] = w[co][ci][t] for a dense filter w [cout, cin, taps] (channels_last = 0) or its channels-last
+ * storage [cout, taps, cin] -> [cin, taps, cout] (channels_last = 1): the filter of the forward convolution that computes
+ * a unit-stride convolution's input gradient (utils/fused_epilogue.py). */
+int mdt_filter_flip_transpose(const float *w, float *out, int cout, int cin, int taps, int channels_last, void *stream);
+
 /*
  * y = act(x + bias[c] (+ residual)) in one pass; y may alias x.  The convolutions stay on MIOpen (torch); this
  * replaces what torch runs around every one of them in the reference's graph: the broadcast bias add, the residual add

@@ -36,6 +36,9 @@ _SIGNATURES = {
     "mdt_crop_and_resize_2d_forward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p, c_void_p]),
     "mdt_crop_and_resize_2d_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_crop_and_resize_2d_backward_ordered": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
+    "mdt_maxpool3d_k3s221_cl_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdt_maxpool3d_k3s221_cl_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdt_filter_flip_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mdt_bias_act_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p]),
     "mdt_bias_act_backward_workspace_bytes": (c_size_t, [c_longlong, c_int, c_longlong]),
     "mdt_bias_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_size_t, c_void_p]),

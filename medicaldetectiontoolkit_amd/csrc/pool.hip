@@ -1,0 +1,162 @@
+// pool.hip -- channels-last helpers around the MIOpen convolutions of the ResNet stem / backward pass (gfx950).
+//
+// (1) Max pooling of the stem (reference graph: models/backbone.py:77-79, MaxPool3d(kernel 3, stride (2, 2, 1), pad 1) in
+//     front of C2).  torch's max_pool3d has no channels-last kernel: on the channels_last_3d activations of this model it
+//     costs a full layout copy in, an NCDHW kernel (0.55 ms forward, 0.86 ms backward with atomics at 8 x 18 x 64 x 64 x 128)
+//     and a transpose back in front of the next convolution.  Here: one thread per (voxel, channel) on the channels-last
+//     storage (consecutive lanes = consecutive channels, then z: fully coalesced), the 27 window reads are served by
+//     L1/L2; the arg-max tap (0..26) is kept as one byte per output; the backward is a GATHER over the <= 12 windows
+//     containing a voxel -- no atomics, fixed summation order, deterministic.  Tie / NaN rule of torch
+//     (first maximum in (y, x, z) scan order, NaN wins) is reproduced.
+//     Algorithmic bytes: forward 4*V_in + 5*V_out, backward 5*V_out + 4*V_in  (V = B*C*voxels).  HBM-bound, no MFMA.
+// (2) mdt_filter_flip_transpose: w[co][ci][taps] -> w'[ci][co][reversed taps] in one launch (either memory order); feeds the
+//     "input gradient as a forward convolution" path (utils/fused_epilogue._ConvStride1).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "mdt_hip.h"
+
+namespace {
+
+constexpr int PL_THREADS = 256;
+
+inline int pl_check()
+{
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MDT_OK;
+    if (getenv("MDT_VERBOSE")) fprintf(stderr, "libmdt_hip: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
+    return MDT_ERR_LAUNCH_FAILED;
+}
+
+__global__ __launch_bounds__(PL_THREADS) void maxpool_k3s221_cl_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                            unsigned char *__restrict__ arg, long long n_out,
+                                                                            int Y, int X, int Z, int C, int OY, int OX)
+{
+    for (long long i = (long long)blockIdx.x * PL_THREADS + threadIdx.x; i < n_out; i += (long long)gridDim.x * PL_THREADS) {
+        long long t = i;
+        const int c = (int)(t % C); t /= C;
+        const int z = (int)(t % Z); t /= Z;
+        const int ox = (int)(t % OX); t /= OX;
+        const int oy = (int)(t % OY);
+        const long long b = t / OY;
+        const float *xb = x + b * (long long)Y * X * Z * C + c;
+        float best = -__builtin_inff();
+        int best_tap = -1;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = 2 * oy - 1 + dy;
+            if (yy < 0 || yy >= Y) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = 2 * ox - 1 + dx;
+                if (xx < 0 || xx >= X) continue;
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    const int zz = z - 1 + dz;
+                    if (zz < 0 || zz >= Z) continue;
+                    const float v = xb[(((long long)yy * X + xx) * Z + zz) * C];
+                    if (best_tap < 0 || v > best || v != v) { best = v; best_tap = dy * 9 + dx * 3 + dz; }
+                }
+            }
+        }
+        y[i] = best;
+        arg[i] = (unsigned char)best_tap;
+    }
+}
+
+__global__ __launch_bounds__(PL_THREADS) void maxpool_k3s221_cl_bwd_kernel(const float *__restrict__ gy, const unsigned char *__restrict__ arg,
+                                                                            float *__restrict__ gx, long long n_in,
+                                                                            int Y, int X, int Z, int C, int OY, int OX)
+{
+    for (long long i = (long long)blockIdx.x * PL_THREADS + threadIdx.x; i < n_in; i += (long long)gridDim.x * PL_THREADS) {
+        long long t = i;
+        const int c = (int)(t % C); t /= C;
+        const int z = (int)(t % Z); t /= Z;
+        const int xx = (int)(t % X); t /= X;
+        const int yy = (int)(t % Y);
+        const long long b = t / Y;
+        const long long ob = b * (long long)OY * OX * Z * C + c;
+        float acc = 0.0f;
+        for (int oy = yy / 2; oy <= (yy + 1) / 2; ++oy) {
+            if (oy >= OY) continue;
+            const int dy = yy - (2 * oy - 1);
+            for (int ox = xx / 2; ox <= (xx + 1) / 2; ++ox) {
+                if (ox >= OX) continue;
+                const int dx = xx - (2 * ox - 1);
+#pragma unroll
+                for (int oz = z - 1; oz <= z + 1; ++oz) {
+                    if (oz < 0 || oz >= Z) continue;
+                    const int tap = dy * 9 + dx * 3 + (z - oz + 1);
+                    const long long o = ob + (((long long)oy * OX + ox) * Z + oz) * C;
+                    if ((int)arg[o] == tap) acc = acc + gy[o];
+                }
+            }
+        }
+        gx[i] = acc;
+    }
+}
+
+template <bool CL>
+__global__ __launch_bounds__(PL_THREADS) void filter_flip_transpose_kernel(const float *__restrict__ w, float *__restrict__ out,
+                                                                            int cout, int cin, int taps)
+{
+    const int n = cout * cin * taps;
+    for (int i = blockIdx.x * PL_THREADS + threadIdx.x; i < n; i += gridDim.x * PL_THREADS) {
+        int co, ci, t;
+        if (CL) { co = i % cout; const int r = i / cout; t = r % taps; ci = r / taps; }        // out[ci][t][co]
+        else { t = i % taps; const int r = i / taps; co = r % cout; ci = r / cout; }           // out[ci][co][t]
+        const int ts = taps - 1 - t;
+        out[i] = CL ? w[((long long)co * taps + ts) * cin + ci] : w[((long long)co * cin + ci) * taps + ts];
+    }
+}
+
+inline unsigned grid_for(long long n)
+{
+    long long blocks = (n + PL_THREADS - 1) / PL_THREADS;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdt_maxpool3d_k3s221_cl_forward(const float *x, float *y, unsigned char *argmax, int batch, int Y, int X, int Z, int channels,
+                                    void *stream)
+{
+    if (batch < 0 || Y <= 0 || X <= 0 || Z <= 0 || channels <= 0) return MDT_ERR_INVALID_ARGUMENT;
+    const int OY = (Y - 1) / 2 + 1, OX = (X - 1) / 2 + 1;
+    const long long n_out = (long long)batch * OY * OX * Z * channels;
+    if (n_out == 0) return MDT_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(maxpool_k3s221_cl_fwd_kernel, dim3(grid_for(n_out)), dim3(PL_THREADS), 0, (hipStream_t)stream,
+                       x, y, argmax, n_out, Y, X, Z, channels, OY, OX);
+    return pl_check();
+}
+
+int mdt_maxpool3d_k3s221_cl_backward(const float *gy, const unsigned char *argmax, float *gx, int batch, int Y, int X, int Z,
+                                     int channels, void *stream)
+{
+    if (batch < 0 || Y <= 0 || X <= 0 || Z <= 0 || channels <= 0) return MDT_ERR_INVALID_ARGUMENT;
+    const int OY = (Y - 1) / 2 + 1, OX = (X - 1) / 2 + 1;
+    const long long n_in = (long long)batch * Y * X * Z * channels;
+    if (n_in == 0) return MDT_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(maxpool_k3s221_cl_bwd_kernel, dim3(grid_for(n_in)), dim3(PL_THREADS), 0, (hipStream_t)stream,
+                       gy, argmax, gx, n_in, Y, X, Z, channels, OY, OX);
+    return pl_check();
+}
+
+int mdt_filter_flip_transpose(const float *w, float *out, int cout, int cin, int taps, int channels_last, void *stream)
+{
+    if (cout <= 0 || cin <= 0 || taps <= 0 || (long long)cout * cin * taps > 0x7fffffffLL) return MDT_ERR_INVALID_ARGUMENT;
+    const long long n = (long long)cout * cin * taps;
+    (void)hipGetLastError();
+    if (channels_last) hipLaunchKernelGGL(filter_flip_transpose_kernel<true>, dim3(grid_for(n)), dim3(PL_THREADS), 0, (hipStream_t)stream, w, out, cout, cin, taps);
+    else hipLaunchKernelGGL(filter_flip_transpose_kernel<false>, dim3(grid_for(n)), dim3(PL_THREADS), 0, (hipStream_t)stream, w, out, cout, cin, taps);
+    return pl_check();
+}
+
+}  // extern "C"

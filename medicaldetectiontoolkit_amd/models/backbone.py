@@ -5,6 +5,7 @@ the convolutions run on MIOpen through torch (the north star leaves the conv pat
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..utils import fused_epilogue
 from ..utils.fused_epilogue import ConvBias
 
 
@@ -75,7 +76,7 @@ class FPN(nn.Module):
             return layers
 
         pool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1) if conv.dim == 2 else \
-            nn.MaxPool3d(kernel_size=3, stride=(2, 2, 1), padding=1)
+            fused_epilogue.MaxPool3dStem(kernel_size=3, stride=(2, 2, 1), padding=1)
         self.C2 = nn.Sequential(pool, *stage(sf, sf, self.n_blocks[0], 1, (sf, self.block_expansion, 1)))
         self.C3 = nn.Sequential(*stage(sfe, sf * 2, self.n_blocks[1], 2, (sfe, 2, 2)))
         self.C4 = nn.Sequential(*stage(sfe * 2, sf * 4, self.n_blocks[2], 2, (sfe * 2, 2, 2)))

@@ -98,6 +98,24 @@ BWD_DATA_AS_FWD = True   # module switch (A/B: bench.py --conv-bwd-as-fwd 0)
 STEM_SPACE_TO_DEPTH = True   # module switch (A/B: bench.py --stem-s2d 0)
 
 
+def flip_transpose_filter(w, mf):
+    """w [cout, cin, *k] -> [cin, cout, *k] with every spatial axis reversed, dense in memory format `mf`: one launch of
+    mdt_filter_flip_transpose when w is an fp32 GPU tensor dense in `mf`, torch ops otherwise"""
+    nd = w.dim() - 2
+    if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous(memory_format=mf) and _on_current_device(w):
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        out = torch.empty((cin, cout) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device, memory_format=mf)
+        rc = _lib.lib().mdt_filter_flip_transpose(w.data_ptr(), out.data_ptr(), cout, cin, int(w.shape[2:].numel()),
+                                                  0 if mf == torch.contiguous_format else 1, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "mdt_filter_flip_transpose")
+        return out
+    wt = w.transpose(0, 1)
+    if w.shape[2:].numel() > 1:
+        wt = wt.flip(*range(2, 2 + nd))
+    return wt.contiguous(memory_format=mf)
+
+
 class _ConvStride1(Function):
     """Unit-stride convolution whose input gradient is computed as a FORWARD convolution of the output gradient with the
     flipped, transposed filter (the textbook identity; same arithmetic up to fp32 summation order).  MIOpen's forward
@@ -119,11 +137,8 @@ class _ConvStride1(Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             mf = torch.contiguous_format if gy.is_contiguous() else (torch.channels_last_3d if nd == 3 else torch.channels_last)
-            wt = w.transpose(0, 1)
-            if w.shape[2:].numel() > 1:
-                wt = wt.flip(*range(2, 2 + nd))
             pad_t = tuple(int(k) - 1 - int(p) for k, p in zip(w.shape[2:], ctx.padding))
-            gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wt.contiguous(memory_format=mf), None, 1, pad_t)
+            gx = (F.conv3d if nd == 3 else F.conv2d)(gy, flip_transpose_filter(w, mf), None, 1, pad_t)
         if ctx.needs_input_grad[1]:
             gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1] * nd, list(ctx.padding), [1] * nd, False, [0] * nd, 1,
                                                      [False, True, False])[1]
@@ -203,3 +218,55 @@ class ConvBiasReLU(nn.Sequential):
 
     def forward(self, x, residual=None):
         return bias_act(_conv(self[0], x), self[0].bias, residual, True)
+
+
+class _MaxPoolK3S221(Function):
+    """MaxPool3d(3, stride (2, 2, 1), padding 1) on channels_last_3d storage (csrc/pool.hip); arg-max taps as uint8"""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, Y, X, Z = x.shape
+        OY, OX = (Y - 1) // 2 + 1, (X - 1) // 2 + 1
+        y = torch.empty((B, C, OY, OX, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+        arg = torch.empty((B, OY, OX, Z, C), dtype=torch.uint8, device=x.device)
+        rc = _lib.lib().mdt_maxpool3d_k3s221_cl_forward(x.data_ptr(), y.data_ptr(), arg.data_ptr(), B, Y, X, Z, C,
+                                                        torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "mdt_maxpool3d_k3s221_cl_forward")
+        ctx.save_for_backward(arg)
+        ctx.in_shape = (B, C, Y, X, Z)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        arg, = ctx.saved_tensors
+        B, C, Y, X, Z = ctx.in_shape
+        if not gy.is_contiguous(memory_format=torch.channels_last_3d):
+            gy = gy.contiguous(memory_format=torch.channels_last_3d)
+        gx = torch.empty((B, C, Y, X, Z), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last_3d)
+        rc = _lib.lib().mdt_maxpool3d_k3s221_cl_backward(gy.data_ptr(), arg.data_ptr(), gx.data_ptr(), B, Y, X, Z, C,
+                                                         torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "mdt_maxpool3d_k3s221_cl_backward")
+        return gx
+
+
+POOL_CHANNELS_LAST = True   # module switch (A/B: bench.py --pool-cl 0)
+
+
+class MaxPool3dStem(nn.MaxPool3d):
+    """nn.MaxPool3d that runs the channels-last kernel when it is the stem pooling (kernel 3, stride (2, 2, 1), padding 1,
+    models/backbone.py:77-79) on an fp32 channels_last_3d GPU activation with C > 1; torch's kernel otherwise (torch has no
+    channels-last 3D max pooling: it copies to NCDHW and the next convolution transposes back)."""
+
+    def forward(self, x):
+        if POOL_CHANNELS_LAST and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] > 1 \
+                and _t3(self.kernel_size) == (3, 3, 3) and _t3(self.stride) == (2, 2, 1) and _t3(self.padding) == (1, 1, 1) \
+                and _t3(self.dilation) == (1, 1, 1) and not self.ceil_mode and not self.return_indices \
+                and x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous() and _on_current_device(x):
+            return _MaxPoolK3S221.apply(x)
+        return super(MaxPool3dStem, self).forward(x)
+
+
+def _t3(v):
+    return tuple(int(a) for a in v) if isinstance(v, (tuple, list)) else (int(v),) * 3

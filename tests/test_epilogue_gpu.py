@@ -109,3 +109,51 @@ def test_stem_space_to_depth_equals_strided_conv(cin, k, cuda):
     assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-4 * x2.grad.abs().max().item())
     conv = torch.nn.Conv3d(cin, 18, k, stride=(2, 2, 1), padding=k // 2).to(cuda)
     assert fe._is_stem221(conv, x0) and not fe._is_stem221(conv, x0[:, :, :31])
+
+
+@pytest.mark.parametrize("shape", [(2, 18, 16, 12, 10), (1, 5, 7, 9, 4), (2, 36, 8, 8, 1), (1, 3, 2, 2, 3)])
+@pytest.mark.parametrize("ties", [False, True])
+def test_maxpool_channels_last_equals_torch(shape, ties, cuda):
+    """csrc/pool.hip vs torch.nn.functional.max_pool3d(3, (2, 2, 1), 1): forward values bit-identical (incl. ties after a
+    ReLU, -inf and NaN), input gradient equal (same arg-max rule; sums of <= 12 terms in a fixed order)"""
+    g = torch.Generator(device=cuda).manual_seed(sum(shape) + int(ties))
+    x0 = torch.randn(shape, device=cuda, generator=g)
+    if ties:
+        x0 = torch.relu(x0)                       # many exact ties at 0, like the activation in front of the stem pooling
+        x0[0, 0, 0, 0, 0] = float("nan")
+        x0[0, 1] = float("-inf")
+    x1 = x0.contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    x2 = x0.clone().requires_grad_(True)
+    pool = fe.MaxPool3dStem(kernel_size=3, stride=(2, 2, 1), padding=1)
+    y1 = pool(x1)
+    y2 = F.max_pool3d(x2, 3, (2, 2, 1), 1)
+    assert y1.shape == y2.shape and y1.is_contiguous(memory_format=torch.channels_last_3d)
+    assert torch.equal(torch.nan_to_num(y1, nan=123.0), torch.nan_to_num(y2, nan=123.0))
+    assert torch.equal(torch.isnan(y1), torch.isnan(y2))
+    gy = torch.randn(y2.shape, device=cuda, generator=g)
+    y1.backward(gy.contiguous(memory_format=torch.channels_last_3d))
+    y2.backward(gy)
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-6, atol=1e-6)
+    # run-to-run identical (torch's backward uses atomics, this one does not)
+    x3 = x0.contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    pool(x3).backward(gy.contiguous(memory_format=torch.channels_last_3d))
+    assert torch.equal(x3.grad, x1.grad)
+
+
+def test_maxpool_module_falls_back_to_torch_outside_its_case(cuda):
+    x = torch.randn(1, 4, 8, 8, 8, device=cuda)                      # contiguous NCDHW: torch path
+    assert torch.equal(fe.MaxPool3dStem(3, (2, 2, 1), 1)(x), F.max_pool3d(x, 3, (2, 2, 1), 1))
+    xc = x.contiguous(memory_format=torch.channels_last_3d)
+    assert torch.equal(fe.MaxPool3dStem(2, 2, 0)(xc), F.max_pool3d(xc, 2, 2, 0))
+
+
+@pytest.mark.parametrize("shape", [(18, 18, 3, 3, 3), (128, 36, 3, 3, 3), (72, 18, 1, 1, 1), (48, 24, 3, 3), (7, 5, 7, 7, 3)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_filter_flip_transpose_equals_torch(shape, channels_last, cuda):
+    g = torch.Generator(device=cuda).manual_seed(len(shape) + shape[0])
+    nd = len(shape) - 2
+    mf = (torch.channels_last_3d if nd == 3 else torch.channels_last) if channels_last else torch.contiguous_format
+    w = torch.randn(shape, device=cuda, generator=g).contiguous(memory_format=mf)
+    got = fe.flip_transpose_filter(w, mf)
+    want = w.transpose(0, 1).flip(*range(2, 2 + nd))
+    assert got.is_contiguous(memory_format=mf) and torch.equal(got, want)
