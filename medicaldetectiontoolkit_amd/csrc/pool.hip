@@ -29,71 +29,96 @@ inline int pl_check()
     return MDT_ERR_LAUNCH_FAILED;
 }
 
+// grid: x covers one output row segment (ox, z, c) with 32-bit index math, y walks the (b, oy) rows
 __global__ __launch_bounds__(PL_THREADS) void maxpool_k3s221_cl_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                                            unsigned char *__restrict__ arg, long long n_out,
+                                                                            unsigned char *__restrict__ arg, int rows,
                                                                             int Y, int X, int Z, int C, int OY, int OX)
 {
-    for (long long i = (long long)blockIdx.x * PL_THREADS + threadIdx.x; i < n_out; i += (long long)gridDim.x * PL_THREADS) {
-        long long t = i;
-        const int c = (int)(t % C); t /= C;
-        const int z = (int)(t % Z); t /= Z;
-        const int ox = (int)(t % OX); t /= OX;
-        const int oy = (int)(t % OY);
-        const long long b = t / OY;
-        const float *xb = x + b * (long long)Y * X * Z * C + c;
+    const unsigned row_len = (unsigned)OX * Z * C;
+    const unsigned j = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (j >= row_len) return;
+    const unsigned c = j % (unsigned)C;
+    const unsigned t = j / (unsigned)C;
+    const int z = (int)(t % (unsigned)Z);
+    const int ox = (int)(t / (unsigned)Z);
+    const unsigned zc = (unsigned)Z * C;
+    const int x0 = 2 * ox - 1;
+    const bool x_in = x0 >= 0 && x0 + 2 < X, z_in = z >= 1 && z + 1 < Z;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        const int oy = r % OY;
+        const long long b = r / OY;
+        const float *xb = x + b * (long long)Y * X * zc + c;
+        const int y0 = 2 * oy - 1;
         float best = -__builtin_inff();
         int best_tap = -1;
+        if (x_in && z_in && y0 >= 0 && y0 + 2 < Y) {          // interior: 27 unguarded loads
+            const float *p = xb + ((long long)y0 * X + x0) * zc + (unsigned)(z - 1) * C;
+            float v[27];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int yy = 2 * oy - 1 + dy;
-            if (yy < 0 || yy >= Y) continue;
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int xx = 2 * ox - 1 + dx;
-                if (xx < 0 || xx >= X) continue;
+                for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                for (int dz = 0; dz < 3; ++dz) {
-                    const int zz = z - 1 + dz;
-                    if (zz < 0 || zz >= Z) continue;
-                    const float v = xb[(((long long)yy * X + xx) * Z + zz) * C];
-                    if (best_tap < 0 || v > best || v != v) { best = v; best_tap = dy * 9 + dx * 3 + dz; }
+                    for (int dz = 0; dz < 3; ++dz) v[dy * 9 + dx * 3 + dz] = p[((long long)dy * X + dx) * zc + (unsigned)dz * C];
+#pragma unroll
+            for (int k = 0; k < 27; ++k)
+                if (best_tap < 0 || v[k] > best || v[k] != v[k]) { best = v[k]; best_tap = k; }
+        } else {
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y0 + dy;
+                if (yy < 0 || yy >= Y) continue;
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int xx = x0 + dx;
+                    if (xx < 0 || xx >= X) continue;
+                    for (int dz = 0; dz < 3; ++dz) {
+                        const int zz = z - 1 + dz;
+                        if (zz < 0 || zz >= Z) continue;
+                        const float v = xb[((long long)yy * X + xx) * zc + (unsigned)zz * C];
+                        if (best_tap < 0 || v > best || v != v) { best = v; best_tap = dy * 9 + dx * 3 + dz; }
+                    }
                 }
             }
         }
-        y[i] = best;
-        arg[i] = (unsigned char)best_tap;
+        const long long o = (long long)r * row_len + j;
+        y[o] = best;
+        arg[o] = (unsigned char)best_tap;
     }
 }
 
+// grid: x covers one input row segment (x, z, c), y walks the (b, y) rows
 __global__ __launch_bounds__(PL_THREADS) void maxpool_k3s221_cl_bwd_kernel(const float *__restrict__ gy, const unsigned char *__restrict__ arg,
-                                                                            float *__restrict__ gx, long long n_in,
+                                                                            float *__restrict__ gx, int rows,
                                                                             int Y, int X, int Z, int C, int OY, int OX)
 {
-    for (long long i = (long long)blockIdx.x * PL_THREADS + threadIdx.x; i < n_in; i += (long long)gridDim.x * PL_THREADS) {
-        long long t = i;
-        const int c = (int)(t % C); t /= C;
-        const int z = (int)(t % Z); t /= Z;
-        const int xx = (int)(t % X); t /= X;
-        const int yy = (int)(t % Y);
-        const long long b = t / Y;
-        const long long ob = b * (long long)OY * OX * Z * C + c;
+    const unsigned row_len = (unsigned)X * Z * C;
+    const unsigned j = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (j >= row_len) return;
+    const unsigned c = j % (unsigned)C;
+    const unsigned t = j / (unsigned)C;
+    const int z = (int)(t % (unsigned)Z);
+    const int xx = (int)(t / (unsigned)Z);
+    const unsigned zc = (unsigned)Z * C;
+    const int ox_lo = xx / 2, ox_hi = min((xx + 1) / 2, OX - 1);
+    const int oz_lo = max(z - 1, 0), oz_hi = min(z + 1, Z - 1);
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        const int yy = r % Y;
+        const long long b = r / Y;
+        const long long ob = b * (long long)OY * OX * zc + c;
         float acc = 0.0f;
-        for (int oy = yy / 2; oy <= (yy + 1) / 2; ++oy) {
-            if (oy >= OY) continue;
+        const int oy_hi = min((yy + 1) / 2, OY - 1);
+        for (int oy = yy / 2; oy <= oy_hi; ++oy) {
             const int dy = yy - (2 * oy - 1);
-            for (int ox = xx / 2; ox <= (xx + 1) / 2; ++ox) {
-                if (ox >= OX) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
                 const int dx = xx - (2 * ox - 1);
-#pragma unroll
-                for (int oz = z - 1; oz <= z + 1; ++oz) {
-                    if (oz < 0 || oz >= Z) continue;
+                const long long base = ob + ((long long)oy * OX + ox) * zc;
+                for (int oz = oz_lo; oz <= oz_hi; ++oz) {
                     const int tap = dy * 9 + dx * 3 + (z - oz + 1);
-                    const long long o = ob + (((long long)oy * OX + ox) * Z + oz) * C;
+                    const long long o = base + (unsigned)oz * C;
                     if ((int)arg[o] == tap) acc = acc + gy[o];
                 }
             }
         }
-        gx[i] = acc;
+        gx[(long long)r * row_len + j] = acc;
     }
 }
 
@@ -128,11 +153,12 @@ int mdt_maxpool3d_k3s221_cl_forward(const float *x, float *y, unsigned char *arg
 {
     if (batch < 0 || Y <= 0 || X <= 0 || Z <= 0 || channels <= 0) return MDT_ERR_INVALID_ARGUMENT;
     const int OY = (Y - 1) / 2 + 1, OX = (X - 1) / 2 + 1;
-    const long long n_out = (long long)batch * OY * OX * Z * channels;
-    if (n_out == 0) return MDT_OK;
+    const long long row_len = (long long)OX * Z * channels, rows = (long long)batch * OY;
+    if (rows == 0) return MDT_OK;
+    if (row_len > 0x3fffffffLL || rows > 0x7fffffffLL || (long long)X * Z * channels > 0x3fffffffLL) return MDT_ERR_UNSUPPORTED;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(maxpool_k3s221_cl_fwd_kernel, dim3(grid_for(n_out)), dim3(PL_THREADS), 0, (hipStream_t)stream,
-                       x, y, argmax, n_out, Y, X, Z, channels, OY, OX);
+    hipLaunchKernelGGL(maxpool_k3s221_cl_fwd_kernel, dim3((unsigned)((row_len + PL_THREADS - 1) / PL_THREADS), (unsigned)(rows < 65535 ? rows : 65535)),
+                       dim3(PL_THREADS), 0, (hipStream_t)stream, x, y, argmax, (int)rows, Y, X, Z, channels, OY, OX);
     return pl_check();
 }
 
@@ -141,11 +167,12 @@ int mdt_maxpool3d_k3s221_cl_backward(const float *gy, const unsigned char *argma
 {
     if (batch < 0 || Y <= 0 || X <= 0 || Z <= 0 || channels <= 0) return MDT_ERR_INVALID_ARGUMENT;
     const int OY = (Y - 1) / 2 + 1, OX = (X - 1) / 2 + 1;
-    const long long n_in = (long long)batch * Y * X * Z * channels;
-    if (n_in == 0) return MDT_OK;
+    const long long row_len = (long long)X * Z * channels, rows = (long long)batch * Y;
+    if (rows == 0) return MDT_OK;
+    if (row_len > 0x3fffffffLL || rows > 0x7fffffffLL) return MDT_ERR_UNSUPPORTED;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(maxpool_k3s221_cl_bwd_kernel, dim3(grid_for(n_in)), dim3(PL_THREADS), 0, (hipStream_t)stream,
-                       gy, argmax, gx, n_in, Y, X, Z, channels, OY, OX);
+    hipLaunchKernelGGL(maxpool_k3s221_cl_bwd_kernel, dim3((unsigned)((row_len + PL_THREADS - 1) / PL_THREADS), (unsigned)(rows < 65535 ? rows : 65535)),
+                       dim3(PL_THREADS), 0, (hipStream_t)stream, gy, argmax, gx, (int)rows, Y, X, Z, channels, OY, OX);
     return pl_check();
 }
 

@@ -10,7 +10,8 @@ from collections import defaultdict
 
 
 def category(n):
-    if "crop_" in n or "nms_" in n or "bias_act" in n or "bias_grad" in n or "anchor" in n or "decode" in n or "wbc" in n:
+    if "crop_" in n or "nms_" in n or "bias_act" in n or "bias_grad" in n or "anchor" in n or "decode" in n or "wbc" in n \
+            or "maxpool_k3" in n or "filter_flip" in n or "match_pass" in n:
         return "mdt_hip (this repo)"
     if n.startswith("_ZN2ck") or "ck::" in n or "miopen" in n.lower() or "Cijk" in n or "gemm" in n.lower() or "batched_transpose" in n \
             or "naive_conv" in n or "SubTensor" in n or "Im2" in n or "Col2" in n or "igemm" in n:
