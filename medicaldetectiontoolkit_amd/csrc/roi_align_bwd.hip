@@ -7,8 +7,9 @@
 //
 // The op is a 4*B*C*V-byte fill (151 MB on the P2 level) plus a few MB of scattered gradient.  Design:
 //
-//   * "Territory".  The map is cut into segments of S contiguous floats (S = 32 = 128 B when the contiguous
-//     extent is a multiple of 32, else one whole row).  The territory of batch element b is the set of segments
+//   * "Territory".  The map is cut into segments of S contiguous floats (S = 8 = 32 B when the contiguous
+//     extent is a multiple of 8 -- finer segments keep the territory close to the RoI footprints -- else 32 or
+//     one whole row).  The territory of batch element b is the set of segments
 //     inside the index bounding box of any RoI with box_ind == b: a bitmap of R*nseg bits (P2: 4096 bits) that
 //     every workgroup recomputes from `boxes` in LDS (one global round trip, a few hundred lane-ops; no
 //     inter-workgroup communication, no prepass launch).
