@@ -1272,6 +1272,13 @@ int launch_bwd_fast(const float *grads, const float *boxes, const int *box_ind, 
 // form once a batch element carries dozens of RoIs (measured: N = 600 on P2 1.4 ms vs 0.25 ms).  The launcher only
 // knows N, so the switch is on N.
 constexpr int BWD_TERRITORY_MAX_BOXES = 128;
+// ... and one scatter workgroup per (batch element, channel) volume: with thousands of small volumes (2D Mask R-CNN:
+// 20 x 192 maps of 72 x 72) the per-workgroup prologue dominates and the two-kernel form wins (N = 120, (7,7):
+// 222 us vs 90 us), so the single-launch form is used up to this many volumes.
+constexpr long long BWD_TERRITORY_MAX_VOLUMES = 1024;
+
+// the workspace query has no batch argument: it reports the two-kernel size whenever that form might be chosen
+inline bool two_phase_possible(int dim, int depth) { return dim == 2 || depth > 128; }
 
 }  // namespace
 
@@ -1320,7 +1327,7 @@ size_t mdt_crop_and_resize_backward_workspace_bytes(int dim, int num_boxes, int 
     if (num_boxes <= 0 || depth <= 0 || crop_height <= 0 || crop_width <= 0 || image_height <= 0 || image_width <= 0)
         return 256;
     const int d3 = dim == 3;
-    if (num_boxes <= BWD_TERRITORY_MAX_BOXES &&
+    if (num_boxes <= BWD_TERRITORY_MAX_BOXES && !two_phase_possible(dim, depth) &&
         bwd_territory_supported(d3 ? 3 : 2, num_boxes, 1, image_height, image_width, d3 ? image_zdepth : 1,
                                 crop_height, crop_width, d3 ? crop_zdepth : 1, depth))
         return 256;   // default single-launch form needs no workspace
@@ -1351,7 +1358,9 @@ int mdt_crop_and_resize_3d_backward(const float *grads, const float *boxes, cons
                                     int ch, int cw, int cd, int depth,
                                     float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (num_boxes <= BWD_TERRITORY_MAX_BOXES) {
+    const bool many_volumes = (long long)batch * depth > BWD_TERRITORY_MAX_VOLUMES && workspace != nullptr &&
+        workspace_bytes >= mdt_crop_and_resize_backward_twophase_workspace_bytes(3, num_boxes, depth, H, W, D, ch, cw, cd);
+    if (num_boxes <= BWD_TERRITORY_MAX_BOXES && !many_volumes) {
         const int rt = launch_bwd_territory(3, grads, boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth,
                                             grads_image, (hipStream_t)stream);
         if (rt != MDT_ERR_UNSUPPORTED) return rt;
@@ -1369,7 +1378,9 @@ int mdt_crop_and_resize_2d_backward(const float *grads, const float *boxes, cons
                                     int ch, int cw, int depth,
                                     float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (num_boxes <= BWD_TERRITORY_MAX_BOXES) {
+    const bool many_volumes = (long long)batch * depth > BWD_TERRITORY_MAX_VOLUMES && workspace != nullptr &&
+        workspace_bytes >= mdt_crop_and_resize_backward_twophase_workspace_bytes(2, num_boxes, depth, H, W, 1, ch, cw, 1);
+    if (num_boxes <= BWD_TERRITORY_MAX_BOXES && !many_volumes) {
         const int rt = launch_bwd_territory(2, grads, boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth,
                                             grads_image, (hipStream_t)stream);
         if (rt != MDT_ERR_UNSUPPORTED) return rt;
@@ -1463,7 +1474,7 @@ int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, co
     if (dim != 2 && dim != 3) return MDT_ERR_INVALID_ARGUMENT;
     if (num_boxes < 0 || batch <= 0 || depth <= 0 || ch <= 0 || cw <= 0 || (dim == 3 && cd <= 0)) return MDT_ERR_INVALID_ARGUMENT;
     if (dim == 2) cd = 1;
-    if (num_boxes > BWD_TERRITORY_MAX_BOXES) return MDT_ERR_UNSUPPORTED;
+    if (num_boxes > BWD_TERRITORY_MAX_BOXES || (long long)batch * depth > BWD_TERRITORY_MAX_VOLUMES) return MDT_ERR_UNSUPPORTED;
     return launch_bwd_territory_multi(dim, n_levels, grads, boxes, batch_ix, level, num_boxes, batch, depth, H, W, D, ch, cw, cd,
                                       grads_images, s);
 }

@@ -583,8 +583,7 @@ class net(nn.Module):
         monitor=False skips building the python box lists (the loss terms are unchanged)."""
         cf = self.cf
         dev = self.device_
-        img = torch.from_numpy(np.ascontiguousarray(batch["data"])).to(dev, non_blocking=True).float() \
-            if not torch.is_tensor(batch["data"]) else batch["data"].to(dev).float()
+        img = mutils.upload(batch["data"], dev).float()
         gt_class_ids = batch["roi_labels"]
         gt_boxes = batch["bb_target"]
         B = img.shape[0]
@@ -593,7 +592,7 @@ class net(nn.Module):
             gt_masks = batch["roi_masks_device"]
         else:
             masks_list = [torch.as_tensor(np.ascontiguousarray(m)) for m in batch["roi_masks"] if len(m) > 0]
-            gt_masks = torch.cat(masks_list, 0).to(dev, non_blocking=True) if masks_list else None
+            gt_masks = mutils.upload(torch.cat(masks_list, 0), dev) if masks_list else None
 
         # all GT boxes / class ids go up in one pinned async copy BEFORE the backbone is launched: nothing in the step
         # waits for the stream afterwards, so the host keeps running ahead of the GPU through the glue

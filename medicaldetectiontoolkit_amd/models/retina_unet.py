@@ -189,8 +189,7 @@ class net(nn.Module):
     def train_forward(self, batch, monitor=True, **kwargs):
         """retina_unet.py:381-457."""
         cf, dev = self.cf, self.device_
-        img = torch.from_numpy(np.ascontiguousarray(batch["data"])).to(dev, non_blocking=True).float() \
-            if not torch.is_tensor(batch["data"]) else batch["data"].to(dev).float()
+        img = mutils.upload(batch["data"], dev).float()
         gt_class_ids, gt_boxes = batch["roi_labels"], batch["bb_target"]
         B = img.shape[0]
         gt_dev = GtOnDevice(gt_boxes, gt_class_ids, cf.dim, dev)      # one pinned async upload, before the backbone launch
@@ -212,8 +211,7 @@ class net(nn.Module):
         loss = batch_class_loss + batch_bbox_loss
         seg_dice = seg_ce = None
         if seg_logits is not None:
-            var_seg = (batch["seg"].to(dev) if torch.is_tensor(batch["seg"]) else
-                       torch.from_numpy(np.ascontiguousarray(batch["seg"])).to(dev, non_blocking=True)).long()
+            var_seg = mutils.upload(batch["seg"], dev).long()
             ohe = F.one_hot(var_seg[:, 0], cf.num_seg_classes).movedim(-1, 1).float()
             seg_dice = 1 - batch_dice(F.softmax(seg_logits, dim=1), ohe)
             seg_ce = F.cross_entropy(seg_logits, var_seg[:, 0])

@@ -67,6 +67,16 @@ def generate_pyramid_anchors(logger, cf, device=None, return_f32=False):
     return anchors
 
 
+def upload(array_or_tensor, device):
+    """host numpy array / CPU tensor -> device through PINNED staging memory with an asynchronous copy: a pageable
+    upload waits for the stream (the host loses its run-ahead) and moves at a fraction of the PCIe rate.  The pinned block
+    comes from torch's caching host allocator, which also keeps it alive until the copy has executed."""
+    t = array_or_tensor if torch.is_tensor(array_or_tensor) else torch.from_numpy(np.ascontiguousarray(array_or_tensor))
+    if t.device.type == "cpu" and torch.device(device).type == "cuda":
+        t = t.pin_memory()
+    return t.to(device, non_blocking=True)
+
+
 # --------------------------------------------------------------------------- anchor <-> GT matching
 _CONST = {}
 
