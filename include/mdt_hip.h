@@ -86,9 +86,14 @@ int mdt_crop_and_resize_2d_forward_bf16(
  * from LDS: per-axis interpolation as separable streaming passes into compact per-RoI blocks, then one ordered sum
  * per voxel over the RoIs covering it.  Deterministic run to run; sums are reassociated relative to the
  * reference's flat 8-corner scatter, so values agree to fp32 rounding (bar: 1e-4).
- * workspace: mdt_crop_and_resize_backward_workspace_bytes(...) -- 256 bytes (unused) whenever the default form
- * supports the shape; shapes beyond its LDS budgets (pool extents > 64, very large maps) run the two-kernel form
- * below and need its workspace; pool extents beyond that form's budget fall back to the _ordered kernel.
+ * Dispatch: the single-launch form runs for num_boxes <= 128 and batch * depth <= 1024 volumes on shapes within its LDS
+ * budgets; more RoIs, more (batch element, channel) volumes (the 2D models: 20 x 192 small maps) or shapes beyond the
+ * budgets (pool extents > 64, very large maps) run the two-kernel form below; pool extents beyond that form's budget
+ * fall back to the _ordered kernel.
+ * workspace: mdt_crop_and_resize_backward_workspace_bytes(...) -- the query has no batch argument, so it answers 256
+ * bytes (unused) only when the single-launch form is certain (dim == 3, depth <= 128, num_boxes <= 128, shape
+ * supported) and the two-kernel size otherwise.  A call that would prefer the two-kernel form but was given less than
+ * its workspace still runs (single-launch form, slower), it never fails for that reason.
  */
 size_t mdt_crop_and_resize_backward_workspace_bytes(int dim, int num_boxes, int depth,
                                                    int image_height, int image_width, int image_zdepth,
