@@ -5,8 +5,10 @@ mask), same `net(cf, logger)` with train_forward / test_forward / forward return
 results_dict.  What changed is the glue between the kernels:
   * proposal_layer (mrcnn.py:297-369): top-k, fused decode+clip+score kernel, ONE batched
     device-resident NMS over the batch with early stop at proposal_count; no D2H, no per-element sync.
-  * pyramid_roi_align (:373-457): level routing through box_ind (rows of other levels are written as
-    zeros by the kernel and summed away) -- no nonzero(), no gather/sort-back.
+  * pyramid_roi_align (:373-457): ONE forward launch and ONE backward launch for all pyramid levels (every RoI is
+    pooled on its own level and written to its own row) -- no per-level loop, no nonzero(), no gather/sort-back.
+  * all GT boxes / class ids of a step go to the device in one pinned asynchronous copy before the backbone is
+    launched (GtOnDevice); small constants are cached on the device: nothing inside a step waits for the stream.
   * detection_target_layer (:461-613), refine_detections (:620-714) and the RPN losses (:176-240) are
     expressed on fixed-size, masked tensors (random keys + top-k for the random sub-sampling, SHEM via
     sorted pools), so a training step has no host synchronisation before the final loss read-out.
