@@ -76,6 +76,9 @@ void oracle_crop_and_resize_3d_forward(
     (void)extrapolation_value;
     const int64_t total = (int64_t)num_boxes * depth * ch * cw * cd;
     memset(crops, 0, (size_t)total * sizeof(float));
+    /* every output element is independent: parallel over the flat index, like the reference's CPU path
+       (crop_and_resize.c:30, `#pragma omp parallel for` over boxes); results are bit-identical to the serial loop */
+#pragma omp parallel for schedule(static)
     for (int64_t out_idx = 0; out_idx < total; ++out_idx) {
         int64_t idx = out_idx;
         const int z = (int)(idx % cd); idx /= cd;
@@ -184,6 +187,9 @@ void oracle_crop_and_resize_2d_forward(
     (void)extrapolation_value;
     const int64_t total = (int64_t)num_boxes * depth * ch * cw;
     memset(crops, 0, (size_t)total * sizeof(float));
+    /* every output element is independent: parallel over the flat index, like the reference's CPU path
+       (crop_and_resize.c:30, `#pragma omp parallel for` over boxes); results are bit-identical to the serial loop */
+#pragma omp parallel for schedule(static)
     for (int64_t out_idx = 0; out_idx < total; ++out_idx) {
         int64_t idx = out_idx;
         const int x = (int)(idx % cw); idx /= cw;
