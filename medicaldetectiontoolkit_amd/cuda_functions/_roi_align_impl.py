@@ -228,9 +228,11 @@ def pyramid_backward(grads, boxes, batch_ix, level, shapes):
     if grads.dtype != torch.float32:
         grads = grads.float()
     dev = grads.device
+    n = grads.size(0)
+    if n == 0:
+        return [torch.zeros(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
     outs = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
     crop = tuple(grads.shape[2:])
-    n = grads.size(0)
     H, W, D = _level_dims(shapes, dim)
     prof = PROFILE
     if prof is not None:
