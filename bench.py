@@ -2,8 +2,10 @@
 patches (LIDC-shape config 3), one process per GPU, plus the RoIAlign-3D-backward roofline measured live.
 
   python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N ...      (WORLD_SIZE unset: re-launches itself under torch.distributed.run with N ranks;
+                                     exits non-zero when the node has fewer than N GPUs -- never an n_gpus:1 line)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W          (how the driver launches N ranks; --gpus must equal WORLD_SIZE)
 
 A "step" = exec.py:68-74 of the reference: net.train_forward(batch) [incl. H2D of the batch], zero_grad,
 backward, (gradient all-reduce over RCCL when N > 1), Adam step; per-GPU batch = 8 patches (weak scaling).
@@ -174,6 +176,61 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
     return out
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this file as N ranks (one per GPU) under torch.distributed.run
+    on 127.0.0.1 and hand its exit code back."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd))
+
+
+def rccl_world1_selftest(net, opt, batch, dev, steps=3):
+    """The N > 1 gradient path on its real backend, on a 1-GPU box: a world-size-1 `nccl` (= RCCL) process group, the
+    collectives of training.FlatGradAllReduce forced on.  (1) local gradient (hooks off) vs the same buffer after the
+    bucket all-reduces: must be bit-identical (sum over one rank, / 1); (2) `steps` train_steps with the async bucket
+    all-reduces launched from the backward hooks: parameters stay finite, step time reported."""
+    from medicaldetectiontoolkit_amd import training
+    t_init = time.time()
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, device_id=dev)
+    try:
+        sync = training.FlatGradAllReduce(net, force=True)
+        res = net.train_forward(batch, monitor=False)
+        sync.zero()
+        sync.force = False
+        res["torch_loss"].backward()
+        local = sync.flat.clone()
+        sync.force = True
+        sync.finish()
+        torch.cuda.synchronize()
+        identical = bool(torch.equal(sync.flat, local))
+        opt.step()
+        t_init = time.time() - t_init
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(steps):
+            training.train_step(net, opt, batch, grad_sync=sync, monitor=False)
+        torch.cuda.synchronize()
+        ms = (time.time() - t0) / steps * 1e3
+        launched = sync._next
+        flat_params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        return {"backend": dist.get_backend(), "world": dist.get_world_size(), "buckets_all_reduced_per_step": int(launched),
+                "grad_bit_identical_after_allreduce": identical, "params_finite": bool(torch.isfinite(flat_params).all()),
+                "ms_per_step_with_collectives": round(ms, 2), "init_plus_first_step_s": round(t_init, 2)}
+    finally:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +241,7 @@ def main():
     ap.add_argument("--model", type=str, default="mrcnn", choices=["mrcnn", "retina_unet"],
                     help="mrcnn = BASELINE config 3 (headline); retina_unet = config 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the world-size-1 RCCL self-test after the timed loop")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra host-batch steps after the timed loop (profiling runs)")
     ap.add_argument("--fused-adam", type=int, default=0)
     ap.add_argument("--fused-epilogue", type=int, default=1, help="1 (default): fused bias/residual/ReLU conv epilogues (csrc/epilogue.hip); 0: torch ops (A/B)")
@@ -195,12 +253,24 @@ def main():
     ap.add_argument("--host-batches", action="store_true", help="hand numpy batches to train_forward (PCIe-inclusive rate)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    n_dev = torch.cuda.device_count()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if n_dev < args.gpus and args.backend == "nccl":
+            raise SystemExit("bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to report a smaller run" % (args.gpus, n_dev))
+        _self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
-    local_dev = local_rank % torch.cuda.device_count()      # == local_rank whenever there is one GPU per rank
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
+    if args.backend == "nccl" and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > n_dev:
+        raise SystemExit("bench.py: %s local ranks but only %d GPU(s): RCCL needs one GPU per rank (use --backend gloo to share a GPU for debugging)"
+                         % (os.environ.get("LOCAL_WORLD_SIZE", world), n_dev))
+    local_dev = local_rank % n_dev      # == local_rank whenever there is one GPU per rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     if world > 1:   # N processes share the host: do not let each spin up one intra-op thread per core
@@ -275,6 +345,19 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # post-step parameters: one checksum per rank; identical weights on every rank <=> min == max
+    with torch.no_grad():
+        csum = torch.stack([p.detach().double().sum() for p in net.parameters()]).sum().reshape(1)
+    cmin, cmax = csum.clone(), csum.clone()
+    devices = [torch.cuda.get_device_name(dev)]
+    if world > 1:
+        dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        devices = [None] * world
+        dist.all_gather_object(devices, "rank %d: cuda:%d %s" % (rank, local_dev, torch.cuda.get_device_name(dev)))
+    dist_rec = {"world": world, "backend": (dist.get_backend() if world > 1 else None), "devices": devices,
+                "param_checksum": float(cmin.item()), "params_identical_across_ranks": bool(cmin.item() == cmax.item()),
+                "grad_buckets": (len(sync.bucket_range) if sync is not None and sync.flat is not None else None)}
 
     if rank == 0:
         roofline = roialign_bwd_roofline(cf, args.batch, dev, prof)
@@ -294,8 +377,13 @@ def main():
                            "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),
                        "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over %s)" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "global_batch": args.batch * world},
-            "roofline": roofline, "cpu_baseline": cpu, "h2d_inclusive": h2d,
+            "roofline": roofline, "cpu_baseline": cpu, "h2d_inclusive": h2d, "distributed": dist_rec,
         }
+        if world == 1 and not args.no_rccl_selftest:
+            try:
+                out["distributed"]["rccl_world1_selftest"] = rccl_world1_selftest(net, opt, pool[0] if not args.host_batches else to_device(pool[0], dev), dev)
+            except Exception as e:   # reported, never fatal for the bench line
+                out["distributed"]["rccl_world1_selftest"] = {"failed": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -36,8 +36,10 @@ inline int ep_check()
 // ---- forward ---------------------------------------------------------------------------------------------------
 // CL: channels-last storage (channel = i % C); else contiguous (channel = (i / inner) % C, inner % 4 == 0 on the vector path)
 template <bool CL, bool RES, bool RELU>
-__global__ __launch_bounds__(EP_THREADS) void bias_act_fwd_kernel(float *__restrict__ y, const float *__restrict__ x,
-                                                                  const float *__restrict__ bias, const float *__restrict__ res,
+// y and x (and res) may alias: the Python side runs the epilogue IN PLACE (y == x); each thread reads its elements before it
+// writes the same ones, so no restrict qualifier on them
+__global__ __launch_bounds__(EP_THREADS) void bias_act_fwd_kernel(float *y, const float *x,
+                                                                  const float *__restrict__ bias, const float *res,
                                                                   long long n4, long long n, int C, long long inner)
 {
     const long long stride = (long long)gridDim.x * EP_THREADS;

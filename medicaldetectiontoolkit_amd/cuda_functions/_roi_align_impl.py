@@ -31,9 +31,10 @@ def _prep(image, boxes, box_ind, dim):
         raise ValueError("box_ind must be [N]")
     # the reference's C glue never checks dtype / contiguity (crop_and_resize_gpu.c); do it here
     image = image.contiguous()
-    # bf16 feature maps (autocast inference, BASELINE config 5) go to the bf16-input kernel as they are when no gradient
-    # is needed; everything else is interpolated from fp32
-    if image.dtype != torch.float32 and not (image.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and image.requires_grad)):
+    # bf16 feature maps (autocast, BASELINE config 5) ALWAYS go to the bf16-input kernel as they are: it widens each bf16
+    # value exactly to fp32 and interpolates in fp32 (bit-equal to the fp32 kernel on the widened map), in training too --
+    # the backward produces an fp32 gradient map that is cast back to the map's dtype.  Other dtypes are converted to fp32.
+    if image.dtype not in (torch.float32, torch.bfloat16):
         image = image.float()
     boxes = boxes.detach().to(device=image.device, dtype=torch.float32).contiguous()
     box_ind = box_ind.detach().to(device=image.device, dtype=torch.int32).contiguous()
@@ -264,8 +265,9 @@ class _PyramidRoIAlign(Function):
         dim = len(crop)
         for m in maps:
             _lib.require_cuda(m, "feature map")
-        need_grad = torch.is_grad_enabled() and any(m.requires_grad for m in maps)
-        bf16 = all(m.dtype == torch.bfloat16 for m in maps) and not need_grad
+        # inside Function.forward grad mode is always off, so there is nothing to test here: bf16 maps are always read by
+        # the bf16-input kernel (exact widening, fp32 interpolation); backward returns fp32 maps cast to ctx.dtypes
+        bf16 = all(m.dtype == torch.bfloat16 for m in maps)
         maps_c = [m.contiguous() if (m.dtype == torch.float32 or bf16) else m.float().contiguous() for m in maps]
         boxes = boxes.detach().to(device=maps_c[0].device, dtype=torch.float32).contiguous()
         batch_ix = batch_ix.detach().to(device=maps_c[0].device, dtype=torch.int32).contiguous()

@@ -27,7 +27,10 @@ class FlatGradAllReduce(object):
       goes out in `finish()`.  No find_unused_parameters machinery, no rank-dependent hangs.
     """
 
-    def __init__(self, net, n_buckets=4, overlap=True):
+    def __init__(self, net, n_buckets=4, overlap=True, force=False):
+        # force=True: run the collectives even at world size 1 (RCCL self-test on a 1-GPU box: the sum over one rank
+        # must leave every gradient bit-identical)
+        self.force = bool(force)
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.n_buckets = max(1, int(n_buckets))
@@ -62,7 +65,7 @@ class FlatGradAllReduce(object):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force)
 
     def _launch_ready(self, force=False):
         while self._next < len(self.bucket_range) and (force or self._left[self._next] == 0):

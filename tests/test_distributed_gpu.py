@@ -75,3 +75,68 @@ def test_real_train_step_two_ranks_on_one_gpu(tmp_path, cuda):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     got = torch.load(str(tmp_path / "ok.pt"))
     assert got["ok"] and got["n_buckets"] >= 2
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """world-size-1 `nccl` (= RCCL) group: the hook-launched async bucket all-reduces run on the real backend."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from medicaldetectiontoolkit_amd import miopen_env
+    miopen_env.setup()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=dev)
+    from medicaldetectiontoolkit_amd import training
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from medicaldetectiontoolkit_amd.models import mrcnn
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch, to_device
+    patch = [64, 64, 32]
+    cf = Configs(dim=3, model="mrcnn", patch_size=patch, batch_size=2)
+    torch.manual_seed(0)
+    net = mrcnn.net(cf, device=dev)
+    opt = training.build_optimizer(net, cf)
+    sync = training.FlatGradAllReduce(net, n_buckets=4, force=True)
+    assert sync._active(), "force=True must switch the collectives on at world size 1"
+    batch = to_device(make_batch(patch, 2, seed=7), dev)
+    # (1) local gradient with the hooks off, then the bucket all-reduces over RCCL: sum over one rank, / 1 = same bits
+    res = net.train_forward(batch, monitor=False)
+    sync.zero()
+    sync.force = False
+    res["torch_loss"].backward()
+    local = sync.flat.clone()
+    assert float(local.abs().sum()) > 0
+    sync.force = True
+    sync.finish()
+    torch.cuda.synchronize()
+    assert sync._next == len(sync.bucket_range) and len(sync._handles) == len(sync.bucket_range)
+    assert torch.equal(sync.flat, local), "RCCL all-reduce at world 1 changed the gradient"
+    opt.step()
+    # (2) the real step: buckets launched asynchronously from the post-accumulate hooks during backward
+    before = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    training.train_step(net, opt, batch, grad_sync=sync, monitor=False)
+    torch.cuda.synchronize()
+    assert sync._next == len(sync.bucket_range), "not every bucket went out"
+    after = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.isfinite(after).all() and not torch.equal(before, after)
+    torch.save({"ok": True, "backend": dist.get_backend(), "buckets": len(sync.bucket_range)}, os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_train_step_over_rccl_world1(tmp_path, cuda):
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = torch.load(str(tmp_path / "rccl.pt"))
+    assert got["ok"] and got["backend"] == "nccl" and got["buckets"] >= 2
+
+
+def test_bench_refuses_more_gpus_than_present(cuda):
+    """`python bench.py --gpus N` with N > device_count must exit non-zero and print no JSON line (never an n_gpus:1
+    line for a larger request)."""
+    import subprocess
+    import sys
+    n = torch.cuda.device_count() + 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert "requested but this node exposes" in r.stderr
+    assert "n_gpus" not in r.stdout

@@ -44,6 +44,11 @@ CASES_3D = [
     (2, 2, 6, 5, 7, 6, (3, 2, 2), True),            # odd extents -> scalar (VEC=1) path
     (1, 2, 9, 9, 12, 4, (1, 1, 1), False),          # P == 1 rule
     (2, 4, 16, 16, 16, 700, (7, 7, 3), True),       # > 256 RoIs: multi-chunk list
+    # 64 < N <= 128: the single-launch kernel's multi-chunk RoI scan (more than one chunk of candidates per volume)
+    (8, 36, 32, 32, 128, 65, (14, 14, 5), False),   # P2
+    (16, 8, 16, 16, 64, 96, (7, 7, 3), True),       # batch 16 x 6 RoIs per image
+    (8, 36, 16, 16, 64, 128, (7, 7, 3), True),      # P3, the dispatch limit itself
+    (2, 6, 32, 32, 64, 100, (14, 14, 5), True),     # ~50 RoIs on one element: many rounds per volume
 ]
 
 
@@ -124,6 +129,30 @@ def test_roialign2d_forward_backward_bitexact(case, cuda):
     assert np.all(err <= FAST_TOL * scale), (err / scale).max()
     go = _roi_align_impl.crop_backward(_t(g, cuda), _t(boxes, cuda), _t(box_ind, cuda), image.shape, mode="ordered")
     assert np.array_equal(go.cpu().numpy(), want_g)
+
+
+@pytest.mark.parametrize("with_workspace", [False, True])
+def test_roialign2d_backward_training_call_many_volumes(with_workspace, cuda):
+    """The 2D Mask R-CNN training call (20 x 192 maps of 72 x 72, N = 120 RoIs, pool (7,7)) through the C ABI: without a
+    workspace the single-launch kernel runs (multi-chunk RoI scan, N > 64); with the two-phase workspace the entry point
+    switches to the two-kernel form (more than 1024 volumes).  Both must match the oracle."""
+    rng = np.random.default_rng(120)
+    B, C, Y, X, N, crop = 20, 192, 72, 72, 120, (7, 7)
+    boxes = random_boxes_2d(rng, N, patch=288.0, size=(8, 128), spill=True)
+    box_ind = (np.arange(N) // 6).astype(np.int32)
+    g = rng.normal(size=(N, C) + crop).astype(np.float32)
+    want = oracle.crop_and_resize_backward(g, boxes, box_ind, (B, C, Y, X))
+    scale = np.maximum(1.0, oracle.crop_and_resize_backward(np.abs(g), boxes, box_ind, (B, C, Y, X)))
+    L = _lib.lib()
+    gt, bt, it = _t(g, cuda), _t(boxes, cuda), _t(box_ind, cuda)
+    out = torch.full((B, C, Y, X), float("nan"), device=cuda)
+    wsb = L.mdt_crop_and_resize_backward_twophase_workspace_bytes(2, N, C, Y, X, 1, crop[0], crop[1], 1) if with_workspace else 0
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=cuda)
+    rc = L.mdt_crop_and_resize_2d_backward(_lib.ptr(gt), _lib.ptr(bt), _lib.ptr(it), N, B, Y, X, crop[0], crop[1], C, _lib.ptr(out),
+                                           _lib.ptr(ws) if with_workspace else None, wsb, _lib.current_stream_ptr())
+    assert rc == 0
+    err = np.abs(out.cpu().numpy() - want)          # a NaN left anywhere (unwritten byte) fails the comparison
+    assert np.all(err <= FAST_TOL * scale), float(np.nanmax(err / scale))
 
 
 def test_roialign3d_backward_deterministic_and_full_size(cuda):
@@ -215,6 +244,57 @@ def test_roialign3d_vs_reference_cuda_kernel_on_gpu(cuda):
     torch.cuda.synchronize()
     got_g = _roi_align_impl.crop_backward(g, boxes, box_ind, image.shape)
     assert ((got_g - ref_g).abs() <= TOL * ref_g.abs().clamp(min=1.0)).all()
+
+
+def test_roialign2d_vs_reference_cuda_kernel_on_gpu(cuda):
+    """oracle/_ref/libref_gpu_roialign2d.so = roi_align_2D/.../crop_and_resize_kernel.cu compiled for gfx950."""
+    L = _ref_gpu("libref_gpu_roialign2d.so")
+    rng = np.random.default_rng(13)
+    B, C, Y, X, N, crop = 4, 16, 72, 72, 60, (7, 7)
+    image = torch.randn(B, C, Y, X, device=cuda)
+    boxes = _t(random_boxes_2d(rng, N, patch=288.0, size=(8, 128), spill=True), cuda)
+    box_ind = _t(rng.integers(0, B, size=N).astype(np.int32), cuda)
+    ref = torch.zeros(N, C, *crop, device=cuda)
+    torch.cuda.synchronize()
+    vp = ctypes.c_void_p
+    L.CropAndResizeLaucher(vp(image.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X,
+                           crop[0], crop[1], C, ctypes.c_float(0), vp(ref.data_ptr()), vp(0))
+    torch.cuda.synchronize()
+    got = _roi_align_impl.crop_forward(image, boxes, box_ind, crop)
+    assert (got - ref).abs().max().item() <= TOL
+    g = torch.randn_like(ref)
+    ref_g = torch.zeros_like(image)
+    torch.cuda.synchronize()
+    L.CropAndResizeBackpropImageLaucher(vp(g.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X,
+                                        crop[0], crop[1], C, vp(ref_g.data_ptr()), vp(0))
+    torch.cuda.synchronize()
+    got_g = _roi_align_impl.crop_backward(g, boxes, box_ind, image.shape)
+    assert ((got_g - ref_g).abs() <= TOL * ref_g.abs().clamp(min=1.0)).all()
+
+
+def test_nms2d_mask_vs_reference_cuda_kernel_on_gpu(cuda):
+    """oracle/_ref/libref_gpu_nms2d.so = nms_2D/src/cuda/nms_kernel.cu compiled for gfx950: same mask words."""
+    L = _ref_gpu("libref_gpu_nms2d.so")
+    rng = np.random.default_rng(14)
+    n = 1000
+    dets = nms_boxes(rng, n, dim=2, patch=320.0)
+    ds = _t(dets[oracle.sort_order(dets[:, -1])], cuda)
+    cb = (n + 63) // 64
+    ref = torch.zeros(n, cb, dtype=torch.int64, device=cuda)
+    torch.cuda.synchronize()
+    vp = ctypes.c_void_p
+    L._nms(n, vp(ds.data_ptr()), vp(ref.data_ptr()), ctypes.c_float(0.7))
+    torch.cuda.synchronize()
+    mine = torch.zeros(n, cb, dtype=torch.int64, device=cuda)
+    rc = _lib.lib().mdt_nms_mask_2d(_lib.ptr(ds), n, ctypes.c_float(0.7), 0, _lib.ptr(mine), _lib.current_stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref, mine = ref.cpu().numpy(), mine.cpu().numpy()
+    rows = np.arange(n)[:, None] // 64
+    upper = np.arange(cb)[None, :] >= rows
+    diff = np.unpackbits((ref[upper] ^ mine[upper]).view(np.uint8)).sum()
+    assert diff <= 1e-5 * upper.sum() * 64
+    assert np.all(mine[~upper] == 0)
 
 
 def test_nms3d_mask_vs_reference_cuda_kernel_on_gpu(cuda):

@@ -42,6 +42,8 @@ CASES = [
     (3, 8, 36, (64, 64, 32), 48, (7, 7, 3)),
     (2, 2, 8, (128, 128), 40, (7, 7)),
     (2, 3, 5, (64, 96), 17, (14, 14)),
+    (3, 16, 4, (64, 64, 32), 96, (7, 7, 3)),    # batch 16 x 6 RoIs: 64 < N <= 128, multi-chunk RoI scan inside the one launch
+    (3, 4, 6, (64, 64, 32), 128, (14, 14, 5)),  # the dispatch limit, ~32 RoIs per element: several rounds per volume
     (3, 1, 3, (24, 20, 12), 9, (7, 7, 3)),      # contiguous extents 12/12/3..: not a multiple of 8 -> per-level fallback inside
 ]
 

@@ -1,6 +1,6 @@
 import os, sys, json, ctypes
 os.environ["MDT_BWD_TUNE"] = "1"
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from medicaldetectiontoolkit_amd import _lib
 from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
@@ -30,7 +30,7 @@ for nt in ("512",):
     for zero_off in (0,):
         os.environ["MDT_BWD_DBG"] = str(zero_off)
         ind_bal = torch.arange(N, dtype=torch.int32, device=dev) % B
-        for name, (bx, ind) in {"balanced": (boxes, ind_bal), "train": (boxes_train, ind_train)}.items():
+        for name, (bx, ind) in {"random": (boxes, ind_rand), "balanced": (boxes, ind_bal), "train": (boxes_train, ind_train)}.items():
             for wg in (0, 150):
                 os.environ["MDT_BWD_DBG_WG"] = str(wg)
                 for _ in range(3):

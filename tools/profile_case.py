@@ -1,6 +1,7 @@
 """One case in a loop, for rocprofv3 --kernel-trace --stats.  Usage: profile_case.py <case> [iters]
 cases: bwd_fast | bwd_twophase | bwd_ordered | fwd | nms6000 | nms6000_keep75 | pmc_bwd
-env: MDT_N, MDT_CROP, MDT_ROIS=random|trainlike, MDT_INVALID=1"""
+       | pyramid_bwd (all four levels in one launch, 48 RoIs routed 24/12/8/4)
+env: MDT_N, MDT_CROP, MDT_ROIS=random|trainlike, MDT_INVALID=1, MDT_LEVEL=P2..P5"""
 import os
 import sys
 
@@ -18,7 +19,8 @@ N = int(os.environ.get("MDT_N", 48))
 crop = tuple(int(v) for v in os.environ.get("MDT_CROP", "14,14,5").split(","))
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
-shape = (8, 36, 32, 32, 128)
+LEVELS = {"P2": (32, 32, 128), "P3": (16, 16, 64), "P4": (8, 8, 32), "P5": (4, 4, 16)}
+shape = (8, 36) + LEVELS[os.environ.get("MDT_LEVEL", "P2")]
 boxes = torch.from_numpy(random_boxes_3d(rng, N)).to(dev)
 box_ind = torch.from_numpy(rng.integers(0, 8, size=N).astype(np.int32)).to(dev)
 if os.environ.get("MDT_ROIS", "random") == "trainlike":   # 6 RoIs per element, P2-sized (tests/helpers.trainlike_rois_3d)
@@ -38,6 +40,19 @@ fns = {
     "nms6000": lambda: _nms_impl.nms_sorted(ds, 0.7, 3),
     "nms6000_keep75": lambda: _nms_impl.nms_sorted(ds, 0.7, 3, max_keep=75),
 }
+if case == "pyramid_bwd":
+    shapes = [(8, 36) + LEVELS[k] for k in ("P2", "P3", "P4", "P5")]
+    per = []
+    for li, (side, n) in enumerate(((8.0, 24), (16.0, 12), (32.0, 8), (64.0, 4))):
+        tb, ti = trainlike_rois_3d(rng, 8, 6, side)
+        keep = rng.permutation(len(tb))[:n]
+        per.append((tb[keep], ti[keep], np.full(n, li, dtype=np.int32)))
+    order = rng.permutation(48)
+    pb = torch.from_numpy(np.concatenate([q[0] for q in per])[order]).to(dev)
+    pi = torch.from_numpy(np.concatenate([q[1] for q in per])[order]).to(dev)
+    pl = torch.from_numpy(np.concatenate([q[2] for q in per])[order]).to(dev)
+    gp = torch.randn((48, 36) + crop, device=dev)
+    fns["pyramid_bwd"] = lambda: _roi_align_impl.pyramid_backward(gp, pb, pi, pl, shapes)
 if case == "pmc_bwd":
     # calibration dispatches (known byte count: plain 151 MB fill) followed by the op under test
     out = torch.empty(shape, device=dev)
