@@ -145,6 +145,9 @@ int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, co
  * >= 64 + 4 * grid int64 entries the kernel records per-stage / per-workgroup wall-clock stamps there; NULL (default)
  * turns it off.  Not part of the reference's interface. */
 void mdt_debug_bwd_timestamps(long long *dev_buf);
+/* Same for the round-3 gather-form backward (csrc/roi_align_bwd_v3.hip; tools/bwd3_probe.py): dev_buf >= 16 int64 or NULL;
+ * dbg bit0 / bit1 make the scatter / zero role return at once (role-by-role timing); wg = traced scatter workgroup. */
+void mdt_debug_bwd3(long long *dev_buf, int dbg, int wg);
 
 /* Exact-order form: gather kernel that adds, per voxel, the terms in exactly the order a
  * sequential out_idx loop would (corner order of crop_and_resize_kernel.cu:256-301), so the

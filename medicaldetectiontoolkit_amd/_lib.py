@@ -31,6 +31,7 @@ _SIGNATURES = {
     "mdt_pyramid_roi_align_forward": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mdt_pyramid_roi_align_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mdt_debug_bwd_timestamps": (None, [c_void_p]),
+    "mdt_debug_bwd3": (None, [c_void_p, c_int, c_int]),
     "mdt_crop_and_resize_3d_backward_ordered": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
     "mdt_crop_and_resize_3d_backward_atomic": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
     "mdt_crop_and_resize_2d_forward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p, c_void_p]),

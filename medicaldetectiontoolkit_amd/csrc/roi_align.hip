@@ -1277,6 +1277,14 @@ constexpr int BWD_TERRITORY_MAX_BOXES = 128;
 // 222 us vs 90 us), so the single-launch form is used up to this many volumes.
 constexpr long long BWD_TERRITORY_MAX_VOLUMES = 1024;
 
+// Which single-launch form runs first: the round-3 gather kernel (roi_align_bwd_v3.hip) unless MDT_BWD_KERNEL=r2 asks for
+// the round-2 territory kernel (same-box A/B rows of tools/microbench.py).  Read once.
+inline bool use_gather_kernel()
+{
+    static const bool v = [] { const char *e = getenv("MDT_BWD_KERNEL"); return !(e && e[0] == 'r' && e[1] == '2'); }();
+    return v;
+}
+
 // the workspace query has no batch argument: it reports the two-kernel size whenever that form might be chosen
 inline bool two_phase_possible(int dim, int depth) { return dim == 2 || depth > 128; }
 
@@ -1361,6 +1369,11 @@ int mdt_crop_and_resize_3d_backward(const float *grads, const float *boxes, cons
     const bool many_volumes = (long long)batch * depth > BWD_TERRITORY_MAX_VOLUMES && workspace != nullptr &&
         workspace_bytes >= mdt_crop_and_resize_backward_twophase_workspace_bytes(3, num_boxes, depth, H, W, D, ch, cw, cd);
     if (num_boxes <= BWD_TERRITORY_MAX_BOXES && !many_volumes) {
+        if (use_gather_kernel()) {
+            const int rg = launch_bwd_gather(3, 1, grads, boxes, box_ind, nullptr, num_boxes, batch, depth, &H, &W, &D, ch, cw, cd,
+                                             &grads_image, (hipStream_t)stream);
+            if (rg != MDT_ERR_UNSUPPORTED) return rg;
+        }
         const int rt = launch_bwd_territory(3, grads, boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth,
                                             grads_image, (hipStream_t)stream);
         if (rt != MDT_ERR_UNSUPPORTED) return rt;
@@ -1381,6 +1394,12 @@ int mdt_crop_and_resize_2d_backward(const float *grads, const float *boxes, cons
     const bool many_volumes = (long long)batch * depth > BWD_TERRITORY_MAX_VOLUMES && workspace != nullptr &&
         workspace_bytes >= mdt_crop_and_resize_backward_twophase_workspace_bytes(2, num_boxes, depth, H, W, 1, ch, cw, 1);
     if (num_boxes <= BWD_TERRITORY_MAX_BOXES && !many_volumes) {
+        if (use_gather_kernel()) {
+            const int one = 1;
+            const int rg = launch_bwd_gather(2, 1, grads, boxes, box_ind, nullptr, num_boxes, batch, depth, &H, &W, &one, ch, cw, 1,
+                                             &grads_image, (hipStream_t)stream);
+            if (rg != MDT_ERR_UNSUPPORTED) return rg;
+        }
         const int rt = launch_bwd_territory(2, grads, boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth,
                                             grads_image, (hipStream_t)stream);
         if (rt != MDT_ERR_UNSUPPORTED) return rt;
@@ -1475,6 +1494,11 @@ int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, co
     if (num_boxes < 0 || batch <= 0 || depth <= 0 || ch <= 0 || cw <= 0 || (dim == 3 && cd <= 0)) return MDT_ERR_INVALID_ARGUMENT;
     if (dim == 2) cd = 1;
     if (num_boxes > BWD_TERRITORY_MAX_BOXES || (long long)batch * depth > BWD_TERRITORY_MAX_VOLUMES) return MDT_ERR_UNSUPPORTED;
+    if (use_gather_kernel()) {
+        const int rg = launch_bwd_gather(dim, n_levels, grads, boxes, batch_ix, level, num_boxes, batch, depth, H, W, D, ch, cw, cd,
+                                         grads_images, s);
+        if (rg != MDT_ERR_UNSUPPORTED) return rg;
+    }
     return launch_bwd_territory_multi(dim, n_levels, grads, boxes, batch_ix, level, num_boxes, batch, depth, H, W, D, ch, cw, cd,
                                       grads_images, s);
 }

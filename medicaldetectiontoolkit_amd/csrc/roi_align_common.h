@@ -75,6 +75,13 @@ int launch_bwd_territory_multi(int dim, int n_levels, const float *grads, const 
                                int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
                                float *const *outs, hipStream_t s);
 
+// roi_align_bwd_v3.hip: round-3 default backward (gather form; one launch for one map or for all pyramid levels; 2D maps as
+// the W = 1 case).  `level` may be null (every RoI on level 0).  MDT_ERR_UNSUPPORTED: outside its budgets -> the caller
+// falls back to the forms above.
+int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
+                      int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
+                      float *const *outs, hipStream_t s);
+
 }  // namespace mdt_ra
 
 #endif
