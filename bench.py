@@ -10,8 +10,9 @@ patches (LIDC-shape config 3), one process per GPU, plus the RoIAlign-3D-backwar
 A "step" = exec.py:68-74 of the reference: net.train_forward(batch) [incl. H2D of the batch], zero_grad,
 backward, (gradient all-reduce over RCCL when N > 1), Adam step; per-GPU batch = 8 patches (weak scaling).
 Rank 0 prints ONE JSON line.  `roofline` is the dominant custom kernel (RoIAlign-3D backward on the P2 level):
-algorithmic bytes / event-timed duration of the C-ABI op with 48 RoIs forced onto the level,
-measured after the timed training loop; `roofline.variants` also carries the op as it ran inside the steps.
+algorithmic bytes / event-timed duration of the C-ABI op with 48 RoIs of the SURVEY.md 8(d) box distribution on the
+level, measured after the timed training loop; `roofline.variants` carries the cache-cold run, the train-realistic
+placement, the four-level one-launch form and the op as it ran inside the steps.
 `cpu_baseline` times a bounded sample of the same work on the host cores with the CPU oracle (native ops) and
 torch-CPU (conv path).
 """
@@ -121,43 +122,89 @@ def _time_op(fn, launches, warmup=10):
     return float(np.mean(t)), float(t[len(t) // 2])
 
 
+def _pyramid_case(rng, cf, batch, n_per_level):
+    """48 sampled RoIs routed to the four levels like the level rule of mrcnn.py:403 would (box side ~ anchor scale of the
+    level): tests/helpers.trainlike_rois_3d per level, shuffled row order"""
+    from tests.helpers import trainlike_rois_3d
+    per = []
+    for li, n in enumerate(n_per_level):
+        side = float(cf.rpn_anchor_scales["xy"][li][0])
+        tb, ti = trainlike_rois_3d(rng, batch, cf.train_rois_per_image, side, float(cf.patch_size[0]))
+        keep = rng.permutation(len(tb))[:n]
+        per.append((tb[keep], ti[keep], np.full(n, li, dtype=np.int32)))
+    order = rng.permutation(sum(n_per_level))
+    return (np.concatenate([q[0] for q in per])[order], np.concatenate([q[1] for q in per])[order],
+            np.concatenate([q[2] for q in per])[order])
+
+
 def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
-    """Roofline of the dominant custom kernel: mdt_crop_and_resize_3d_backward on the P2 level:
-    grads_image 8x36x32x32x128, pool (14,14,5), N = 48 valid RoIs forced onto the level, event-timed launches of the
-    C-ABI op after the training loop.  Headline case = train-realistic placement (6 sampled RoIs per batch element,
-    P2-sized boxes, tests/helpers.trainlike_rois_3d); `variants` carries the SURVEY 8(d) random-box placement
-    (log-uniform 8..64 px boxes, box_ind ~ U{0..B-1}) and the op as it ran inside the timed training steps."""
+    """Roofline of the dominant custom kernel, RoIAlign-3D backward: algorithmic bytes (every gradient
+    map written once + the pooled gradients read once + 28 B per RoI) / event-timed duration of the C-ABI op, measured
+    after the training loop.  pool (14,14,5), N = 48 valid RoIs.
+      headline   P2 map 8x36x32x32x128, the survey's own box distribution (centre U(0,1)^3, xy side
+                 log-uniform 8..64 px, z 2..16 px, box_ind ~ U{0..B-1}), all 48 RoIs on the level, the SAME output
+                 buffer rewritten every launch (cache-warm: the 256 MiB Infinity Cache may absorb part of the write);
+      variants   the same case CACHE-COLD (4 output buffers = 604 MB rotated), the train-realistic placement (6 sampled
+                 RoIs per element around one object, level-sized boxes) warm and cold, all four pyramid levels in ONE launch
+                 with the 48 RoIs routed 24/12/8/4 (warm and cold), and the op as it ran inside the timed training steps."""
     from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
     from tests.helpers import random_boxes_3d, trainlike_rois_3d
-    p2 = tuple(int(v) for v in cf.backbone_shapes[0])
-    shape = (batch, cf.end_filts) + p2
+    shapes = [(batch, cf.end_filts) + tuple(int(v) for v in sh) for sh in cf.backbone_shapes]
+    shape = shapes[0]
     crop = tuple(cf.mask_pool_size)
     n = cf.train_rois_per_image * batch
-    V, P = int(np.prod(p2)), int(np.prod(crop))
+    V, P = int(np.prod(shape[2:])), int(np.prod(crop))
     alg = 4.0 * batch * cf.end_filts * V + 4.0 * n * cf.end_filts * P + 28.0 * n
+    alg_pyr = 4.0 * sum(int(np.prod(sh)) for sh in shapes) + 4.0 * n * cf.end_filts * P + 36.0 * n
     rng = np.random.default_rng(0)
     g = torch.randn((n, cf.end_filts) + crop, device=dev)
     tb, ti = trainlike_rois_3d(rng, batch, cf.train_rois_per_image, 8.0, float(cf.patch_size[0]))
     rb, ri = random_boxes_3d(rng, n), rng.integers(0, batch, size=n).astype(np.int32)
+    pb, pi, pl = _pyramid_case(rng, cf, batch, (n // 2, n // 4, n // 6, n - n // 2 - n // 4 - n // 6))
     traffic = {}
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc", "traffic.json")))
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc", "traffic.json")))
     except Exception:
         pass
+    n_rot = 4                      # 4 x 151 MB = 604 MB > the 256 MiB Infinity Cache: every launch writes lines it does not hold
+    rot = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(n_rot)]
+    rot_pyr = [[rot[k]] + [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes[1:]] for k in range(n_rot)]
+    state = {"k": 0}
 
-    def case(boxes, ind, key):
+    def rec_of(mean_s, med_s, byts, rois, tkey=None):
+        r = {"achieved": round(byts / mean_s / 1e9, 1), "frac": round(byts / mean_s / HBM_PEAK_BPS, 4), "avg_us": round(mean_s * 1e6, 2),
+             "median_us": round(med_s * 1e6, 2), "launches": launches, "alg_bytes_per_launch": int(byts), "rois": rois}
+        t = traffic.get(tkey) if tkey else None
+        r["traffic"] = t["hbm_bytes"] if t else None
+        return r
+
+    def single(boxes, ind, cold, tkey=None):
         bx, bi = torch.from_numpy(boxes).to(dev), torch.from_numpy(ind).to(dev)
-        mean_s, med_s = _time_op(lambda: _roi_align_impl.crop_backward(g, bx, bi, shape), launches)
-        rec = {"achieved": round(alg / mean_s / 1e9, 1), "frac": round(alg / mean_s / HBM_PEAK_BPS, 4), "avg_us": round(mean_s * 1e6, 2),
-               "median_us": round(med_s * 1e6, 2), "launches": launches, "alg_bytes_per_launch": int(alg), "mean_rois_on_level": float(n)}
-        t = traffic.get(key)
-        rec["traffic"] = t["hbm_bytes"] if t else None
-        return rec
 
-    head = case(tb, ti, "trainlike_48_rois")
-    variants = {"survey_8d_random_boxes_random_box_ind": case(rb, ri, "random_48_rois")}
+        def fn():
+            state["k"] += 1
+            _roi_align_impl.crop_backward(g, bx, bi, shape, out=rot[state["k"] % n_rot if cold else 0])
+        return rec_of(*_time_op(fn, launches), alg, n, tkey)
+
+    def pyramid(cold):
+        bx, bi, lv = torch.from_numpy(pb).to(dev), torch.from_numpy(pi).to(dev), torch.from_numpy(pl).to(dev)
+
+        def fn():
+            state["k"] += 1
+            _roi_align_impl.pyramid_backward(g, bx, bi, lv, shapes, outs=rot_pyr[state["k"] % n_rot if cold else 0])
+        return rec_of(*_time_op(fn, launches), alg_pyr, n)
+
+    head = single(rb, ri, False, "survey_random_48_rois")
+    variants = {
+        "P2_survey_8d_random_boxes_cache_cold": single(rb, ri, True),
+        "P2_train_realistic_placement": single(tb, ti, False, "trainlike_48_rois"),
+        "P2_train_realistic_placement_cache_cold": single(tb, ti, True),
+        "all_four_levels_one_launch_48_rois": pyramid(False),
+        "all_four_levels_one_launch_48_rois_cache_cold": pyramid(True),
+    }
     # the op as it ran inside the timed steps: ONE launch for all four pyramid levels (mdt_pyramid_roi_align_backward), so
-    # the algorithmic bytes are the four gradient maps + the pooled gradients of the RoIs the level rule kept
+    # the algorithmic bytes are the four gradient maps + the pooled gradients of the RoIs the level rule kept; fresh output
+    # maps from the allocator after 50 ms of convolutions: cache-cold by construction
     recs = [(a.elapsed_time(b) * 1e-3, m) for a, b, m in (in_step_prof or []) if m.get("mode") == "pyramid" and m["crop"] == crop]
     if recs:
         maps_bytes = 4.0 * sum(int(np.prod(sh)) for sh in recs[0][1]["levels"])
@@ -166,13 +213,15 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
         variants["in_training_step_all_levels_one_launch"] = {
             "achieved": round(float(np.mean(byts)) / dur / 1e9, 1), "frac": round(float(np.mean(byts)) / dur / HBM_PEAK_BPS, 4),
             "avg_us": round(dur * 1e6, 2), "launches": len(recs), "alg_bytes_per_launch": int(np.mean(byts)),
-            "mean_rois": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
+            "rois": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
     out = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": head["frac"], "traffic": head["traffic"],
-           "traffic_source": "profiles/r02_pmc/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this op, tools/gpu_pmc.sh)" if head["traffic"] else None,
-           "kernel": "crop_bwd_territory_kernel (mdt_crop_and_resize_3d_backward): P2 %s, pool %s, %d RoIs forced onto the level, "
-                     "train-realistic placement (%d per batch element)" % ("x".join(map(str, shape)), "x".join(map(str, crop)), n, cf.train_rois_per_image),
+           "traffic_source": ("OFFLINE measurement, not part of this run: profiles/r03_pmc/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes "
+                              "of this op, tools/gpu_pmc.sh)") if head["traffic"] else None,
+           "kernel": "crop_bwd_gather_kernel (mdt_crop_and_resize_3d_backward, csrc/roi_align_bwd_v3.hip): P2 %s, pool %s, %d RoIs on the level, "
+                     "SURVEY 8(d) box distribution, cache-warm" % ("x".join(map(str, shape)), "x".join(map(str, crop)), n),
            "alg_bytes_per_launch": head["alg_bytes_per_launch"], "avg_us": head["avg_us"], "median_us": head["median_us"], "launches": launches,
-           "mean_rois_on_level": head["mean_rois_on_level"], "variants": variants}
+           "timing": "HIP events around every launch on the launch stream; adds ~2 us over the kernel's own duration (profiles/r03_* rocprofv3 stats)",
+           "variants": variants}
     return out
 
 
@@ -193,6 +242,38 @@ def _self_launch(n):
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
     raise SystemExit(subprocess.call(cmd))
+
+
+def secondary_configs(timeout_s=240):
+    """BASELINE configs 2 and 5 under the same clock as the headline line: each runs in its OWN process with a
+    timeout (a cold MIOpen find for their layer shapes must never hold the headline line back), results parsed from the
+    child's JSON line.  config 2: LIDC-shape 3D Retina U-Net, 128^3, batch 8, 3 timed steps; config 5: one 512x512x256
+    volume, 75 patches, bf16, single pass, device-resident predictor (tools/bench_inference.py)."""
+    import subprocess
+    env = dict(os.environ)
+    env["MDT_MIOPEN_SKIP_NAIVE"] = "1"          # never let the find try the naive direct solvers on 128^3 decoder maps
+    out = {}
+    jobs = {
+        "config2_retina_unet_128_b8": [sys.executable, os.path.abspath(__file__), "--model", "retina_unet", "--steps", "3", "--warmup", "2",
+                                       "--no-cpu-baseline", "--no-h2d-leg", "--no-rccl-selftest", "--no-secondary", "--no-roofline"],
+        "config5_inference_512x512x256_bf16": [sys.executable, os.path.join(ROOT, "tools", "bench_inference.py"), "--amp", "bf16",
+                                               "--test-aug", "0", "--repeats", "1"],
+    }
+    for key, cmd in jobs.items():
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            rec = json.loads(lines[-1]) if lines else {"failed": "no JSON line; rc=%d; %s" % (r.returncode, r.stderr[-300:])}
+        except subprocess.TimeoutExpired:
+            rec = {"failed": "timeout after %d s (cold MIOpen find?)" % timeout_s}
+        except Exception as e:
+            rec = {"failed": repr(e)}
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "config", "patients_per_min", "patches_per_s", "s_per_patient", "n_patches",
+                "n_passes", "forwards", "raw_boxes", "boxes_after_wbc", "amp", "failed")
+        out[key] = {k: rec[k] for k in keep if k in rec}
+        out[key]["wall_s"] = round(time.time() - t0, 1)
+    return out
 
 
 def rccl_world1_selftest(net, opt, batch, dev, steps=3):
@@ -241,6 +322,8 @@ def main():
     ap.add_argument("--model", type=str, default="mrcnn", choices=["mrcnn", "retina_unet"],
                     help="mrcnn = BASELINE config 3 (headline); retina_unet = config 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 2 and 5 (run in child processes after the headline line is assembled, N = 1 only)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the RoIAlign-backward roofline section (child runs of --secondary)")
     ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the world-size-1 RCCL self-test after the timed loop")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra host-batch steps after the timed loop (profiling runs)")
     ap.add_argument("--fused-adam", type=int, default=0)
@@ -360,7 +443,7 @@ def main():
                 "grad_buckets": (len(sync.bucket_range) if sync is not None and sync.flat is not None else None)}
 
     if rank == 0:
-        roofline = roialign_bwd_roofline(cf, args.batch, dev, prof)
+        roofline = None if args.no_roofline else roialign_bwd_roofline(cf, args.batch, dev, prof)
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.model == "mrcnn":
             try:
@@ -384,6 +467,13 @@ def main():
                 out["distributed"]["rccl_world1_selftest"] = rccl_world1_selftest(net, opt, pool[0] if not args.host_batches else to_device(pool[0], dev), dev)
             except Exception as e:   # reported, never fatal for the bench line
                 out["distributed"]["rccl_world1_selftest"] = {"failed": repr(e)}
+        if world == 1 and not args.no_secondary and args.model == "mrcnn":
+            try:
+                del net, opt, pool
+                torch.cuda.empty_cache()
+                out["secondary"] = secondary_configs()
+            except Exception as e:
+                out["secondary"] = {"failed": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

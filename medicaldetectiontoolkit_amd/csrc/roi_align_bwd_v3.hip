@@ -7,31 +7,39 @@
 // rounding (test bar 2e-6 * sum|terms|; north-star bar 1e-4).  The exact-order form lives in roi_align.hip.
 //
 // Why a third form.  Round 2's territory kernel (roi_align_bwd.hip) hides a 151 MB fill behind one scatter workgroup per
-// (batch element, channel) volume, but that workgroup's own dependency chain -- territory bitmap, prefix popcounts,
-// segment list, touched-index compaction, three sequential streaming passes, combine: ~20 LDS-latency-bound stages --
-// measured 22 us even on a level whose fill is nothing (P5 alone: 25 us; profiles/r03_probe1/), and 27-33 us with
-// large boxes: the scatter role, not the fill, was the critical path.  This kernel shortens the chain to
-//     1 global hop (boxes) -> sample tables -> 1 global hop (gradient blocks, LDS-DMA) -> 2 LDS passes -> fused
-//     z-pass + combine + store
-// with every stage a flat data-parallel loop (one work item per OUTPUT element, gathering the 1..P samples that touch
-// it), no bitmap / prefix / compaction on the scatter side, and dense (bounding-box) intermediate blocks.
+// (batch element, channel) volume, but that workgroup's own dependency chain measured 22 us even on a level whose fill is
+// nothing (P5 alone: 25 us; profiles/r03_probe1/) and 27-33 us with large boxes: the scatter role, not the fill, was the
+// critical path.  Stage stamps of a first item-per-thread rewrite (profiles/r03_bwd_gather/stage_stamps_v3a_*.jsonl) showed
+// why: the role is bound by INSTRUCTION ISSUE of a few lone waves (a wave retires ~1 instruction per 4-8 cycles and pays
+// ~100 cycles per dependent LDS hop; a warm instruction cache changes nothing), so per-lane searches, integer divisions and
+// sample-range loops cost microseconds each.  This kernel therefore runs every stage as WAVE-UNIFORM TASKS:
 //
-//   scatter role  one workgroup per (batch element b, channel c[, row slab]) for ALL pyramid levels: the RoIs of b are
-//                 listed once (box_ind == b), each with its level; per round the RoIs that fit the LDS budget are staged:
-//                   g[r,c] (global -> LDS by LDS-DMA)                                [py][px][pz]
-//                   pass y: one item per (RoI, iy, px, pz)  -> out1                   [iy][px][pz]
-//                   pass x: one item per (RoI, iy, ix, pz)  -> out2                   [iy][ix][pz]
-//                   final : one item per (RoI, iy, ix, 16-byte unit of the RoI's segment range): the item whose RoI is
-//                           the FIRST one covering the segment owns it, sums -- RoI ascending -- the z-contraction of
-//                           every staged RoI covering the unit and stores 16 bytes; later rounds (more RoIs on one
-//                           element than fit LDS) read-modify-write.
-//                 Levels whose (b, c) volume is small (<= 64 KB) have no zero role: the scatter workgroup also stores
-//                 the zeros of its volume outside the territory (after its scatter work, fire-and-forget).
+//   scatter role  one workgroup per (batch element b, channel c) for ALL pyramid levels:
+//                   list   the RoIs of b (box_ind == b), ascending, with level and index bounding box: ONE global round
+//                          trip, four lanes per RoI (one axis each);
+//                   plan   (one wave, one lane per RoI) which RoIs fit the LDS pool this round, arena offsets, task counts;
+//                   tables the gradient blocks g[r, c] start travelling global -> LDS by LDS-DMA; meanwhile one lane per
+//                          (RoI, sample) writes its two interpolation weights into dense tables Wy[q][iy], Wx[q][ix],
+//                          Wz[quad][pz][voxel] (4 consecutive outputs = one 16-byte LDS broadcast) and the sample band of
+//                          every 4-output chunk;
+//                   pass y task (RoI, 4 rows, 64 of the px*pz lanes):   out1[iy][px][pz] = sum_q Wy[q][iy] g[q][px][pz]
+//                   pass x task (RoI, 4 columns, 64 of the iy*pz lanes): out2[iy][ix][pz] = sum_q Wx[q][ix] out1[iy][q][pz]
+//                   final  task (RoI, 16-byte quad, 64 columns (iy, ix)): z-contraction of out2; the lowest staged RoI whose
+//                          segment box covers a quad-column owns it and adds -- RoI ascending -- every later staged RoI
+//                          covering it (weights stay wave-uniform: the quad is), then stores 16 bytes; RoIs of earlier
+//                          rounds (more RoIs on one element than fit LDS): read-modify-write.
+//                 Intermediate blocks are dense over the RoI's index bounding box (no touched-index compaction).
+//                 Levels whose (b, c) volume is small (<= 32 KB) have no zero role: the scatter workgroup also stores the
+//                 zeros of its volume outside the territory (after its scatter work, fire-and-forget).
 //   zero role     levels with large volumes (P2: 151 MB): persistent workgroups -- as many as stay resident beside the
 //                 scatter workgroups -- each streaming 16-byte zero stores over one contiguous run of rows, skipping the
 //                 territory segments through an LDS bitmap built for the batch elements its run touches.
 // Territory of (b, level) = segments (S = 8..32 contiguous floats) inside the index bounding box of any RoI of b on that
 // level; both roles derive it from `boxes` alone, so they write disjoint bytes and nothing orders them.
+//
+// Measured (rocprofv3, MI355X, 48 RoIs, pool (14,14,5); profiles/r03_bwd_gather/): P2 train-like 26.5 us (round 2: 28.9),
+// SURVEY 8(d) random boxes 29.5 us (43.3), all four levels in one launch 30.6-32 us (50.6); the scatter chain of one
+// workgroup is 15-20 us and hidden behind the fill (zero role alone: 24.9 us, 22.7 us without its box-load prologue).
 //
 // 2D maps are the 3D case with W = 1, pw = 1 (the singleton axis interpolates with weight exactly 1).
 // HBM-bound, no MFMA.  Algorithmic bytes per launch: 4*B*C*V per map (written once) + 4*N*C*P (grads once) + 28*N.
@@ -50,11 +58,6 @@ constexpr int V3_MAX_LEVELS = 5;
 constexpr int V3_LDS_CAP = 80 * 1024;  // gfx950: 160 KB per CU -> two workgroups resident per CU
 constexpr long long V3_MERGE_BYTES = 32 * 1024;   // volumes up to this size are zero-filled by their scatter workgroup
 constexpr int V3_LEV_BYTES = 512;      // head of the LDS carve: the level table (kernel arguments indexed dynamically would go through scratch)
-
-struct SEntry {                        // one sample of one axis
-    float lerp;
-    int lo;
-};
 
 struct V3Level {
     float *out;
@@ -83,7 +86,7 @@ struct V3Params {
     float inv_psum, inv_pd;            // 1 / psum, 1 / pd (division-free index math)
     int off_hdr, off_rbox, off_bb, off_misc;
     long long *ts;                     // tuning only (mdt_debug_bwd3): wall-clock stamps of scatter workgroup `dbg_wg`, or null
-    int dbg, dbg_wg;                   // tuning only: bit0 scatter role returns at once, bit1 zero role returns at once
+    int dbg, dbg_wg;                   // tuning only: bit0 scatter role returns at once, bit1 zero role returns at once, bit3 zero role skips its box loads
     V3Level lev[V3_MAX_LEVELS];
 };
 
@@ -96,14 +99,6 @@ __device__ __forceinline__ void axis_bounds(float a1, float a2, int L, int P, in
     const AxisEntry e1 = axis_entry(a1, a2, L, P, P - 1);
     lo = min(e0.lo, e1.lo);
     hi = max(entry_hi(e0), entry_hi(e1));
-}
-
-__device__ __forceinline__ float sweight(const SEntry e, int idx)
-{
-    float w = 0.0f;
-    if (e.lo == idx) w = 1.0f - e.lerp;
-    if (e.lerp > 0.0f && e.lo + 1 == idx) w = w + e.lerp;
-    return w;
 }
 
 // box row r -> per-axis (a1, a2): y = (b0, b2), x = (b1, b3), z = (b4, b5); 2D: y = (b0, b2), x = none, z = (b1, b3)
@@ -151,9 +146,9 @@ __device__ __forceinline__ void zero_role(const V3Params &p, const int li, const
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
-    V3Level *slev = stage_levels(p, smem_raw);
-    __syncthreads();
-    const V3Level lv = slev[li];
+    V3Level lv = p.lev[0];
+#pragma unroll
+    for (int l = 1; l < V3_MAX_LEVELS; ++l) if (l == li) lv = p.lev[l];     // static indices: the table stays in scalar registers
     const long long total_rows = (long long)p.B * p.C * lv.R;
     const long long g0 = (long long)zi * lv.rows_per_part;
     long long g1 = g0 + lv.rows_per_part;
@@ -169,7 +164,7 @@ __device__ __forceinline__ void zero_role(const V3Params &p, const int li, const
     for (int t = tid; t < nb * lv.bw; t += V3_NT) bm[t] = 0ULL;
     if (tid == 0) *ncand = 0;
     __syncthreads();
-    if (tid < p.N) {
+    if (tid < p.N && !(p.dbg & 8)) {       // (dbg bit 3, tuning only: no territory -> what the bitmap prologue costs)
         const int r = tid;
         const int bi = p.box_ind[r];
         const int l = p.level ? p.level[r] : 0;
@@ -250,6 +245,24 @@ __device__ __forceinline__ int task_owner(const int *tp, int ng, int T, int lane
 {
     const int e = (lane < ng) ? tp[lane + 1] : 0x7fffffff;
     return __popcll(__ballot(T >= e));
+}
+
+// acc += sum_pz Wz[pz][0..3] * o2[pz], pz ascending; loads of four samples issued together
+__device__ __forceinline__ v4f zdot(v4f acc, const float *o2, const float *Wz, int pd)
+{
+    for (int pz = 0; pz < pd; pz += 4) {
+        float v1[4];
+        v4f w4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int qq = min(pz + u, pd - 1);
+            v1[u] = (pz + u < pd) ? o2[qq] : 0.0f;
+            w4[u] = *reinterpret_cast<const v4f *>(Wz + qq * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = acc + w4[u] * v1[u];
+    }
+    return acc;
 }
 
 __device__ __forceinline__ void scatter_role(const V3Params &p, const unsigned bid, const int stamp_base)
@@ -492,10 +505,19 @@ __device__ __forceinline__ void scatter_role(const V3Params &p, const unsigned b
                 const float *g = pool + ufl(h[8]) + (act ? rest : 0);
                 const float *Wy = W + chunk * 4;
                 v4f acc = {0.f, 0.f, 0.f, 0.f};
-                for (int q = qlo; q < qhi; ++q) {
-                    const float gv = g[q * ppd];
-                    const v4f w4 = *reinterpret_cast<const v4f *>(Wy + q * ny4);
-                    acc = acc + w4 * gv;
+                // four samples per trip: all eight LDS loads are issued before the first use (a dependent LDS hop costs ~100
+                // cycles and a wave has nothing else to overlap it with); trips past the band multiply by a zero value
+                for (int q = qlo; q < qhi; q += 4) {
+                    float gv[4];
+                    v4f w4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int qq = min(q + u, qhi - 1);
+                        gv[u] = (q + u < qhi) ? g[qq * ppd] : 0.0f;
+                        w4[u] = *reinterpret_cast<const v4f *>(Wy + qq * ny4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = acc + w4[u] * gv[u];
                 }
                 if (act) {
                     float *o = pool + ufl(h[9]) + chunk * 4 * ppd + rest;
@@ -528,10 +550,17 @@ __device__ __forceinline__ void scatter_role(const V3Params &p, const unsigned b
                 const float *o1 = pool + ufl(h[9]) + iy * ppd + pz;
                 const float *Wx = W + p.ph * ny4 + chunk * 4;
                 v4f acc = {0.f, 0.f, 0.f, 0.f};
-                for (int q = qlo; q < qhi; ++q) {
-                    const float ov = o1[q * p.pd];
-                    const v4f w4 = *reinterpret_cast<const v4f *>(Wx + q * nx4);
-                    acc = acc + w4 * ov;
+                for (int q = qlo; q < qhi; q += 4) {
+                    float ov[4];
+                    v4f w4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int qq = min(q + u, qhi - 1);
+                        ov[u] = (q + u < qhi) ? o1[qq * p.pd] : 0.0f;
+                        w4[u] = *reinterpret_cast<const v4f *>(Wx + qq * nx4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = acc + w4[u] * ov[u];
                 }
                 if (act) {
                     float *o = pool + ufl(h[8]) + (iy * nx + chunk * 4) * p.pd + pz;
@@ -567,13 +596,14 @@ __device__ __forceinline__ void scatter_role(const V3Params &p, const unsigned b
                 const bool shared = ufl(h[13]) != 0;
                 bool rmw = false;
                 if (shared) {
-                    for (int k = 0; k < g0 + j; ++k) {
+                    const int ssh = ufl(lv.S_shift);
+#pragma unroll 4
+                    for (int k = 0; k < g0 + j; ++k) {            // branch-free: the bb reads of consecutive k overlap
                         const int4 q = bb[k];                       // same address in every lane
-                        if ((q.w & 127) != lvi || !(q.w & 128)) continue;
-                        if (sg < ((q.z & 0xffff) >> lv.S_shift) || sg > ((q.z >> 16) >> lv.S_shift)) continue;
-                        const bool in = y >= (q.x & 0xffff) && y <= (q.x >> 16) && x >= (q.y & 0xffff) && x <= (q.y >> 16);
-                        if (k >= g0) act = act && !in;
-                        else rmw = rmw || in;
+                        const bool rel = ((q.w & 255) == (lvi | 128)) && sg >= ((q.z & 0xffff) >> ssh) && sg <= ((q.z >> 16) >> ssh);
+                        const bool in = rel && y >= (q.x & 0xffff) && y <= (q.x >> 16) && x >= (q.y & 0xffff) && x <= (q.y >> 16);
+                        act = act && !(in && k >= g0);
+                        rmw = rmw || (in && k < g0);
                     }
                     if (__ballot(act) == 0ULL) continue;
                 }
@@ -586,30 +616,23 @@ __device__ __forceinline__ void scatter_role(const V3Params &p, const unsigned b
                 {
                     const float *o2 = pool + ufl(h[8]) + (act ? col : 0) * p.pd;
                     const float *Wz = pool + ufl(h[10]) + p.ph * ufl(h[11]) + p.pw * ufl(h[12]) + quad * p.pd * 4;
-                    for (int pz = 0; pz < p.pd; ++pz) {
-                        const float v1 = o2[pz];
-                        const v4f w4 = *reinterpret_cast<const v4f *>(Wz + pz * 4);
-                        acc = acc + w4 * v1;
-                    }
+                    acc = zdot(acc, o2, Wz, p.pd);
                 }
                 if (shared) {
                     for (int jk = j + 1; jk < ng; ++jk) {
-                        const int *hk = hdr + jk * V3_HDRN;
-                        if (ufl(hk[1]) != lvi || ufl(hk[13]) == 0) continue;
-                        const int qk = Q - ufl(hk[6]);
-                        if (qk < 0 || qk >= ufl(hk[7])) continue;
-                        const int yk = y - ufl(hk[2]), xk = x - ufl(hk[4]);
-                        const int nxk = ufl(hk[5]);
-                        const bool in = act && yk >= 0 && yk < ufl(hk[3]) && xk >= 0 && xk < nxk;
+                        const int4 *hk4 = reinterpret_cast<const int4 *>(hdr + jk * V3_HDRN);
+                        const int4 ha = hk4[0], hb = hk4[1], hc = hk4[2], hd = hk4[3];      // one LDS round trip for the header
+                        if (ufl(ha.y) != lvi || ufl(hd.y) == 0) continue;
+                        const int qk = Q - ufl(hb.z);
+                        if (qk < 0 || qk >= ufl(hb.w)) continue;
+                        const int yk = y - ufl(ha.z), xk = x - ufl(hb.x);
+                        const int nxk = ufl(hb.y);
+                        const bool in = act && yk >= 0 && yk < ufl(ha.w) && xk >= 0 && xk < nxk;
                         if (__ballot(in) == 0ULL) continue;
-                        const float *o2 = pool + ufl(hk[8]) + (in ? (yk * nxk + xk) : 0) * p.pd;
-                        const float *Wz = pool + ufl(hk[10]) + p.ph * ufl(hk[11]) + p.pw * ufl(hk[12]) + qk * p.pd * 4;
-                        v4f s4 = {0.f, 0.f, 0.f, 0.f};
-                        for (int pz = 0; pz < p.pd; ++pz) {
-                            const float v1 = o2[pz];
-                            const v4f w4 = *reinterpret_cast<const v4f *>(Wz + pz * 4);
-                            s4 = s4 + w4 * v1;
-                        }
+                        const float *o2 = pool + ufl(hc.x) + (in ? (yk * nxk + xk) : 0) * p.pd;
+                        const float *Wz = pool + ufl(hc.z) + p.ph * ufl(hc.w) + p.pw * ufl(hd.x) + qk * p.pd * 4;
+                        const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+                        const v4f s4 = zdot(zero4, o2, Wz, p.pd);
                         if (in) acc = acc + s4;
                     }
                 }

@@ -85,9 +85,11 @@ def _workspace(nbytes, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
-def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False):
-    """grads [N, C, *crop] -> grad_image of shape im_size; fully written by the kernel(s).
-    mode: "fast" (default: single-launch territory kernel, csrc/roi_align_bwd.hip), "twophase" (round-1 separable
+def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False, out=None):
+    """grads [N, C, *crop] -> grad_image of shape im_size; fully written by the kernel(s) (`out`: write into this
+    contiguous fp32 tensor instead of a fresh one -- cache-cold timing rotates several).
+    mode: "fast" (default: single-launch gather-form kernel, csrc/roi_align_bwd_v3.hip; MDT_BWD_KERNEL=r2 selects the
+    round-2 territory kernel csrc/roi_align_bwd.hip for A/B), "twophase" (round-1 separable
     two-kernel form, A/B and fallback for shapes beyond the LDS budgets), "ordered" (bit-exact vs the sequential
     oracle), "atomic" (reference algorithm, A/B only)."""
     if atomic:
@@ -98,7 +100,12 @@ def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False):
     if grads.dtype != torch.float32:
         grads = grads.float()
     n = grads.size(0)
-    grad_image = torch.empty(tuple(im_size), dtype=torch.float32, device=grads.device)
+    if out is not None:
+        if tuple(out.shape) != tuple(im_size) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous fp32 tensor of shape im_size")
+        grad_image = out
+    else:
+        grad_image = torch.empty(tuple(im_size), dtype=torch.float32, device=grads.device)
     if grad_image.numel() == 0:
         return grad_image
     crop = tuple(grads.shape[2:])
@@ -220,9 +227,9 @@ def pyramid_forward(maps, boxes, batch_ix, level, crop):
     return crops
 
 
-def pyramid_backward(grads, boxes, batch_ix, level, shapes):
+def pyramid_backward(grads, boxes, batch_ix, level, shapes, outs=None):
     """grads [N, C, *crop] -> list of grad maps (one per level, fully written).  One launch when every level fits the
-    single-launch kernel, else one default backward per level (box_ind = -1 off-level)."""
+    single-launch kernel, else one default backward per level (box_ind = -1 off-level).  `outs`: write into these maps."""
     dim = len(shapes[0]) - 2
     L = _lib.lib()
     grads = grads.contiguous()
@@ -232,7 +239,10 @@ def pyramid_backward(grads, boxes, batch_ix, level, shapes):
     n = grads.size(0)
     if n == 0:
         return [torch.zeros(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
-    outs = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    if outs is None:
+        outs = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    else:
+        outs = list(outs)
     crop = tuple(grads.shape[2:])
     H, W, D = _level_dims(shapes, dim)
     prof = PROFILE

@@ -530,8 +530,9 @@ class net(nn.Module):
         return self.anchors_f64.cpu().numpy()
 
     # ------------------------------------------------------------------ forward passes
-    def forward(self, img, is_training=True):
-        """mrcnn.py:987-1050."""
+    def forward(self, img, is_training=True, with_masks=True):
+        """mrcnn.py:987-1050.  with_masks=False skips the mask head over the detections (the reference always runs it and
+        drops the result when return_masks is off, mrcnn.py:1046-1048 / :984): box-only inference."""
         cf = self.cf
         B = img.shape[0]
         if self.memory_format is not None:
@@ -563,8 +564,10 @@ class net(nn.Module):
         detection_boxes = detections[:, :dim * 2 + 1] / scale
         detection_boxes = torch.cat([detection_boxes[:, :dim * 2],
                                      torch.where(det_valid, detection_boxes[:, dim * 2], torch.full_like(detection_boxes[:, dim * 2], -1.0)).unsqueeze(1)], 1)
-        with torch.no_grad():
-            detection_masks = self.mask(self.mrcnn_feature_maps, detection_boxes)
+        detection_masks = None
+        if with_masks:
+            with torch.no_grad():
+                detection_masks = self.mask(self.mrcnn_feature_maps, detection_boxes)
         return [rpn_pred_logits, rpn_pred_deltas, batch_proposal_boxes, detections, det_valid, detection_masks]
 
     def loss_samples_forward(self, batch_gt_class_ids, batch_gt_boxes, batch_gt_masks, B, gt_dev=None):
@@ -600,7 +603,10 @@ class net(nn.Module):
         # waits for the stream afterwards, so the host keeps running ahead of the GPU through the glue
         gt_dev = GtOnDevice(gt_boxes, gt_class_ids, cf.dim, dev)
 
-        rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(img)
+        # the mask head over the detections only feeds the validation read-out (return_masks, :949): not run for a training
+        # step (the reference runs it and drops the result)
+        rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(
+            img, with_masks=bool(is_validation and cf.return_masks_in_val))
         (mrcnn_class_logits, mrcnn_pred_deltas, mrcnn_pred_mask, target_class_ids, mrcnn_target_deltas, target_mask,
          sample_proposals, s_valid, s_pos) = self.loss_samples_forward(gt_class_ids, gt_boxes, gt_masks, B, gt_dev=gt_dev)
 
@@ -625,7 +631,12 @@ class net(nn.Module):
             mrcnn_mask_loss = torch.zeros((), device=dev)
         loss = batch_rpn_class_loss + batch_rpn_bbox_loss + mrcnn_class_loss + mrcnn_bbox_loss + mrcnn_mask_loss
 
-        results_dict = {"torch_loss": loss}
+        # the five terms of mrcnn.py:946 as device scalars (no read-out here): what the assembled-step parity test compares
+        results_dict = {"torch_loss": loss,
+                        "loss_terms": {"rpn_class": batch_rpn_class_loss.detach(), "rpn_bbox": batch_rpn_bbox_loss.detach(),
+                                       "mrcnn_class": mrcnn_class_loss.detach(), "mrcnn_bbox": mrcnn_bbox_loss.detach(),
+                                       "mrcnn_mask": mrcnn_mask_loss.detach()},
+                        "sample_counts": (s_valid.sum(), s_pos.sum())}
         if monitor:
             box_results_list = [[] for _ in range(B)]
             for b in range(B):
@@ -664,5 +675,20 @@ class net(nn.Module):
         img = batch["data"]
         img = torch.from_numpy(np.ascontiguousarray(img)).to(self.device_).float() if not torch.is_tensor(img) else img.to(self.device_).float()
         with torch.no_grad():
-            _, _, _, detections, det_valid, detection_masks = self.forward(img, is_training=False)
+            _, _, _, detections, det_valid, detection_masks = self.forward(img, is_training=False, with_masks=return_masks)
         return get_results(self.cf, img.shape, detections, det_valid, detection_masks, return_masks=return_masks)
+
+    def test_forward_detections(self, img):
+        """test_forward without leaving the device (patch-tiled inference, predictor.collect_raw_boxes): img [B, C, *patch]
+        device tensor -> (rows [B * M, 2 * dim + 3] float32 = box (y1, x1, y2, x2, (z1, z2)) truncated to integers like
+        get_results (:467), batch_ix, class id, score; keep [B * M] bool = real detection with positive extent, :470-474).
+        Rows are element-major in detection order -- the order get_results emits box dicts in.  No mask head, no read-out."""
+        with torch.no_grad():
+            img = img.to(self.device_).float()
+            _, _, _, det, det_valid, _ = self.forward(img, is_training=False, with_masks=False)
+            dim = self.cf.dim
+            boxes = det[:, :2 * dim].to(torch.int32).float()
+            ext = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+            if dim == 3:
+                ext = ext * (boxes[:, 5] - boxes[:, 4])
+            return torch.cat([boxes, det[:, 2 * dim:]], 1), det_valid & (ext > 0)

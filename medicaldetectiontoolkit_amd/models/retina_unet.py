@@ -206,7 +206,8 @@ class net(nn.Module):
             matches.append(m)
             argmaxes.append(am)
         batch_class_loss, batch_bbox_loss, samples = compute_rpn_losses(
-            torch.stack(matches), torch.stack(argmaxes), class_logits, pred_deltas, self.anchors_f64, gt_boxes, cf, shem_poolsize=20,
+            torch.stack(matches), torch.stack(argmaxes), class_logits, pred_deltas, self.anchors_f64, gt_boxes, cf,
+            shem_poolsize=getattr(cf, "retina_shem_poolsize", 20),      # the reference calls compute_class_loss with its default 20 (retina_unet.py:432)
             gt_dev=gt_dev)
         loss = batch_class_loss + batch_bbox_loss
         seg_dice = seg_ce = None
@@ -216,7 +217,10 @@ class net(nn.Module):
             seg_dice = 1 - batch_dice(F.softmax(seg_logits, dim=1), ohe)
             seg_ce = F.cross_entropy(seg_logits, var_seg[:, 0])
             loss = loss + (seg_dice + seg_ce) / 2
-        results_dict = {"torch_loss": loss}
+        results_dict = {"torch_loss": loss,
+                        "loss_terms": {"class": batch_class_loss.detach(), "bbox": batch_bbox_loss.detach(),
+                                       "seg_dice": None if seg_dice is None else seg_dice.detach(),
+                                       "seg_ce": None if seg_ce is None else seg_ce.detach()}}
         if monitor:
             box_results_list = [[] for _ in range(B)]
             for b in range(B):
@@ -245,3 +249,17 @@ class net(nn.Module):
         with torch.no_grad():
             detections, det_valid, _, _, seg_logits = self.forward(img)
         return get_results(self.cf, img.shape, detections, det_valid, seg_logits)
+
+    def test_forward_detections(self, img):
+        """test_forward without leaving the device (predictor.collect_raw_boxes): (rows [B * M, 2 * dim + 3] = integer box,
+        batch_ix, class id, score; keep = real detection, positive extent, score >= model_min_confidence, :291-300)"""
+        with torch.no_grad():
+            img = img.to(self.device_).float()
+            det, det_valid, _, _, _ = self.forward(img)
+            dim = self.cf.dim
+            boxes = det[:, :2 * dim].to(torch.int32).float()
+            ext = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+            if dim == 3:
+                ext = ext * (boxes[:, 5] - boxes[:, 4])
+            keep = det_valid & (ext > 0) & (det[:, 2 * dim + 2] >= self.cf.model_min_confidence)
+            return torch.cat([boxes, det[:, 2 * dim:]], 1), keep

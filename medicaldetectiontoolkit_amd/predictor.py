@@ -110,14 +110,85 @@ def box_patch_center_factor(box_coords, patch_size):
     return float(np.mean([np.exp(-0.5 * ((bc - pc) / (pc * 0.8)) ** 2) for bc, pc in zip(centres, half)]))
 
 
-def _forward_patches(net, data, coords, chunk_ids, cf, amp_dtype, with_seg):
-    patches = np.stack([data[:, coords[p][0]:coords[p][1], coords[p][2]:coords[p][3], coords[p][4]:coords[p][5]] for p in chunk_ids])
-    batch = {"data": np.ascontiguousarray(patches, dtype=np.float32)}
+def _axis_cover_prefix(intervals, extent):
+    """prefix sums P[i] = sum_{k < i} cover[k] of the number of [lo, hi) intervals covering index k along one axis"""
+    cover = np.zeros(extent + 1, dtype=np.int64)
+    for lo, hi in intervals:
+        cover[lo] += 1
+        cover[hi] -= 1
+    cover = np.cumsum(cover)[:extent]
+    return np.concatenate([[0], np.cumsum(cover)])
+
+
+def _python_slice_bounds(start, stop, extent):
+    """vectorised slice(start, stop).indices(extent): negative values wrap once, everything is clamped to [0, extent]"""
+    a = np.where(start < 0, start + extent, start)
+    b = np.where(stop < 0, stop + extent, stop)
+    return np.clip(a, 0, extent), np.clip(b, 0, extent)
+
+
+def box_n_overlaps(int_coords, crop_coords, spatial):
+    """predictor.py:432-434 for all boxes at once.  The reference builds the patch-overlap map of the pass (:392-401) and takes
+    np.mean(map[ic[1]:ic[3], ic[0]:ic[2], ic[4]:ic[5]]) per box -- the y axis sliced with the x coordinates and vice versa,
+    negative starts wrapping like any numpy slice, NaN when the slice is empty.  The patches are a
+    cartesian product of per-axis intervals (dataloader_utils.get_patch_crop_coords), so the map is the outer product of
+    three per-axis cover counts and a box mean is (sum_y)(sum_x)(sum_z) / (n_y n_x n_z) from three prefix tables: exact integer
+    sums, the same float64 quotient np.mean forms.  int_coords [n, 6] int64 (floor / ceil already applied)."""
+    c = np.asarray(int_coords, dtype=np.int64).reshape(-1, 6)
+    axes = [np.unique(crop_coords[:, 2 * a:2 * a + 2], axis=0) for a in range(3)]
+    if len(axes[0]) * len(axes[1]) * len(axes[2]) != crop_coords.shape[0]:      # not a product grid: the literal map
+        overlap = np.zeros(spatial, dtype=np.uint8)
+        for pc in crop_coords:
+            overlap[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += 1
+        out = np.empty(c.shape[0])
+        for i, ic in enumerate(c):
+            region = overlap[ic[1]:ic[3], ic[0]:ic[2], ic[4]:ic[5]]
+            out[i] = float(np.mean(region)) if region.size else float("nan")
+        return out
+    prefix = [_axis_cover_prefix(axes[a], spatial[a]) for a in range(3)]
+    num = np.ones(c.shape[0], dtype=np.int64)
+    den = np.ones(c.shape[0], dtype=np.int64)
+    for axis, (s_col, e_col) in enumerate(((1, 3), (0, 2), (4, 5))):                 # axis 0 is sliced with the x columns
+        a, b = _python_slice_bounds(c[:, s_col], c[:, e_col], spatial[axis])
+        n = np.maximum(b - a, 0)
+        num *= np.where(n > 0, prefix[axis][np.maximum(b, a)] - prefix[axis][a], 0)
+        den *= n
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(den > 0, num.astype(np.float64) / den.astype(np.float64), np.nan)
+
+
+def box_patch_center_factors(coords, patch_size):
+    """box_patch_center_factor for [n, 2 * dim] patch-frame boxes at once"""
+    c = np.asarray(coords, dtype=np.float64).reshape(-1, 2 * len(patch_size))
+    dim = len(patch_size)
+    centres = [(c[:, 0] + c[:, 2]) / 2, (c[:, 1] + c[:, 3]) / 2] + ([(c[:, 4] + c[:, 5]) / 2] if dim == 3 else [])
+    half = np.asarray(patch_size, dtype=np.float64) / 2
+    return np.mean([np.exp(-0.5 * ((bc - pc) / (pc * 0.8)) ** 2) for bc, pc in zip(centres, half)], axis=0)
+
+
+def _patch_tensor(vol_t, pc, fy, fx):
+    """patch `pc` (crop coordinates in the MIRRORED frame of the pass) of the device-resident volume [C, Y, X, Z]: the
+    mirrored volume is never materialised -- the patch is cut from the original at the mirrored-back coordinates and flipped"""
+    Y, X = vol_t.shape[1], vol_t.shape[2]
+    y0, y1 = (Y - pc[1], Y - pc[0]) if fy else (pc[0], pc[1])
+    x0, x1 = (X - pc[3], X - pc[2]) if fx else (pc[2], pc[3])
+    p = vol_t[:, y0:y1, x0:x1, pc[4]:pc[5]]
+    dims = ([1] if fy else []) + ([2] if fx else [])
+    return p.flip(dims) if dims else p
+
+
+def _forward_chunk_dicts(net, batch_t, amp_dtype):
+    """generic nets (anything with test_forward): box dicts per chunk -> (boxes [n, 6], batch_ix, class, score) numpy"""
+    batch = {"data": batch_t}
     kw = {"return_masks": False} if "return_masks" in net.test_forward.__code__.co_varnames else {}
     if amp_dtype is not None:
         with torch.autocast("cuda", dtype=amp_dtype):
-            return net.test_forward(batch, **kw)
-    return net.test_forward(batch, **kw)
+            res = net.test_forward(batch, **kw)
+    else:
+        res = net.test_forward(batch, **kw)
+    rows = [list(np.asarray(box["box_coords"], dtype=np.float64)) + [float(k), float(box["box_pred_class_id"]), float(box["box_score"])]
+            for k, bl in enumerate(res["boxes"]) for box in bl if box["box_type"] == "det"]
+    return np.asarray(rows, dtype=np.float64).reshape(-1, 9), res
 
 
 def collect_raw_boxes(net, data, cf, amp_dtype=None, rank_ix="0", test_aug=False, with_seg=False):
@@ -125,73 +196,107 @@ def collect_raw_boxes(net, data, cf, amp_dtype=None, rank_ix="0", test_aug=False
     (raw_boxes, info) where raw_boxes is the reference's per-patient box-dict list in patient coordinates, each det
     carrying 'patch_id' = "<rank_ix>_<aug>_<patch>", 'box_patch_center_factor' and 'box_n_overlaps'
     (this is what the reference pickles as raw_pred_boxes_list, predictor.py:192-194).  Patches (x mirrored passes)
-    are sharded round-robin over ranks and the rows all_gathered."""
+    are sharded round-robin over ranks and the rows all_gathered.
+
+    Device-resident: the volume goes up ONCE, patches (and their mirrored versions) are cut on the device, nets that offer
+    `test_forward_detections` keep their detections on the device through all chunks and passes (ONE read-out per patient),
+    and patch-centre factor / overlap count / un-mirroring are computed for all boxes at once; box dicts are built at the end."""
     from . import distributed as mdist
     from .utils.dataloader_utils import get_patch_crop_coords
     dim = cf.dim
     assert dim == 3, "patch-tiled 3D prediction (2D slices go through merge_2D_to_3D_preds_per_patient)"
     dev = net.device_
+    vol_t = data.to(dev) if torch.is_tensor(data) else torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
     # volumes smaller than the training patch are edge-padded to it, the surplus split low//2 | rest like
     # dataloader_utils.pad_nd_image (experiments/lidc_exp/data_loader.py:346-349); like the reference, predictions
     # stay in the PADDED frame (info["pad_below"] lets a caller shift them back)
     pad_below = [0, 0, 0]
-    if any(data.shape[d + 1] < cf.patch_size[d] for d in range(3)):
-        diff = [max(cf.patch_size[d] - data.shape[d + 1], 0) for d in range(3)]
+    if any(vol_t.shape[d + 1] < cf.patch_size[d] for d in range(3)):
+        diff = [max(cf.patch_size[d] - vol_t.shape[d + 1], 0) for d in range(3)]
         pad_below = [v // 2 for v in diff]
-        data = np.pad(data, [(0, 0)] + [(v // 2, v // 2 + v % 2) for v in diff], mode="edge")
-    spatial = data.shape[1:]
+        pads = []
+        for v in reversed(diff):                      # F.pad lists the last axis first
+            pads += [v // 2, v // 2 + v % 2]
+        vol_t = torch.nn.functional.pad(vol_t[None], pads, mode="replicate")[0]
+    spatial = tuple(int(v) for v in vol_t.shape[1:])
     Y, X = spatial[0], spatial[1]
     coords = get_patch_crop_coords(np.zeros(spatial, dtype=np.uint8), cf.patch_size)
     n_patches = coords.shape[0]
     augs = [(False, False)] + ([(True, False), (False, True), (True, True)] if test_aug else [])
     items = [(a, p) for a in range(len(augs)) for p in range(n_patches)]
     mine = [items[i] for i in mdist.shard_indices(len(items))]
-    rows = []
-    overlap0 = None
+    fast = hasattr(net, "test_forward_detections") and not with_seg
+    dev_rows, dev_keep, host_rows, row_pass, row_patch = [], [], [], [], []
+    pass_coords = []
     seg_sum = np.zeros(spatial, dtype=np.float32) if with_seg else None
     for a, (fy, fx) in enumerate(augs):
         ids = [p for (aa, p) in mine if aa == a]
-        d = data
         c_a = coords.copy()
         if fy:      # mirrored image + mirrored crop coordinates (get_mirrored_patch_crops, predictor.py:777-816)
-            d = d[:, ::-1]
             c_a[:, 0], c_a[:, 1] = Y - coords[:, 1], Y - coords[:, 0]
         if fx:
-            d = d[:, :, ::-1]
             c_a[:, 2], c_a[:, 3] = X - coords[:, 3], X - coords[:, 2]
-        # patches covering each voxel, in the frame of THIS pass (spatial_tiling_forward builds it per call, :392-401)
-        overlap = np.zeros(spatial, dtype=np.uint8)
-        for pc in c_a:
-            overlap[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += 1
-        if a == 0:
-            overlap0 = overlap
+        pass_coords.append(c_a)
         for i in range(0, len(ids), cf.batch_size):
             chunk = ids[i:i + cf.batch_size]
-            res = _forward_patches(net, d, c_a, chunk, cf, amp_dtype, with_seg)
-            for k, p in enumerate(chunk):
-                pc = c_a[p]
+            batch_t = torch.stack([_patch_tensor(vol_t, c_a[p], fy, fx) for p in chunk])
+            if fast:
+                if amp_dtype is not None:
+                    with torch.autocast("cuda", dtype=amp_dtype):
+                        rows, keep = net.test_forward_detections(batch_t)
+                else:
+                    rows, keep = net.test_forward_detections(batch_t)
+                dev_rows.append(rows)
+                dev_keep.append(keep)
+                per = rows.shape[0] // len(chunk)                       # M rows per batch element, element-major
+                row_pass += [a] * rows.shape[0]
+                row_patch += [p for p in chunk for _ in range(per)]
+            else:
+                rows, res = _forward_chunk_dicts(net, batch_t, amp_dtype)
+                host_rows.append(rows)
+                row_pass += [a] * rows.shape[0]
+                row_patch += [chunk[int(k)] for k in rows[:, 6]]
                 if with_seg and a == 0:
-                    seg_sum[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += res["seg_preds"][k][0]
-                for box in res["boxes"][k]:
-                    if box["box_type"] != "det":
-                        continue
-                    c = np.asarray(box["box_coords"], dtype=np.float64)
-                    fac = box_patch_center_factor(c, cf.patch_size)
-                    c = c + np.array([pc[0], pc[2], pc[0], pc[2], pc[4], pc[4]])
-                    # overlap count under the box, evaluated in the (possibly mirrored) frame of the pass BEFORE the box is
-                    # mirrored back.  The reference slices the y axis with the x coordinates and vice versa, lets numpy
-                    # wrap negative starts and takes np.mean of what is left -- NaN when the slice is empty, which happens
-                    # on non-square volumes (predictor.py:432-434, SURVEY quirk 5).  Reproduced literally.
-                    ic = [int(np.floor(v)) if ix % 2 == 0 else int(np.ceil(v)) for ix, v in enumerate(c)]
-                    region = overlap[ic[1]:ic[3], ic[0]:ic[2], ic[4]:ic[5]]
-                    n_ov = float(np.mean(region)) if region.size else float("nan")
-                    if fy:
-                        c[0], c[2] = Y - c[2], Y - c[0]
-                    if fx:
-                        c[1], c[3] = X - c[3], X - c[1]
-                    rows.append(list(c) + [float(box["box_score"]), float(box["box_pred_class_id"]), fac, float(a * n_patches + p), n_ov])
-    local = torch.tensor(rows, dtype=torch.float64, device=dev).view(-1, 11)
-    allrows = mdist.gather_rows(local).cpu().numpy()
+                    for k, p in enumerate(chunk):
+                        pc = c_a[p]
+                        seg_sum[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += np.asarray(res["seg_preds"][k][0], dtype=np.float32)
+    row_pass, row_patch = np.asarray(row_pass, dtype=np.int64), np.asarray(row_patch, dtype=np.int64)
+    if fast:
+        if dev_rows:
+            det = torch.cat(dev_rows).double().cpu().numpy()                # the one read-out of the patient
+            keep = torch.cat(dev_keep).cpu().numpy()
+            det, row_pass, row_patch = det[keep], row_pass[keep], row_patch[keep]
+        else:
+            det = np.zeros((0, 9))
+    else:
+        det = np.concatenate(host_rows, 0) if host_rows else np.zeros((0, 9))
+    # ---- all boxes at once: centre factor in the patch frame, shift to the (mirrored) patient frame, overlap count, un-mirror
+    local = np.zeros((det.shape[0], 11), dtype=np.float64)
+    if det.shape[0]:
+        c = det[:, :6].copy()
+        fac = box_patch_center_factors(c, cf.patch_size)
+        n_ov = np.empty(det.shape[0])
+        for a, (fy, fx) in enumerate(augs):
+            sel = np.nonzero(row_pass == a)[0]
+            if sel.size == 0:
+                continue
+            pc = pass_coords[a][row_patch[sel]]
+            c[sel] += pc[:, [0, 2, 0, 2, 4, 4]]
+            ic = c[sel].copy()
+            ic[:, [0, 1, 4]] = np.floor(ic[:, [0, 1, 4]])
+            ic[:, [2, 3, 5]] = np.ceil(ic[:, [2, 3, 5]])
+            n_ov[sel] = box_n_overlaps(ic.astype(np.int64), pass_coords[a], spatial)       # in the frame of the pass, BEFORE un-mirroring
+            if fy:
+                c[sel, 0], c[sel, 2] = Y - c[sel, 2], Y - c[sel, 0]
+            if fx:
+                c[sel, 1], c[sel, 3] = X - c[sel, 3], X - c[sel, 1]
+        local[:, :6] = c
+        local[:, 6] = det[:, 8]                      # score
+        local[:, 7] = det[:, 7]                      # class id
+        local[:, 8] = fac
+        local[:, 9] = row_pass * n_patches + row_patch
+        local[:, 10] = n_ov
+    allrows = mdist.gather_rows(torch.from_numpy(local).to(dev)).cpu().numpy() if mdist.world()[1] > 1 else local
     raw = []
     for r in allrows:
         q = int(r[9])
@@ -200,6 +305,9 @@ def collect_raw_boxes(net, data, cf, amp_dtype=None, rank_ix="0", test_aug=False
                     "box_n_overlaps": float(r[10])})
     info = {"n_patches": n_patches, "n_passes": len(augs), "pad_below": pad_below, "padded_shape": tuple(spatial)}
     if with_seg:
+        overlap0 = np.zeros(spatial, dtype=np.uint8)
+        for pc in coords:
+            overlap0[pc[0]:pc[1], pc[2]:pc[3], pc[4]:pc[5]] += 1
         m = overlap0 > 0
         seg_sum[m] /= overlap0[m]
         info["seg_preds"] = seg_sum[None, None]

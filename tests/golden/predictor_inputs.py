@@ -54,8 +54,24 @@ class CannedNet(object):
                         "box_score": float(rng.uniform(0.1, 0.99)), "box_pred_class_id": int(rng.integers(1, 3))})
         return out
 
+    def test_forward_detections(self, img):
+        """the device-resident interface of the real nets (models/mrcnn.py test_forward_detections): rows [B * M, 9] =
+        integer box, batch_ix, class id, score (float64 here so that the canned scores survive bit for bit); keep [B * M]"""
+        import torch
+        self.calls += 1
+        data = img.detach().cpu().numpy()
+        M = 4
+        rows = np.zeros((data.shape[0] * M, 9), dtype=np.float64)
+        keep = np.zeros(data.shape[0] * M, dtype=bool)
+        for i in range(data.shape[0]):
+            for k, b in enumerate(self.boxes_for(*self._identify(data[i]))):
+                rows[i * M + k] = list(b["box_coords"]) + [i, b["box_pred_class_id"], b["box_score"]]
+                keep[i * M + k] = True
+        return torch.from_numpy(rows).to(img.device), torch.from_numpy(keep).to(img.device)
+
     def test_forward(self, batch, **kwargs):
         self.calls += 1
-        data = np.asarray(batch["data"])
+        data = batch["data"]
+        data = data.detach().cpu().numpy() if hasattr(data, "detach") else np.asarray(data)
         boxes = [self.boxes_for(*self._identify(data[i])) for i in range(data.shape[0])]
         return {"boxes": boxes, "seg_preds": np.zeros((data.shape[0], 1) + tuple(data.shape[2:]), dtype=np.uint8)}

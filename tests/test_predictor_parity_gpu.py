@@ -35,10 +35,18 @@ def _table(boxes):
 
 
 @pytest.mark.gpu
-def test_collect_raw_boxes_and_wbc_vs_reference(cuda):
+@pytest.mark.parametrize("path", ["device_rows", "box_dicts"])
+def test_collect_raw_boxes_and_wbc_vs_reference(path, cuda):
+    """both feeds of collect_raw_boxes: detections kept on the device through all chunks (test_forward_detections, one
+    read-out per patient) and the generic box-dict interface (test_forward)"""
     from medicaldetectiontoolkit_amd import predictor
     cf = pi.make_cf()
     net = pi.CannedNet(device=cuda)
+    if path == "box_dicts":
+        class DictOnly(object):       # a net that only offers the reference's test_forward
+            device_ = net.device_
+            test_forward = staticmethod(net.test_forward)
+        net = DictOnly()
     raw, info = predictor.collect_raw_boxes(net, pi.make_volume(), cf, test_aug=True)
     assert info["n_patches"] == G["patch_crop_coords"].shape[0] and info["n_passes"] == 4
     got, want = _table(raw), G["raw_table"]

@@ -1,14 +1,16 @@
 #!/bin/bash
-# rocprofv3 kernel trace of a short bench.py run + steady-state breakdown -> gpurun_out/r02_step_steady_state.csv
+# rocprofv3 kernel trace of a short bench.py run + steady-state breakdown -> gpurun_out/${OUT_NAME:-r03_step_steady_state}.csv
+# env: BENCH_ARGS (e.g. "--model retina_unet"), OUT_NAME
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 STEPS=${1:-5}
+BENCH_ARGS=${BENCH_ARGS:-}
 mkdir -p $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $ROOT/gpurun_out/prof_step
-timeout ${2:-420} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_step -o step -- python $ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-h2d-leg > $ROOT/gpurun_out/prof_step.log 2>&1 < /dev/null
+timeout ${2:-420} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_step -o step -- python $ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-h2d-leg --no-rccl-selftest $BENCH_ARGS > $ROOT/gpurun_out/prof_step.log 2>&1 < /dev/null
 LINE=$(grep '^{"metric"' $ROOT/gpurun_out/prof_step.log | tail -1)
 echo "$LINE" | cut -c1-300
 MS=$(echo "$LINE" | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
 T=$(find $ROOT/gpurun_out/prof_step -name "*kernel_trace.csv" | head -1)
-python $ROOT/tools/steady_state.py "$T" $STEPS $MS $ROOT/gpurun_out/r02_step_steady_state.csv
+python $ROOT/tools/steady_state.py "$T" $STEPS $MS $ROOT/gpurun_out/${OUT_NAME:-r03_step_steady_state}.csv
 rm -rf $ROOT/gpurun_out/prof_step

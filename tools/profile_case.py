@@ -40,6 +40,9 @@ fns = {
     "nms6000": lambda: _nms_impl.nms_sorted(ds, 0.7, 3),
     "nms6000_keep75": lambda: _nms_impl.nms_sorted(ds, 0.7, 3, max_keep=75),
 }
+if os.environ.get("MDT_BWD3_DBG"):       # role switches of the gather-form backward (include/mdt_hip.h mdt_debug_bwd3)
+    from medicaldetectiontoolkit_amd import _lib
+    _lib.lib().mdt_debug_bwd3(None, int(os.environ["MDT_BWD3_DBG"]), 0)
 if case == "pyramid_bwd":
     shapes = [(8, 36) + LEVELS[k] for k in ("P2", "P3", "P4", "P5")]
     per = []

@@ -1,8 +1,8 @@
 """Steady-state kernel breakdown of the timed training steps from a rocprofv3 --kernel-trace csv of bench.py.
 
 usage: python tools/steady_state.py <*_kernel_trace.csv> <steps> <ms_per_step> [out.csv]
-The window ends at the first single-level crop_bwd_territory_kernel launch (bench.py's roofline measurement starts there:
-the training step itself only uses the multi-level kernel) and spans steps * ms_per_step before it."""
+The window ends at the last optimizer (multi_tensor_apply) kernel of the trace -- run bench.py with --no-h2d-leg
+--no-rccl-selftest so that the last Adam launch belongs to the last timed step -- and spans steps * ms_per_step before it."""
 import csv
 import re
 import sys
@@ -37,16 +37,10 @@ def main():
     path, steps, ms = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
     rows = list(csv.DictReader(open(path)))
     ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
-    ends = [s for s, e, n in ks if "crop_bwd_territory_kernel" in n]
-    if not ends:
-        raise SystemExit("no crop_bwd_territory_kernel launch in the trace")
-    t1 = ends[0]
-    # the last training kernel before the roofline section
-    t1 = max(e for s, e, n in ks if e <= t1)
-    # ... more precisely the last optimizer kernel of the last timed step (what follows is bench.py's own set-up work)
-    adam = [e for s, e, n in ks if e <= t1 and "multi_tensor_apply" in n]
-    if adam:
-        t1 = max(adam)
+    adam = [e for s, e, n in ks if "multi_tensor_apply" in n]
+    if not adam:
+        raise SystemExit("no optimizer (multi_tensor_apply) launch in the trace")
+    t1 = max(adam)
     t0 = t1 - int(steps * ms * 1e6)
     win = [(s, e, n) for s, e, n in ks if s >= t0 and e <= t1]
     busy, cur_s, cur_e = 0, None, None
