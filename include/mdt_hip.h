@@ -375,6 +375,15 @@ int mdt_nms_2to3d(const double *dets_sorted, int n, int n_slices, double thresh,
                   long long *keep, double *keep_z, int *num_out,
                   void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- 1x1(x1) convolution weight gradient (csrc/conv1x1_wgrad.hip) -------------------------------------------------------
+ * dW[co][ci] = sum_v grad_out[v][co] * x[v][ci] over the n_voxels rows of channels-last activations (what
+ * torch.ops.aten.convolution_backward(..., output_mask = [0, 1, 0]) returns for a 1x1(x1) convolution; the reference gets it
+ * from cuDNN through nn.Conv3d, utils/model_utils.py:751).  fp32 MFMA, deterministic (no atomics); workspace = per-workgroup
+ * partial sums.  MDT_ERR_UNSUPPORTED never occurs for c_out, c_in <= 4096. */
+size_t mdt_conv1x1_wgrad_workspace_bytes(long long n_voxels, int c_out, int c_in);
+int mdt_conv1x1_wgrad(const float *grad_out, const float *x, float *grad_weight, long long n_voxels, int c_out, int c_in,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,6 +116,46 @@ def flip_transpose_filter(w, mf):
     return wt.contiguous(memory_format=mf)
 
 
+WGRAD_1X1 = True   # module switch (A/B: bench.py --wgrad-1x1 0)
+
+
+def conv1x1_wgrad_pays(n_voxels, cout, cin):
+    """where the kernel beats MIOpen's backward-weights (tools/wgrad_probe.py, profiles/r03_wgrad_probe.jsonl): the few-channel
+    layers on the large maps -- 18 -> 72: 432 -> 154 us, 72 -> 18: 310 -> 154, 18 -> 18: 547 -> 59..87, 128 -> 18: 308 -> 178 on
+    8 x 32x32x128; 36 <-> 144 and 72 -> 36 on 8 x 16x16x64: 1.2-1.4x.  Many-tile layers (72 -> 36 on the large map re-reads one
+    operand per tile group) and the small maps (launch-bound) stay on MIOpen."""
+    tiles = ((cout + 31) // 32) * ((cin + 31) // 32)
+    if cout > 4096 or cin > 4096:
+        return False
+    return (tiles <= 4 and n_voxels >= 65536) or (tiles <= 10 and 65536 <= n_voxels <= 262144)
+
+
+def conv1x1_weight_grad(gy, x, w, force=False):
+    """Weight gradient of a 1x1(x1) unit-stride convolution on channels-last activations with the fp32-MFMA kernel of
+    csrc/conv1x1_wgrad.hip (MIOpen's backward-weights solvers take 310-434 us for the 18/72-channel layers on the 8 x 32x32x128
+    maps against a 47 us HBM floor).  None when the layer is not of that form (the caller then asks MIOpen)."""
+    if w.shape[2:].numel() != 1 or gy.dtype != torch.float32 or x.dtype != torch.float32 or not gy.is_cuda or not _on_current_device(gy):
+        return None
+    mf = torch.channels_last_3d if gy.dim() == 5 else torch.channels_last if gy.dim() == 4 else None
+    if mf is None or not x.is_contiguous(memory_format=mf):
+        return None
+    if not gy.is_contiguous(memory_format=mf):
+        gy = gy.contiguous(memory_format=mf)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    V = gy.numel() // cout
+    if not force and not conv1x1_wgrad_pays(V, cout, cin):
+        return None
+    L = _lib.lib()
+    wsb = L.mdt_conv1x1_wgrad_workspace_bytes(V, cout, cin)
+    ws = _workspace(wsb, gy.device)
+    gw = torch.empty((cout, cin), dtype=torch.float32, device=gy.device)
+    rc = L.mdt_conv1x1_wgrad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), V, cout, cin, ws.data_ptr(), ws.numel(),
+                             torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _lib.check(rc, "mdt_conv1x1_wgrad")
+    return gw.view(w.shape)
+
+
 class _ConvStride1(Function):
     """Unit-stride convolution whose input gradient is computed as a FORWARD convolution of the output gradient with the
     flipped, transposed filter (the textbook identity; same arithmetic up to fp32 summation order).  MIOpen's forward
@@ -140,8 +180,10 @@ class _ConvStride1(Function):
             pad_t = tuple(int(k) - 1 - int(p) for k, p in zip(w.shape[2:], ctx.padding))
             gx = (F.conv3d if nd == 3 else F.conv2d)(gy, flip_transpose_filter(w, mf), None, 1, pad_t)
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1] * nd, list(ctx.padding), [1] * nd, False, [0] * nd, 1,
-                                                     [False, True, False])[1]
+            gw = conv1x1_weight_grad(gy, x, w) if WGRAD_1X1 else None
+            if gw is None:
+                gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1] * nd, list(ctx.padding), [1] * nd, False, [0] * nd, 1,
+                                                         [False, True, False])[1]
         return gx, gw, None
 
 
