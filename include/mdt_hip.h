@@ -384,6 +384,14 @@ size_t mdt_conv1x1_wgrad_workspace_bytes(long long n_voxels, int c_out, int c_in
 int mdt_conv1x1_wgrad(const float *grad_out, const float *x, float *grad_weight, long long n_voxels, int c_out, int c_in,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- linear x2 up-sampling of (y, x) on channels-last storage (csrc/upsample.hip) -------------------------------------------
+ * F.interpolate(x, scale_factor=(2, 2, 1), mode='trilinear', align_corners=False) on a channels_last_3d tensor (the decoder's
+ * P2 -> P1 -> P0 path, models/backbone.py:209-217 Interpolate) and scale 2 'bilinear' on channels_last 2D maps: the tensor
+ * is [batch, Y, X, inner] with inner = Z * C (3D) or C (2D); out is [batch, 2Y, 2X, inner].  The backward is the exact
+ * adjoint in gather form (deterministic). */
+int mdt_upsample2x_yx_cl_forward(const float *in, float *out, long long batch, int Y, int X, long long inner, void *stream);
+int mdt_upsample2x_yx_cl_backward(const float *grad_out, float *grad_in, long long batch, int Y, int X, long long inner, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -312,3 +312,50 @@ class MaxPool3dStem(nn.MaxPool3d):
 
 def _t3(v):
     return tuple(int(a) for a in v) if isinstance(v, (tuple, list)) else (int(v),) * 3
+
+
+UPSAMPLE_CL = True   # module switch (A/B: bench.py --upsample-cl 0)
+
+
+class _Upsample2xYX(Function):
+    """x2 linear up-sampling of (y, x) on channels-last storage (csrc/upsample.hip)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        nd = x.dim() - 2
+        B, C, Y, X = int(x.shape[0]), int(x.shape[1]), int(x.shape[2]), int(x.shape[3])
+        Z = int(x.shape[4]) if nd == 3 else 1
+        mf = torch.channels_last_3d if nd == 3 else torch.channels_last
+        shape = (B, C, 2 * Y, 2 * X) + ((Z,) if nd == 3 else ())
+        y = torch.empty(shape, dtype=torch.float32, device=x.device, memory_format=mf)
+        rc = _lib.lib().mdt_upsample2x_yx_cl_forward(x.data_ptr(), y.data_ptr(), B, Y, X, Z * C, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "mdt_upsample2x_yx_cl_forward")
+        ctx.dims = (B, C, Y, X, Z, nd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, Y, X, Z, nd = ctx.dims
+        mf = torch.channels_last_3d if nd == 3 else torch.channels_last
+        if not gy.is_contiguous(memory_format=mf):
+            gy = gy.contiguous(memory_format=mf)
+        gx = torch.empty((B, C, Y, X) + ((Z,) if nd == 3 else ()), dtype=torch.float32, device=gy.device, memory_format=mf)
+        rc = _lib.lib().mdt_upsample2x_yx_cl_backward(gy.data_ptr(), gx.data_ptr(), B, Y, X, Z * C, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "mdt_upsample2x_yx_cl_backward")
+        return gx
+
+
+def upsample2x_yx(x, scale_factor, mode):
+    """F.interpolate(x, scale_factor, mode, align_corners=False) through the channels-last kernel when it is the decoder's
+    form -- 'trilinear' with scale (2, 2, 1) on a channels_last_3d fp32 GPU tensor, or 'bilinear' with scale 2 on a
+    channels_last one (C > 1) -- else None (the caller uses torch)."""
+    if not (UPSAMPLE_CL and x.is_cuda and x.dtype == torch.float32 and x.shape[1] > 1 and _on_current_device(x)):
+        return None
+    sf = tuple(float(v) for v in scale_factor) if isinstance(scale_factor, (tuple, list)) else (float(scale_factor),) * (x.dim() - 2)
+    if x.dim() == 5 and mode == "trilinear" and sf == (2.0, 2.0, 1.0) and x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous():
+        return _Upsample2xYX.apply(x)
+    if x.dim() == 4 and mode == "bilinear" and sf == (2.0, 2.0) and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        return _Upsample2xYX.apply(x)
+    return None

@@ -214,3 +214,32 @@ def test_conv1x1_wgrad_inside_autograd_matches_miopen(cuda):
         scale = float(grads[1][0].abs().max())
         assert float((grads[0][0] - grads[1][0]).abs().max()) <= 1e-4 * scale
         assert torch.allclose(grads[0][1], grads[1][1])
+
+
+# ------------------------------------------------------------------ x2 (y, x) linear up-sampling on channels-last storage
+@pytest.mark.parametrize("case", [(2, 36, (8, 12, 16), "trilinear"), (1, 5, (3, 4, 7), "trilinear"), (2, 18, (1, 6, 8), "trilinear"),
+                                  (2, 48, (10, 14), "bilinear"), (1, 3, (5, 1), "bilinear")])
+def test_upsample2x_channels_last_matches_interpolate(case, cuda):
+    """csrc/upsample.hip == F.interpolate(scale (2, 2, 1) 'trilinear' / scale 2 'bilinear', align_corners=False), forward 1e-6 and
+    the backward (gather-form adjoint) against torch's autograd; deterministic"""
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    B, C, sp, mode = case
+    nd = len(sp)
+    mf = torch.channels_last_3d if nd == 3 else torch.channels_last
+    sf = (2, 2, 1) if nd == 3 else 2
+    g = torch.Generator(device=cuda).manual_seed(C)
+    x = torch.randn((B, C) + sp, device=cuda, generator=g).contiguous(memory_format=mf).requires_grad_(True)
+    y = fe.upsample2x_yx(x, sf, mode)
+    assert y is not None and y.is_contiguous(memory_format=mf)
+    xr = x.detach().clone().requires_grad_(True)
+    want = F.interpolate(xr, scale_factor=sf, mode=mode, align_corners=False)
+    assert y.shape == want.shape
+    assert torch.allclose(y, want, rtol=1e-6, atol=1e-6), float((y - want).abs().max())
+    go = torch.randn(want.shape, device=cuda, generator=g)
+    y.backward(go.contiguous(memory_format=mf))
+    want.backward(go)
+    assert torch.allclose(x.grad, xr.grad, rtol=1e-5, atol=1e-5), float((x.grad - xr.grad).abs().max())
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = fe.upsample2x_yx(x2, sf, mode)
+    y2.backward(go.contiguous(memory_format=mf))
+    assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad)
