@@ -194,6 +194,16 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
             _roi_align_impl.pyramid_backward(g, bx, bi, lv, shapes, outs=rot_pyr[state["k"] % n_rot if cold else 0])
         return rec_of(*_time_op(fn, launches), alg_pyr, n)
 
+    def plain_fill(cold):
+        """calibration: what a bare 151 MB fill (torch's fill kernel, no RoIs, no skip logic) does under the same protocol"""
+        def fn():
+            state["k"] += 1
+            rot[state["k"] % n_rot if cold else 0].zero_()
+        mean_s, med_s = _time_op(fn, launches)
+        byts = 4.0 * batch * cf.end_filts * V
+        return {"achieved": round(byts / mean_s / 1e9, 1), "frac": round(byts / mean_s / HBM_PEAK_BPS, 4), "avg_us": round(mean_s * 1e6, 2),
+                "median_us": round(med_s * 1e6, 2), "launches": launches, "bytes": int(byts)}
+
     head = single(rb, ri, False, "survey_random_48_rois")
     variants = {
         "P2_survey_8d_random_boxes_cache_cold": single(rb, ri, True),
@@ -201,6 +211,8 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
         "P2_train_realistic_placement_cache_cold": single(tb, ti, True),
         "all_four_levels_one_launch_48_rois": pyramid(False),
         "all_four_levels_one_launch_48_rois_cache_cold": pyramid(True),
+        "calibration_torch_zero_fill_151MB": plain_fill(False),
+        "calibration_torch_zero_fill_151MB_cache_cold": plain_fill(True),
     }
     # the op as it ran inside the timed steps: ONE launch for all four pyramid levels (mdt_pyramid_roi_align_backward), so
     # the algorithmic bytes are the four gradient maps + the pooled gradients of the RoIs the level rule kept; fresh output
@@ -331,6 +343,7 @@ def main():
     ap.add_argument("--conv-bwd-as-fwd", type=int, default=1, help="1 (default): input gradients of unit-stride convolutions as forward convolutions (utils/fused_epilogue._ConvStride1); 0: MIOpen backward-data (A/B)")
     ap.add_argument("--stem-s2d", type=int, default=1, help="1 (default): stem convolution forward in space-to-depth form (utils/fused_epilogue._ConvStem221); 0: as is (A/B)")
     ap.add_argument("--wgrad-1x1", type=int, default=1, help="1 (default): weight gradients of the 1x1x1 convolutions with the fp32-MFMA kernel (csrc/conv1x1_wgrad.hip); 0: MIOpen backward-weights (A/B)")
+    ap.add_argument("--head-as-linear", type=int, default=1, help="1 (default): the classifier head's full-extent / 1x1x1 convolutions as GEMMs (models/mrcnn.py Classifier); 0: MIOpen convolutions (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
     ap.add_argument("--pool-cl", type=int, default=1, help="1 (default): channels-last max pooling kernel of the stem (csrc/pool.hip); 0: torch (A/B)")
     ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
@@ -379,6 +392,7 @@ def main():
     from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
     from medicaldetectiontoolkit_amd.models import mrcnn, retina_unet
     from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch, to_device
+    mrcnn.HEAD_AS_LINEAR = bool(args.head_as_linear)
 
     # MIOpen's immediate-mode heuristics pick naive 3D solvers for the 18/36/72-channel convolutions of this
     # backbone (3.2 s per step); the exhaustive find selects im2col+GEMM / CK kernels (42x faster, profiles/).

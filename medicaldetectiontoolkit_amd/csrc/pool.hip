@@ -5,8 +5,8 @@
 //     costs a full layout copy in, an NCDHW kernel (0.55 ms forward, 0.86 ms backward with atomics at 8 x 18 x 64 x 64 x 128)
 //     and a transpose back in front of the next convolution.  Here: one thread per (voxel, channel) on the channels-last
 //     storage (consecutive lanes = consecutive channels, then z: fully coalesced), the 27 window reads are served by
-//     L1/L2; the arg-max tap (0..26) is kept as one byte per output; the backward is a GATHER over the <= 12 windows
-//     containing a voxel -- no atomics, fixed summation order, deterministic.  Tie / NaN rule of torch
+//     L1/L2; the arg-max tap (0..26) is kept as one byte per output; the backward is a GATHER (one thread per 2 x 2 input
+//     block over the 12 windows that can contain it) -- no atomics, fixed summation order, deterministic.  Tie / NaN rule of torch
 //     (first maximum in (y, x, z) scan order, NaN wins) is reproduced.
 //     Algorithmic bytes: forward 4*V_in + 5*V_out, backward 5*V_out + 4*V_in  (V = B*C*voxels).  HBM-bound, no MFMA.
 // (2) mdt_filter_flip_transpose: w[co][ci][taps] -> w'[ci][co][reversed taps] in one launch (either memory order); feeds the
@@ -85,40 +85,63 @@ __global__ __launch_bounds__(PL_THREADS) void maxpool_k3s221_cl_fwd_kernel(const
     }
 }
 
-// grid: x covers one input row segment (x, z, c), y walks the (b, y) rows
+// One thread per 2 x 2 (y, x) block of inputs at one (z, c): the 2 x 2 x 3 windows that can contain any of the four are read
+// ONCE (12 arg bytes + 12 gradients, all independent loads) and each window's gradient goes to the one input its arg-max tap
+// names -- a quarter of the window reads of a thread-per-input gather and 4 stores per thread.  Per input the windows are
+// still visited in (oy, ox, oz) ascending order: same sums, bit for bit, as the thread-per-input form.
+// grid: x covers one row segment (ox', z, c) of 2 x 2 blocks, y walks the (b, oy') block rows
 __global__ __launch_bounds__(PL_THREADS) void maxpool_k3s221_cl_bwd_kernel(const float *__restrict__ gy, const unsigned char *__restrict__ arg,
                                                                             float *__restrict__ gx, int rows,
                                                                             int Y, int X, int Z, int C, int OY, int OX)
 {
-    const unsigned row_len = (unsigned)X * Z * C;
+    const int BX = (X + 1) / 2, BY = (Y + 1) / 2;
+    const unsigned row_len = (unsigned)BX * Z * C;
     const unsigned j = blockIdx.x * PL_THREADS + threadIdx.x;
     if (j >= row_len) return;
     const unsigned c = j % (unsigned)C;
     const unsigned t = j / (unsigned)C;
     const int z = (int)(t % (unsigned)Z);
-    const int xx = (int)(t / (unsigned)Z);
+    const int bx = (int)(t / (unsigned)Z);
     const unsigned zc = (unsigned)Z * C;
-    const int ox_lo = xx / 2, ox_hi = min((xx + 1) / 2, OX - 1);
     const int oz_lo = max(z - 1, 0), oz_hi = min(z + 1, Z - 1);
     for (int r = blockIdx.y; r < rows; r += gridDim.y) {
-        const int yy = r % Y;
-        const long long b = r / Y;
+        const int by = r % BY;
+        const long long b = r / BY;
         const long long ob = b * (long long)OY * OX * zc + c;
-        float acc = 0.0f;
-        const int oy_hi = min((yy + 1) / 2, OY - 1);
-        for (int oy = yy / 2; oy <= oy_hi; ++oy) {
-            const int dy = yy - (2 * oy - 1);
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                const int dx = xx - (2 * ox - 1);
+        float a00 = 0.0f, a01 = 0.0f, a10 = 0.0f, a11 = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = by + a;
+            if (oy >= OY) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ox = bx + e;
+                if (ox >= OX) continue;
                 const long long base = ob + ((long long)oy * OX + ox) * zc;
                 for (int oz = oz_lo; oz <= oz_hi; ++oz) {
-                    const int tap = dy * 9 + dx * 3 + (z - oz + 1);
                     const long long o = base + (unsigned)oz * C;
-                    if ((int)arg[o] == tap) acc = acc + gy[o];
+                    const int tap = (int)arg[o];
+                    const float g = gy[o];
+                    const int dy = tap / 9, rem = tap - dy * 9;
+                    const int dx = rem / 3, dz = rem - dx * 3;
+                    const int iy = 2 * a - 1 + dy, ix = 2 * e - 1 + dx;       // position inside the 2 x 2 block
+                    if (oz - 1 + dz == z) {
+                        if (iy == 0 && ix == 0) a00 = a00 + g;
+                        if (iy == 0 && ix == 1) a01 = a01 + g;
+                        if (iy == 1 && ix == 0) a10 = a10 + g;
+                        if (iy == 1 && ix == 1) a11 = a11 + g;
+                    }
                 }
             }
         }
-        gx[(long long)r * row_len + j] = acc;
+        const long long ib = b * (long long)Y * X * zc + (unsigned)z * C + c;
+        const int y0 = 2 * by, x0 = 2 * bx;
+        gx[ib + ((long long)y0 * X + x0) * zc] = a00;
+        if (x0 + 1 < X) gx[ib + ((long long)y0 * X + x0 + 1) * zc] = a01;
+        if (y0 + 1 < Y) {
+            gx[ib + ((long long)(y0 + 1) * X + x0) * zc] = a10;
+            if (x0 + 1 < X) gx[ib + ((long long)(y0 + 1) * X + x0 + 1) * zc] = a11;
+        }
     }
 }
 
@@ -167,7 +190,7 @@ int mdt_maxpool3d_k3s221_cl_backward(const float *gy, const unsigned char *argma
 {
     if (batch < 0 || Y <= 0 || X <= 0 || Z <= 0 || channels <= 0) return MDT_ERR_INVALID_ARGUMENT;
     const int OY = (Y - 1) / 2 + 1, OX = (X - 1) / 2 + 1;
-    const long long row_len = (long long)X * Z * channels, rows = (long long)batch * Y;
+    const long long row_len = (long long)((X + 1) / 2) * Z * channels, rows = (long long)batch * ((Y + 1) / 2);
     if (rows == 0) return MDT_OK;
     if (row_len > 0x3fffffffLL || rows > 0x7fffffffLL) return MDT_ERR_UNSUPPORTED;
     (void)hipGetLastError();

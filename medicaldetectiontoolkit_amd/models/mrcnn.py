@@ -25,6 +25,7 @@ from ..cuda_functions import _nms_impl
 from ..cuda_functions._roi_align_impl import pyramid_crop_and_resize
 from ..cuda_functions.roi_align_2D.roi_align.crop_and_resize import CropAndResizeFunction as ra2D
 from ..cuda_functions.roi_align_3D.roi_align.crop_and_resize import CropAndResizeFunction as ra3D
+from ..utils import fused_epilogue
 from ..utils import model_utils as mutils
 from . import backbone as backbone_module
 
@@ -32,6 +33,9 @@ from . import backbone as backbone_module
 ############################################################
 # Networks on top of backbone (state_dict-compatible with the reference)
 ############################################################
+HEAD_AS_LINEAR = True    # module switch (A/B: bench.py --head-as-linear 0): classifier-head convolutions as matrix products
+
+
 class RPN(nn.Module):
     """Region Proposal Network (mrcnn.py:40-86)."""
 
@@ -88,7 +92,16 @@ class Classifier(nn.Module):
 
     def _forward(self, x, rois):
         x = pyramid_roi_align(x, rois, self.pool_size, self.pyramid_levels, self.dim)
-        x = self.conv2(self.conv1(x))
+        if HEAD_AS_LINEAR and isinstance(self.conv1, fused_epilogue.ConvBiasReLU) and isinstance(self.conv2, fused_epilogue.ConvBiasReLU) \
+                and tuple(self.conv1[0].kernel_size) == tuple(x.shape[2:]) and not any(self.conv1[0].padding):
+            # conv1's kernel IS the pooled extent (mrcnn.py:104) and conv2 is 1x1(x1) on a single voxel: both are matrix products
+            # [n, C * ph * pw * pd] x [.., 4C] -- MIOpen's convolution kernels take 1.2 ms for conv1's backward on 48 RoIs
+            # (tools/op_profile.py), the GEMM path microseconds.  Same sums up to fp32 order; weights keep their conv shape.
+            c1, c2 = self.conv1[0], self.conv2[0]
+            x = F.relu(F.linear(x.flatten(1), c1.weight.flatten(1), c1.bias))
+            x = F.relu(F.linear(x, c2.weight.flatten(1), c2.bias))
+        else:
+            x = self.conv2(self.conv1(x))
         x = x.view(-1, self.in_channels * 4)
         mrcnn_class_logits = self.linear_class(x)
         mrcnn_bbox = self.linear_bbox(x)

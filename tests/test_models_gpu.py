@@ -164,3 +164,33 @@ def test_predict_test_set_ensembling_and_raw_pickle(cuda, tmp_path):
     assert members <= {"0", "1"}
     for b in raw[0][0][0]:
         assert {"box_coords", "box_score", "box_pred_class_id", "patch_id", "box_patch_center_factor", "box_n_overlaps"} <= set(b)
+
+
+def test_classifier_head_as_linear_equals_conv_path(cuda):
+    """Classifier head: conv1 (kernel = pooled extent) and conv2 (1x1x1) as matrix products == the convolution path, forward
+    and parameter gradients (models/mrcnn.py HEAD_AS_LINEAR)"""
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from medicaldetectiontoolkit_amd.models import mrcnn
+    from medicaldetectiontoolkit_amd.utils.model_utils import NDConvGenerator
+    cf = Configs(dim=3, model="mrcnn", patch_size=[64, 64, 32], batch_size=2)
+    torch.manual_seed(3)
+    head = mrcnn.Classifier(cf, NDConvGenerator(3)).to(cuda)
+    maps = [torch.randn((2, cf.end_filts) + tuple(int(v) for v in s), device=cuda) for s in cf.backbone_shapes]
+    g = torch.Generator(device=cuda).manual_seed(4)
+    lo = torch.rand((20, 3), device=cuda, generator=g) * 0.6
+    ext = 0.1 + 0.3 * torch.rand((20, 3), device=cuda, generator=g)
+    rois = torch.stack([lo[:, 0], lo[:, 1], lo[:, 0] + ext[:, 0], lo[:, 1] + ext[:, 1], lo[:, 2], lo[:, 2] + ext[:, 2],
+                        torch.randint(0, 2, (20,), device=cuda, generator=g).float()], 1)
+    outs, grads = [], []
+    for flag in (True, False):
+        mrcnn.HEAD_AS_LINEAR = flag
+        head.zero_grad()
+        logits, boxes = head(maps, rois)
+        (logits.square().sum() + boxes.square().sum()).backward()
+        outs.append((logits.detach().clone(), boxes.detach().clone()))
+        grads.append([p.grad.detach().clone() for p in head.parameters()])
+    mrcnn.HEAD_AS_LINEAR = True
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
+    for a, b in zip(grads[0], grads[1]):
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-3, atol=1e-4 * float(b.abs().max()) + 1e-6), float((a - b).abs().max())
