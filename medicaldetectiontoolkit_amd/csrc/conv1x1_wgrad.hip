@@ -9,7 +9,7 @@
 // that instruction is one element per lane, lane l <-> (channel l & 31, voxel l >> 5): with channels-last rows a wave's load
 // IS the fragment (two 128-byte runs), so operands go global -> VGPR -> MFMA with no LDS staging and no transposes.  Lanes
 // beyond the channel count read a clamped (valid) address: they only feed rows / columns of the tile that are never stored.
-// 16 voxels (8 K-steps) of loads are issued before the first MFMA of a trip.
+// 8 voxels (4 K-steps) of loads form a trip; two operand register sets keep the next trip's loads in flight under the MFMAs.
 // Reduction: the 4 waves of a workgroup add their tiles through LDS in wave order, every workgroup writes one [Cout][Cin]
 // partial, and a second small kernel adds the partials in a fixed order -- deterministic, no atomics.
 //
@@ -25,7 +25,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int W_THREADS = 256;       // 4 waves per workgroup
-constexpr int W_UNROLL = 8;          // K-steps (of 2 voxels) whose loads are in flight together
+constexpr int W_UNROLL = 4;          // K-steps (of 2 voxels) per trip; two trips' operands are live (double buffering)
 constexpr int W_MAX_TILES = 4;       // 32 x 32 accumulator tiles per wave (64 VGPRs)
 
 // MT x NT tiles per wave: rows = output channels (dY), columns = input channels (X)
@@ -35,22 +35,22 @@ __global__ __launch_bounds__(W_THREADS) void conv1x1_wgrad_partial_kernel(const 
                                                                         int groups_n)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [4 waves][MT * NT][1024]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: block addresses stay in SGPRs
     const int gm = blockIdx.y / groups_n, gn = blockIdx.y - gm * groups_n;
     const int co0 = gm * MT * 32, ci0 = gn * NT * 32;
-    // block-cyclic split of the voxels: trip t of wave w takes the 16 voxels [(t * n_waves + w) * 16, +16), so at any moment all
+    // block-cyclic split of the voxels: trip t of wave w takes the 8 voxels [(t * n_waves + w) * 8, +8), so at any moment all
     // waves of the chip read ONE contiguous window (a private contiguous chunk per wave makes 2048 waves advance in lockstep
     // at a fixed 147 KB stride: 1.4 TB/s, HBM channel camping)
     const long long wave_id = (long long)blockIdx.x * (W_THREADS / 64) + wave;
     const long long n_waves = (long long)gridDim.x * (W_THREADS / 64);
-    const long long n_blocks = V / (2 * W_UNROLL);                 // full 16-voxel blocks
+    const long long n_blocks = V / (2 * W_UNROLL);                 // full blocks of 2 * W_UNROLL voxels
     const int ch = lane & 31, kk = lane >> 5;
-    const float *pa[MT];
-    const float *pb[NT];
+    // per-lane 32-bit offsets inside a 2-voxel K-step (channel clamped: see the header); the K-step's base address is wave-uniform
+    unsigned offa[MT], offb[NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) pa[m] = dY + min(co0 + 32 * m + ch, Cout - 1);      // clamped: see the header
+    for (int m = 0; m < MT; ++m) offa[m] = (unsigned)(kk * Cout + min(co0 + 32 * m + ch, Cout - 1));
 #pragma unroll
-    for (int n = 0; n < NT; ++n) pb[n] = X + min(ci0 + 32 * n + ch, Cin - 1);
+    for (int n = 0; n < NT; ++n) offb[n] = (unsigned)(kk * Cin + min(ci0 + 32 * n + ch, Cin - 1));
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -59,35 +59,55 @@ __global__ __launch_bounds__(W_THREADS) void conv1x1_wgrad_partial_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-    for (long long blk = wave_id; blk < n_blocks; blk += n_waves) {
+    // two operand register sets: the loads of the NEXT block are issued before the MFMAs of the current one, so the memory
+    // pipe works while the wave computes (a single set leaves it idle for the ~1500 MFMA cycles of every trip)
+    auto load_block = [&](long long blk, float (&a)[W_UNROLL][MT], float (&b)[W_UNROLL][NT]) {
         const long long v = blk * (2 * W_UNROLL);
-        float a[W_UNROLL][MT], b[W_UNROLL][NT];
 #pragma unroll
         for (int u = 0; u < W_UNROLL; ++u) {
-            const long long row = v + 2 * u + kk;
+            const float *ra = dY + (v + 2 * u) * Cout;       // scalar base + per-lane 32-bit offset
+            const float *rb = X + (v + 2 * u) * Cin;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[u][m] = pa[m][row * Cout];
+            for (int m = 0; m < MT; ++m) a[u][m] = ra[offa[m]];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) b[u][n] = pb[n][row * Cin];
+            for (int n = 0; n < NT; ++n) b[u][n] = rb[offb[n]];
         }
+    };
+    auto mfma_block = [&](const float (&a)[W_UNROLL][MT], const float (&b)[W_UNROLL][NT]) {
 #pragma unroll
         for (int u = 0; u < W_UNROLL; ++u)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][m], b[u][n], acc[m][n], 0, 0, 0);
+    };
+    {
+        float a0[W_UNROLL][MT], b0[W_UNROLL][NT], a1[W_UNROLL][MT], b1[W_UNROLL][NT];
+        long long blk = wave_id;
+        if (blk < n_blocks) load_block(blk, a0, b0);
+        while (blk < n_blocks) {
+            long long nb = blk + n_waves;
+            if (nb < n_blocks) load_block(nb, a1, b1);
+            mfma_block(a0, b0);
+            blk = nb;
+            if (blk >= n_blocks) break;
+            nb = blk + n_waves;
+            if (nb < n_blocks) load_block(nb, a0, b0);
+            mfma_block(a1, b1);
+            blk = nb;
+        }
     }
-    if (wave_id == 0) {               // the < 16 voxels past the last full block: rows past the end contribute zeros
+    if (wave_id == 0) {               // the voxels past the last full block: rows past the end contribute zeros
         for (long long v = n_blocks * (2 * W_UNROLL); v < V; v += 2) {
-            const long long row = v + kk;
-            const bool ok = row < V;
-            const long long rr = ok ? row : v;
+            const bool ok = v + kk < V;
+            const float *ra = dY + (ok ? v : v - 1) * Cout;      // v - 1 + kk == v: a valid row for the lanes past the end (zeroed below)
+            const float *rb = X + (ok ? v : v - 1) * Cin;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const float av = ok ? pa[m][rr * Cout] : 0.0f;
+                const float av = ok ? ra[offa[m]] : 0.0f;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const float bv = ok ? pb[n][rr * Cin] : 0.0f;
+                    const float bv = ok ? rb[offb[n]] : 0.0f;
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][n], 0, 0, 0);
                 }
             }
@@ -177,11 +197,11 @@ bool make_plan(long long V, int Cout, int Cin, Plan &p)
     p.mt = mt; p.nt = nt;
     p.groups_m = (tm + mt - 1) / mt;
     p.groups_n = (tn + nt - 1) / nt;
-    // workgroups per CU (MDT_WGRAD_WGS_PER_CU overrides), never more than one 16-voxel block per wave would justify
+    // workgroups per CU (MDT_WGRAD_WGS_PER_CU overrides), never more than one block per wave would justify
     static const int forced = [] { const char *e = getenv("MDT_WGRAD_WGS_PER_CU"); return e ? atoi(e) : 0; }();
     const int per_cu = forced > 0 ? forced : (mt * nt == 1 ? 4 : 2);      // measured: 18 -> 18 59 vs 87 us; 36 -> 144 65 vs 81 us
     long long n_wg = (long long)cu_count() * per_cu;
-    const long long blocks = (V + 15) / 16;
+    const long long blocks = (V + 2 * W_UNROLL - 1) / (2 * W_UNROLL);
     const long long max_wg = (blocks + (W_THREADS / 64) - 1) / (W_THREADS / 64);
     if (n_wg > max_wg) n_wg = max_wg;
     if (n_wg < 1) n_wg = 1;

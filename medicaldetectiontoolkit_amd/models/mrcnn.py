@@ -258,7 +258,7 @@ def detection_target_layer(batch_proposals, batch_mrcnn_class_scores, batch_gt_c
     proposals = batch_proposals[:, :2 * dim].detach().view(B, pc, 2 * dim)
     has_gt = gt_valid.any(1)                                                          # [B]
 
-    overlaps = torch.stack([mutils.bbox_overlaps(proposals[b], gt_boxes[b]) for b in range(B)])   # [B, pc, Gmax]
+    overlaps = mutils.bbox_overlaps(proposals, gt_boxes)                              # [B, pc, Gmax], all elements at once
     overlaps = torch.where(gt_valid[:, None, :], overlaps, torch.full_like(overlaps, -1.0))
     roi_iou_max, roi_gt_assign = overlaps.max(dim=2)                                  # [B, pc]
     pos_thr, neg_thr = (0.5, 0.1) if dim == 2 else (0.3, 0.01)
