@@ -120,14 +120,14 @@ WGRAD_1X1 = True   # module switch (A/B: bench.py --wgrad-1x1 0)
 
 
 def conv1x1_wgrad_pays(n_voxels, cout, cin):
-    """where the kernel beats MIOpen's backward-weights (tools/wgrad_probe.py, profiles/r03_wgrad_probe.jsonl): the few-channel
-    layers on the large maps -- 18 -> 72: 432 -> 154 us, 72 -> 18: 310 -> 154, 18 -> 18: 547 -> 59..87, 128 -> 18: 308 -> 178 on
-    8 x 32x32x128; 36 <-> 144 and 72 -> 36 on 8 x 16x16x64: 1.2-1.4x.  Many-tile layers (72 -> 36 on the large map re-reads one
-    operand per tile group) and the small maps (launch-bound) stay on MIOpen."""
+    """where the kernel beats MIOpen's backward-weights (tools/wgrad_probe.py, profiles/r03_wgrad_probe.jsonl, B = 8): the
+    few-channel layers on the large maps -- 18 -> 72: 431 -> 107 us, 72 -> 18: 310 -> 103, 18 -> 18: 549 -> 46, 128 -> 18: 309 -> 140,
+    72 -> 36: 314 -> 195 on 32x32x128; 36 <-> 144 and 72 -> 36 on 16x16x64: 1.4-1.7x.  The small maps (launch-bound: 72 <-> 288 on
+    8x8x32 74 vs 33 us) and many-tile layers stay on MIOpen."""
     tiles = ((cout + 31) // 32) * ((cin + 31) // 32)
     if cout > 4096 or cin > 4096:
         return False
-    return (tiles <= 4 and n_voxels >= 65536) or (tiles <= 10 and 65536 <= n_voxels <= 262144)
+    return (tiles <= 6 and n_voxels >= 65536) or (tiles <= 10 and 65536 <= n_voxels <= 262144)
 
 
 def conv1x1_weight_grad(gy, x, w, force=False):
