@@ -392,6 +392,15 @@ int mdt_conv1x1_wgrad(const float *grad_out, const float *x, float *grad_weight,
 int mdt_upsample2x_yx_cl_forward(const float *in, float *out, long long batch, int Y, int X, long long inner, void *stream);
 int mdt_upsample2x_yx_cl_backward(const float *grad_out, float *grad_in, long long batch, int Y, int X, long long inner, void *stream);
 
+/* ---- 3x3x3 convolution with few channels (csrc/conv3x3x3_small.hip) ----------------------------------------------------------
+ * out[b, y, x, z, co] = sum_{tap, ci} in[b, (y, x, z) + tap - 1, ci] * w[tap][ci][co] (zero padding, stride 1), channels-last fp32,
+ * c_in even <= 32, c_out <= 32, Z a multiple of 32: the 18 -> 18 ResBlock.conv2 layers of stage C2 (models/backbone.py:186-190),
+ * which cuDNN / MIOpen compute through nn.Conv3d (utils/model_utils.py:751).  w is the filter in [27][c_in][c_out] order
+ * (w_torch.permute(2, 3, 4, 1, 0)).  `..._supported` answers 1 when the shape fits; else MDT_ERR_UNSUPPORTED. */
+int mdt_conv3x3x3_small_supported(int Y, int X, int Z, int c_in, int c_out);
+int mdt_conv3x3x3_small_forward(const float *in, const float *w_tap_ci_co, float *out, int batch, int Y, int X, int Z,
+                                int c_in, int c_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,6 +156,31 @@ def conv1x1_weight_grad(gy, x, w, force=False):
     return gw.view(w.shape)
 
 
+CONV3_SMALL = True   # module switch (A/B: bench.py --conv3-small 0)
+
+
+def conv3x3x3_small(x, w):
+    """3x3x3 / stride 1 / pad 1 convolution of a channels_last_3d fp32 activation with a few-channel filter (C_in even <= 32,
+    C_out <= 32, Z % 32 == 0) on the fp32-MFMA kernel of csrc/conv3x3x3_small.hip (MIOpen: 862 us for 18 -> 18 on 8 x 32x32x128).
+    w: [C_out, C_in, 3, 3, 3] in any memory format.  None when the shape is not of that form (the caller then asks MIOpen)."""
+    if not (CONV3_SMALL and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 5
+            and tuple(w.shape[2:]) == (3, 3, 3) and _on_current_device(x)):
+        return None
+    B, cin, Y, X, Z = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    L = _lib.lib()
+    if int(w.shape[1]) != cin or not L.mdt_conv3x3x3_small_supported(Y, X, Z, cin, cout) or B * Y * X * Z < 65536:
+        return None
+    if not x.is_contiguous(memory_format=torch.channels_last_3d):
+        return None
+    wt = w.permute(2, 3, 4, 1, 0).contiguous()                  # [27][C_in][C_out]
+    y = torch.empty((B, cout, Y, X, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+    rc = L.mdt_conv3x3x3_small_forward(x.data_ptr(), wt.data_ptr(), y.data_ptr(), B, Y, X, Z, cin, cout, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _lib.check(rc, "mdt_conv3x3x3_small_forward")
+    return y
+
+
 class _ConvStride1(Function):
     """Unit-stride convolution whose input gradient is computed as a FORWARD convolution of the output gradient with the
     flipped, transposed filter (the textbook identity; same arithmetic up to fp32 summation order).  MIOpen's forward
@@ -168,6 +193,10 @@ class _ConvStride1(Function):
     def forward(ctx, x, w, padding):
         ctx.save_for_backward(x, w)
         ctx.padding = padding
+        if w.dim() == 5 and tuple(padding) == (1, 1, 1):
+            y = conv3x3x3_small(x, w)
+            if y is not None:
+                return y
         return (F.conv3d if w.dim() == 5 else F.conv2d)(x, w, None, 1, padding)
 
     @staticmethod
@@ -178,7 +207,11 @@ class _ConvStride1(Function):
         if ctx.needs_input_grad[0]:
             mf = torch.contiguous_format if gy.is_contiguous() else (torch.channels_last_3d if nd == 3 else torch.channels_last)
             pad_t = tuple(int(k) - 1 - int(p) for k, p in zip(w.shape[2:], ctx.padding))
-            gx = (F.conv3d if nd == 3 else F.conv2d)(gy, flip_transpose_filter(w, mf), None, 1, pad_t)
+            wf = flip_transpose_filter(w, mf)
+            gx = conv3x3x3_small(gy if gy.is_contiguous(memory_format=torch.channels_last_3d) or nd != 3 else gy.contiguous(memory_format=torch.channels_last_3d), wf) \
+                if (nd == 3 and pad_t == (1, 1, 1)) else None
+            if gx is None:
+                gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, 1, pad_t)
         if ctx.needs_input_grad[1]:
             gw = conv1x1_weight_grad(gy, x, w) if WGRAD_1X1 else None
             if gw is None:

@@ -243,3 +243,57 @@ def test_upsample2x_channels_last_matches_interpolate(case, cuda):
     y2 = fe.upsample2x_yx(x2, sf, mode)
     y2.backward(go.contiguous(memory_format=mf))
     assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad)
+
+
+# ------------------------------------------------------------------ few-channel 3x3x3 convolution (csrc/conv3x3x3_small.hip)
+CONV3_CASES = [
+    # B, Cin, Cout, (Y, X, Z)
+    (2, 18, 18, (16, 16, 128)),      # the C2 bottleneck layer (3 K-steps per trip)
+    (1, 18, 18, (5, 7, 32)),         # x not a multiple of 4, single z tile, borders everywhere
+    (2, 6, 30, (6, 9, 64)),          # C_out > C_in
+    (2, 16, 5, (4, 6, 64)),          # generic K loop (8 K-steps), few outputs
+    (1, 12, 20, (3, 5, 32)),         # LDS budget: 27 * 12 * 20 + 18 rows * 34 * 12 floats
+]
+
+
+@pytest.mark.parametrize("case", CONV3_CASES, ids=[str(c) for c in CONV3_CASES])
+def test_conv3x3x3_small_vs_torch(case, cuda):
+    """mdt_conv3x3x3_small_forward == F.conv3d(padding=1) to fp32 summation order (1e-5 of the summed magnitudes), zero padding on
+    all six faces; asymmetric random operands"""
+    from medicaldetectiontoolkit_amd import _lib
+    B, cin, cout, sp = case
+    g = torch.Generator(device=cuda).manual_seed(cin * 100 + cout)
+    x = torch.randn((B, cin) + sp, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    w = torch.randn((cout, cin, 3, 3, 3), device=cuda, generator=g)
+    assert _lib.lib().mdt_conv3x3x3_small_supported(sp[0], sp[1], sp[2], cin, cout) == 1
+    wt = w.permute(2, 3, 4, 1, 0).contiguous()
+    y = torch.empty((B, cout) + sp, device=cuda).contiguous(memory_format=torch.channels_last_3d)
+    y.fill_(float("nan"))
+    rc = _lib.lib().mdt_conv3x3x3_small_forward(x.data_ptr(), wt.data_ptr(), y.data_ptr(), B, sp[0], sp[1], sp[2], cin, cout,
+                                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    want = F.conv3d(x.double(), w.double(), None, 1, 1)
+    mag = F.conv3d(x.double().abs(), w.double().abs(), None, 1, 1)
+    err = (y.double() - want).abs()
+    assert torch.all(err <= 1e-5 * mag + 1e-12), float((err / mag).max())      # a NaN left anywhere (unwritten output) fails
+
+
+def test_conv3x3x3_small_inside_autograd_matches_miopen(cuda):
+    """an 18 -> 18 ConvBiasReLU layer: forward, input gradient (the kernel with the flipped / transposed filter) and weight
+    gradient with the kernel on / off"""
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    from medicaldetectiontoolkit_amd.utils.model_utils import NDConvGenerator
+    torch.manual_seed(5)
+    layer = NDConvGenerator(3)(18, 18, ks=3, pad=1, relu="relu").to(cuda).to(memory_format=torch.channels_last_3d)
+    x = torch.randn((2, 18, 16, 16, 128), device=cuda).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    res = []
+    for flag in (True, False):
+        fe.CONV3_SMALL = flag
+        layer.zero_grad()
+        x.grad = None
+        y = layer(x)
+        y.square().sum().backward()
+        res.append((y.detach().clone(), x.grad.clone(), layer[0].weight.grad.clone()))
+    fe.CONV3_SMALL = True
+    for a, b in zip(res[0], res[1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), float((a - b).abs().max())
