@@ -343,6 +343,7 @@ def main():
     ap.add_argument("--conv-bwd-as-fwd", type=int, default=1, help="1 (default): input gradients of unit-stride convolutions as forward convolutions (utils/fused_epilogue._ConvStride1); 0: MIOpen backward-data (A/B)")
     ap.add_argument("--stem-s2d", type=int, default=1, help="1 (default): stem convolution forward in space-to-depth form (utils/fused_epilogue._ConvStem221); 0: as is (A/B)")
     ap.add_argument("--wgrad-1x1", type=int, default=1, help="1 (default): weight gradients of the 1x1x1 convolutions with the fp32-MFMA kernel (csrc/conv1x1_wgrad.hip); 0: MIOpen backward-weights (A/B)")
+    ap.add_argument("--stem-wgrad", type=int, default=1, help="1 (default): weight gradient of the one-channel 7x7x7 stem on the fp32-MFMA kernel (csrc/conv_stem_wgrad.hip); 0: MIOpen (A/B)")
     ap.add_argument("--conv3-small", type=int, default=1, help="1 (default): the few-channel 3x3x3 convolutions (18 -> 18 on the large maps) on the fp32-MFMA kernel (csrc/conv3x3x3_small.hip), forward and input gradient; 0: MIOpen (A/B)")
     ap.add_argument("--head-as-linear", type=int, default=1, help="1 (default): the classifier head's full-extent / 1x1x1 convolutions as GEMMs (models/mrcnn.py Classifier); 0: MIOpen convolutions (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
@@ -390,6 +391,7 @@ def main():
     fused_epilogue.WGRAD_1X1 = bool(args.wgrad_1x1)
     fused_epilogue.UPSAMPLE_CL = bool(args.upsample_cl)
     fused_epilogue.CONV3_SMALL = bool(args.conv3_small)
+    fused_epilogue.STEM_WGRAD = bool(args.stem_wgrad)
     from medicaldetectiontoolkit_amd.configs import Configs
     from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
     from medicaldetectiontoolkit_amd.models import mrcnn, retina_unet

@@ -401,6 +401,15 @@ int mdt_conv3x3x3_small_supported(int Y, int X, int Z, int c_in, int c_out);
 int mdt_conv3x3x3_small_forward(const float *in, const float *w_tap_ci_co, float *out, int batch, int Y, int X, int Z,
                                 int c_in, int c_out, void *stream);
 
+/* ---- weight gradient of the one-channel stem convolution (csrc/conv_stem_wgrad.hip) ------------------------------------------
+ * dW[co][ky, kx, kz] = sum_{b, oy, ox, oz} grad_out[b, oy, ox, oz][co] * x_padded[b, sy * oy + ky, sx * ox + kx, oz + kz]: the
+ * backward-weights of C1 = conv(1 -> 18, ks 7, stride (2, 2, 1), pad 3) (models/backbone.py:66-68), which the reference gets from
+ * cuDNN.  grad_out channels-last [B, OY, OX, OZ, c_out] (c_out <= 32, OZ % 8 == 0); x_padded = the ONE-channel input zero-padded
+ * by k / 2 on every face, [B, YP, XP, ZP]; k odd, k^3 <= 384; z stride 1.  fp32 MFMA, deterministic. */
+size_t mdt_conv_stem_wgrad_workspace_bytes(int c_out, int k);
+int mdt_conv_stem_wgrad(const float *grad_out, const float *x_padded, float *grad_weight, int batch, int OY, int OX, int OZ,
+                        int c_out, int k, int sy, int sx, int YP, int XP, int ZP, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

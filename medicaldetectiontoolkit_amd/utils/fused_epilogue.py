@@ -220,6 +220,37 @@ class _ConvStride1(Function):
         return gx, gw, None
 
 
+STEM_WGRAD = True   # module switch (A/B: bench.py --stem-wgrad 0)
+
+
+def stem_weight_grad(gy, x, w, stride):
+    """Weight gradient of a one-channel k x k x k convolution with stride (sy, sx, 1) and padding k // 2 on the fp32-MFMA kernel of
+    csrc/conv_stem_wgrad.hip (MIOpen: 3.7 ms for the 7x7x7 stem on 8 x 128^3).  None when the layer is not of that form."""
+    if not (STEM_WGRAD and gy.is_cuda and gy.dtype == torch.float32 and x.dtype == torch.float32 and x.dim() == 5 and int(x.shape[1]) == 1
+            and int(w.shape[1]) == 1 and int(stride[2]) == 1 and _on_current_device(gy)):
+        return None
+    k = int(w.shape[2])
+    cout = int(w.shape[0])
+    B, _, OY, OX, OZ = (int(v) for v in gy.shape)
+    if tuple(int(v) for v in w.shape[2:]) != (k, k, k) or k % 2 == 0 or k ** 3 > 384 or cout > 32 or OZ % 8 != 0:
+        return None
+    pad = k // 2
+    if (int(x.shape[2]) + 2 * pad - k) // int(stride[0]) + 1 != OY or (int(x.shape[3]) + 2 * pad - k) // int(stride[1]) + 1 != OX or int(x.shape[4]) != OZ:
+        return None
+    if not gy.is_contiguous(memory_format=torch.channels_last_3d):
+        gy = gy.contiguous(memory_format=torch.channels_last_3d)
+    xp = F.pad(x.reshape(B, int(x.shape[2]), int(x.shape[3]), int(x.shape[4])), (pad, pad, pad, pad, pad, pad)).contiguous()
+    L = _lib.lib()
+    wsb = L.mdt_conv_stem_wgrad_workspace_bytes(cout, k)
+    ws = _workspace(wsb, gy.device)
+    gw = torch.empty((cout, k * k * k), dtype=torch.float32, device=gy.device)
+    rc = L.mdt_conv_stem_wgrad(gy.data_ptr(), xp.data_ptr(), gw.data_ptr(), B, OY, OX, OZ, cout, k, int(stride[0]), int(stride[1]),
+                               int(xp.shape[1]), int(xp.shape[2]), int(xp.shape[3]), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _lib.check(rc, "mdt_conv_stem_wgrad")
+    return gw.view(w.shape)
+
+
 class _ConvStem221(Function):
     """The stem: few input channels, odd k x k x k filter, stride (2, 2, 1), pad k // 2 (backbone.py:66-68: 1 -> 18, 7x7x7).
     Forward in space-to-depth form: the 2 x 2 (y, x) phases of the padded input become 4x the input channels and the filter
@@ -246,8 +277,14 @@ class _ConvStem221(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         p = int(w.shape[2]) // 2
-        gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2, 1], [p, p, p], [1, 1, 1], False, [0, 0, 0], 1,
-                                                        [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        gw = stem_weight_grad(gy, x, w, (2, 2, 1)) if ctx.needs_input_grad[1] else None
+        need_w = bool(ctx.needs_input_grad[1]) and gw is None
+        gx = None
+        if ctx.needs_input_grad[0] or need_w:
+            gx, gw2, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2, 1], [p, p, p], [1, 1, 1], False, [0, 0, 0], 1,
+                                                             [bool(ctx.needs_input_grad[0]), need_w, False])
+            if need_w:
+                gw = gw2
         return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None)
 
 

@@ -297,3 +297,28 @@ def test_conv3x3x3_small_inside_autograd_matches_miopen(cuda):
     fe.CONV3_SMALL = True
     for a, b in zip(res[0], res[1]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), float((a - b).abs().max())
+
+
+# ------------------------------------------------------------------ stem weight gradient (csrc/conv_stem_wgrad.hip)
+@pytest.mark.parametrize("case", [(2, 18, 7, (32, 32, 32)), (1, 18, 7, (16, 24, 16)), (2, 5, 3, (12, 8, 8)), (1, 32, 5, (8, 8, 24))],
+                         ids=lambda c: str(c))
+def test_stem_wgrad_vs_aten(case, cuda):
+    """mdt_conv_stem_wgrad == aten.convolution_backward's weight gradient of a one-channel k^3 convolution with stride (2, 2, 1),
+    pad k // 2 (1e-5 of the summed magnitudes; deterministic)"""
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    B, cout, k, sp = case
+    g = torch.Generator(device=cuda).manual_seed(cout * 10 + k)
+    x = torch.randn((B, 1) + sp, device=cuda, generator=g)
+    w = torch.randn((cout, 1, k, k, k), device=cuda, generator=g)
+    osp = ((sp[0] + 2 * (k // 2) - k) // 2 + 1, (sp[1] + 2 * (k // 2) - k) // 2 + 1, sp[2])
+    gy = torch.randn((B, cout) + osp, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    got = fe.stem_weight_grad(gy, x, w, (2, 2, 1))
+    assert got is not None and got.shape == w.shape
+    p = k // 2
+    want = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [2, 2, 1], [p, p, p], [1, 1, 1], False, [0, 0, 0], 1,
+                                               [False, True, False])[1]
+    mag = torch.ops.aten.convolution_backward(gy.double().abs(), x.double().abs(), w.double(), None, [2, 2, 1], [p, p, p], [1, 1, 1], False,
+                                              [0, 0, 0], 1, [False, True, False])[1]
+    err = (got.double() - want).abs()
+    assert torch.all(err <= 1e-5 * mag + 1e-12), float((err / mag).max())
+    assert torch.equal(got, fe.stem_weight_grad(gy, x, w, (2, 2, 1)))
