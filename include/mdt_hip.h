@@ -400,6 +400,12 @@ int mdt_upsample2x_yx_cl_backward(const float *grad_out, float *grad_in, long lo
 int mdt_conv3x3x3_small_supported(int Y, int X, int Z, int c_in, int c_out);
 int mdt_conv3x3x3_small_forward(const float *in, const float *w_tap_ci_co, float *out, int batch, int Y, int X, int Z,
                                 int c_in, int c_out, void *stream);
+/* weight gradient of the same layer, dW[tap][ci][co] = sum_v in[v + tap - 1][ci] * grad_out[v][co] (what
+ * aten.convolution_backward(..., output_mask = [0, 1, 0]) returns, in [27][c_in][c_out] order); workspace = one partial per
+ * workgroup tile; deterministic */
+size_t mdt_conv3x3x3_small_wgrad_workspace_bytes(int batch, int Y, int X, int c_in, int c_out);
+int mdt_conv3x3x3_small_wgrad(const float *in, const float *grad_out, float *grad_w_tap_ci_co, int batch, int Y, int X, int Z,
+                              int c_in, int c_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- weight gradient of the one-channel stem convolution (csrc/conv_stem_wgrad.hip) ------------------------------------------
  * dW[co][ky, kx, kz] = sum_{b, oy, ox, oz} grad_out[b, oy, ox, oz][co] * x_padded[b, sy * oy + ky, sx * ox + kx, oz + kz]: the

@@ -147,6 +147,149 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3x3_small_kernel(C3Params p)
     }
 }
 
+// ---- weight gradient of the same layer:  dW[tap][ci][co] = sum_v X[v + off(tap)][ci] * dY[v][co]
+// M = input channels (A = the shifted input voxel: lanes run over ci, conflict-free), N = output channels (B = dY), K = voxels.
+// The workgroup tile and the LDS image of the input rows are those of the forward kernel, plus the tile's 4 x 32 dY rows; the 27
+// taps are dealt to the four waves (7, 7, 7, 6 accumulator tiles), every wave walking all 64 K-steps of the tile.  A workgroup
+// accumulates over its z tiles and writes one [27][C_in][C_out] partial; a second kernel adds the partials in a fixed order.
+constexpr int C3_WTAPS = 7;           // taps per wave (4 x 7 >= 27)
+
+__global__ __launch_bounds__(C3_THREADS) void conv3x3x3_small_wgrad_kernel(C3Params p, const float *__restrict__ dy, float *__restrict__ ws)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Al = lds;                                        // [3][XT + 2][ZT + 2][Cin]
+    float *Dl = lds + 3 * (C3_XT + 2) * p.row_floats;       // [XT][ZT][Cout]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int g = blockIdx.x;
+    const int xq = g % p.xg; g /= p.xg;
+    const int y = g % p.Y;
+    const int b = g / p.Y;
+    const int x0 = xq * C3_XT;
+    const int rf = p.row_floats;
+    const int i = lane & 31, kk = lane >> 5;
+    const int ci = min(i, p.Cin - 1), cj = min(i, p.Cout - 1);
+    const int drow = C3_ZT * p.Cout;                        // floats of one dY row in the tile
+    f32x16 acc[C3_WTAPS];
+#pragma unroll
+    for (int t = 0; t < C3_WTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    // per-lane LDS offsets of this wave's taps inside the input image (relative to x position 0, voxel 0)
+    int aoff[C3_WTAPS];
+#pragma unroll
+    for (int t = 0; t < C3_WTAPS; ++t) {
+        const int tap = min(wave * C3_WTAPS + t, 26);
+        const int dy_ = tap / 9, rem = tap - dy_ * 9;
+        const int dx = rem / 3, dz = rem - dx * 3;
+        aoff[t] = (dy_ * (C3_XT + 2) + dx) * rf + (dz + kk) * p.Cin + ci;
+    }
+    for (int z0 = 0; z0 < p.Z; z0 += C3_ZT) {
+        __syncthreads();
+        const bool first_z = (z0 == 0), last_z = (z0 + C3_ZT >= p.Z);
+        const int chunks = (rf + 63) >> 6;
+        for (int row = 0; row < 3 * (C3_XT + 2); ++row) {
+            const int ry = row / (C3_XT + 2), rx = row - ry * (C3_XT + 2);
+            const int yy = y + ry - 1, xx = x0 + rx - 1;
+            const bool row_ok = yy >= 0 && yy < p.Y && xx >= 0 && xx < p.X;
+            const float *src = p.in + ((((long long)b * p.Y + yy) * p.X + xx) * p.Z + z0 - 1) * p.Cin;
+            float *dst = Al + row * rf;
+            for (int c = wave; c < chunks; c += C3_THREADS / 64) {
+                const int e = c * 64 + lane;
+                if (e < rf) {
+                    const bool ok = row_ok && !(first_z && e < p.Cin) && !(last_z && e >= (C3_ZT + 1) * p.Cin);
+                    if (ok)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + e),
+                                                         (__attribute__((address_space(3))) void *)(dst + c * 64), 4, 0, 0);
+                    else
+                        dst[e] = 0.0f;
+                }
+            }
+        }
+        const int dchunks = (drow + 63) >> 6;
+        for (int xp = 0; xp < C3_XT; ++xp) {                 // dY rows of the tile (zeros past the last x)
+            const bool row_ok = x0 + xp < p.X;
+            const float *src = dy + ((((long long)b * p.Y + y) * p.X + x0 + xp) * p.Z + z0) * p.Cout;
+            float *dst = Dl + xp * drow;
+            for (int c = wave; c < dchunks; c += C3_THREADS / 64) {
+                const int e = c * 64 + lane;
+                if (e < drow) {
+                    if (row_ok)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + e),
+                                                         (__attribute__((address_space(3))) void *)(dst + c * 64), 4, 0, 0);
+                    else
+                        dst[e] = 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+        // 4 x positions x 16 K-steps; per K-step one B read and this wave's 7 A reads, issued two K-steps ahead of their MFMAs
+        auto load_step = [&](int s, float (&a)[C3_WTAPS], float &bv) {
+            const int xp = s >> 4, zk = (s & 15) * 2;
+            bv = Dl[xp * drow + (zk + kk) * p.Cout + cj];
+            const float *base = Al + xp * rf + zk * p.Cin;
+#pragma unroll
+            for (int t = 0; t < C3_WTAPS; ++t) a[t] = base[aoff[t]];
+        };
+        auto mfma_step = [&](const float (&a)[C3_WTAPS], float bv) {
+#pragma unroll
+            for (int t = 0; t < C3_WTAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bv, acc[t], 0, 0, 0);
+        };
+        float a0[C3_WTAPS], a1[C3_WTAPS], b0, b1;
+        load_step(0, a0, b0);
+        constexpr int NS = C3_XT * (C3_ZT / 2);
+        for (int s = 0; s < NS; s += 2) {
+            load_step(s + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < NS) load_step(s + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // C/D map: column = lane & 31 (co), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (ci)
+    float *out = ws + (size_t)blockIdx.x * 27 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < C3_WTAPS; ++t) {
+        const int tap = wave * C3_WTAPS + t;
+        if (tap < 27 && i < p.Cout) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c_in = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (c_in < p.Cin) out[((size_t)tap * p.Cin + c_in) * p.Cout + i] = acc[t][r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3x3x3_small_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dW, int n_elem, int n_part)
+{
+    __shared__ float part[16][17];
+    const int sub = threadIdx.x & 15, el = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    float s = 0.0f;
+    if (e < n_elem) {
+        int q = sub;
+        for (; q + 16 * 7 < n_part; q += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(q + 16 * u) * n_elem + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = s + v[u];
+        }
+        for (; q < n_part; q += 16) s = s + ws[(size_t)q * n_elem + e];
+    }
+    part[el][sub] = s;
+    __syncthreads();
+    if (sub == 0 && e < n_elem) {
+        float t = part[el][0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t = t + part[el][k];
+        dW[e] = t;
+    }
+}
+
 inline int c3_check()
 {
     const hipError_t e = hipGetLastError();
@@ -192,6 +335,43 @@ int mdt_conv3x3x3_small_forward(const float *in, const float *w_tap_ci_co, float
     if (c_in == 18) hipLaunchKernelGGL(conv3x3x3_small_kernel<9>, dim3((unsigned)grid), dim3(C3_THREADS), lds, static_cast<hipStream_t>(stream), p);
     else if (c_in == 6) hipLaunchKernelGGL(conv3x3x3_small_kernel<3>, dim3((unsigned)grid), dim3(C3_THREADS), lds, static_cast<hipStream_t>(stream), p);
     else hipLaunchKernelGGL(conv3x3x3_small_kernel<0>, dim3((unsigned)grid), dim3(C3_THREADS), lds, static_cast<hipStream_t>(stream), p);
+    return c3_check();
+}
+
+size_t mdt_conv3x3x3_small_wgrad_workspace_bytes(int batch, int Y, int X, int c_in, int c_out)
+{
+    if (batch <= 0 || Y <= 0 || X <= 0 || c_in <= 0 || c_out <= 0) return 0;
+    return (size_t)batch * Y * ((X + C3_XT - 1) / C3_XT) * 27 * c_in * c_out * sizeof(float) + 256;
+}
+
+int mdt_conv3x3x3_small_wgrad(const float *in, const float *grad_out, float *grad_w_tap_ci_co, int batch, int Y, int X, int Z,
+                              int c_in, int c_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!in || !grad_out || !grad_w_tap_ci_co || batch <= 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (!mdt_conv3x3x3_small_supported(Y, X, Z, c_in, c_out)) return MDT_ERR_UNSUPPORTED;
+    C3Params p;
+    p.in = in; p.wt = nullptr; p.out = nullptr;
+    p.B = batch; p.Y = Y; p.X = X; p.Z = Z; p.Cin = c_in; p.Cout = c_out;
+    p.xg = (X + C3_XT - 1) / C3_XT;
+    p.row_floats = (C3_ZT + 2) * c_in;
+    const long long grid = (long long)batch * Y * p.xg;
+    if (grid > 0x7fffffLL) return MDT_ERR_UNSUPPORTED;
+    const size_t need = (size_t)grid * 27 * c_in * c_out * sizeof(float);
+    if (!workspace || workspace_bytes < need) return MDT_ERR_WORKSPACE_TOO_SMALL;
+    const size_t lds = ((size_t)3 * (C3_XT + 2) * p.row_floats + (size_t)C3_XT * C3_ZT * c_out) * sizeof(float);
+    if (lds > 80 * 1024) return MDT_ERR_UNSUPPORTED;
+    static bool optin = false;
+    if (!optin) {
+        (void)hipFuncSetAttribute((const void *)conv3x3x3_small_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipGetLastError();
+        optin = true;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(conv3x3x3_small_wgrad_kernel, dim3((unsigned)grid), dim3(C3_THREADS), lds, s, p, grad_out, static_cast<float *>(workspace));
+    const int n_elem = 27 * c_in * c_out;
+    hipLaunchKernelGGL(conv3x3x3_small_reduce_kernel, dim3((unsigned)((n_elem + 15) / 16)), dim3(256), 0, s, static_cast<const float *>(workspace),
+                       grad_w_tap_ci_co, n_elem, (int)grid);
     return c3_check();
 }
 

@@ -159,6 +159,12 @@ def conv1x1_weight_grad(gy, x, w, force=False):
 CONV3_SMALL = True   # module switch (A/B: bench.py --conv3-small 0)
 
 
+def _conv3_small_pays(cin, cout):
+    """MIOpen has efficient kernels when the channel counts are multiples of 8 (16 -> 16 on 8 x 32x32x128: 254 us forward against
+    504 us here) and poor ones otherwise (18 -> 18: 857 us against 393; 6 -> 6: 330 against 148; tools/conv3_probe.py)"""
+    return cin % 8 != 0 or cout % 8 != 0
+
+
 def conv3x3x3_small(x, w):
     """3x3x3 / stride 1 / pad 1 convolution of a channels_last_3d fp32 activation with a few-channel filter (C_in even <= 32,
     C_out <= 32, Z % 32 == 0) on the fp32-MFMA kernel of csrc/conv3x3x3_small.hip (MIOpen: 862 us for 18 -> 18 on 8 x 32x32x128).
@@ -169,7 +175,7 @@ def conv3x3x3_small(x, w):
     B, cin, Y, X, Z = (int(v) for v in x.shape)
     cout = int(w.shape[0])
     L = _lib.lib()
-    if int(w.shape[1]) != cin or not L.mdt_conv3x3x3_small_supported(Y, X, Z, cin, cout) or B * Y * X * Z < 65536:
+    if int(w.shape[1]) != cin or not L.mdt_conv3x3x3_small_supported(Y, X, Z, cin, cout) or B * Y * X * Z < 65536 or not _conv3_small_pays(cin, cout):
         return None
     if not x.is_contiguous(memory_format=torch.channels_last_3d):
         return None
@@ -179,6 +185,30 @@ def conv3x3x3_small(x, w):
     if rc != 0:
         _lib.check(rc, "mdt_conv3x3x3_small_forward")
     return y
+
+
+def conv3x3x3_small_weight_grad(gy, x, w):
+    """weight gradient of the few-channel 3x3x3 layer on the same MFMA machinery (csrc/conv3x3x3_small.hip; MIOpen: 1078 us for
+    18 -> 18 on 8 x 32x32x128).  None when the shape is not of that form."""
+    if not (CONV3_SMALL and gy.is_cuda and gy.dtype == torch.float32 and x.dtype == torch.float32 and x.dim() == 5
+            and tuple(w.shape[2:]) == (3, 3, 3) and _on_current_device(gy)):
+        return None
+    B, cin, Y, X, Z = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    L = _lib.lib()
+    if not L.mdt_conv3x3x3_small_supported(Y, X, Z, cin, cout) or B * Y * X * Z < 65536 or not _conv3_small_pays(cin, cout) \
+            or not x.is_contiguous(memory_format=torch.channels_last_3d):
+        return None
+    if not gy.is_contiguous(memory_format=torch.channels_last_3d):
+        gy = gy.contiguous(memory_format=torch.channels_last_3d)
+    wsb = L.mdt_conv3x3x3_small_wgrad_workspace_bytes(B, Y, X, cin, cout)
+    ws = _workspace(wsb, gy.device)
+    gw = torch.empty((3, 3, 3, cin, cout), dtype=torch.float32, device=gy.device)
+    rc = L.mdt_conv3x3x3_small_wgrad(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, Y, X, Z, cin, cout, ws.data_ptr(), ws.numel(),
+                                     torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _lib.check(rc, "mdt_conv3x3x3_small_wgrad")
+    return gw.permute(4, 3, 0, 1, 2)
 
 
 class _ConvStride1(Function):
@@ -214,6 +244,8 @@ class _ConvStride1(Function):
                 gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, 1, pad_t)
         if ctx.needs_input_grad[1]:
             gw = conv1x1_weight_grad(gy, x, w) if WGRAD_1X1 else None
+            if gw is None and nd == 3 and tuple(ctx.padding) == (1, 1, 1):
+                gw = conv3x3x3_small_weight_grad(gy, x, w)
             if gw is None:
                 gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1] * nd, list(ctx.padding), [1] * nd, False, [0] * nd, 1,
                                                          [False, True, False])[1]

@@ -322,3 +322,31 @@ def test_stem_wgrad_vs_aten(case, cuda):
     err = (got.double() - want).abs()
     assert torch.all(err <= 1e-5 * mag + 1e-12), float((err / mag).max())
     assert torch.equal(got, fe.stem_weight_grad(gy, x, w, (2, 2, 1)))
+
+
+@pytest.mark.parametrize("case", CONV3_CASES, ids=[str(c) for c in CONV3_CASES])
+def test_conv3x3x3_small_wgrad_vs_aten(case, cuda):
+    """mdt_conv3x3x3_small_wgrad == aten.convolution_backward's weight gradient (1e-5 of the summed magnitudes), deterministic"""
+    from medicaldetectiontoolkit_amd import _lib
+    B, cin, cout, sp = case
+    g = torch.Generator(device=cuda).manual_seed(cin * 100 + cout + 1)
+    x = torch.randn((B, cin) + sp, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    gy = torch.randn((B, cout) + sp, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    w = torch.randn((cout, cin, 3, 3, 3), device=cuda, generator=g)
+    L = _lib.lib()
+    wsb = L.mdt_conv3x3x3_small_wgrad_workspace_bytes(B, sp[0], sp[1], cin, cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    outs = []
+    for _ in range(2):
+        gw = torch.full((3, 3, 3, cin, cout), float("nan"), device=cuda)
+        rc = L.mdt_conv3x3x3_small_wgrad(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, sp[0], sp[1], sp[2], cin, cout, ws.data_ptr(), wsb,
+                                         torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        outs.append(gw.permute(4, 3, 0, 1, 2).contiguous())
+    assert torch.equal(outs[0], outs[1])
+    want = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
+                                               [False, True, False])[1]
+    mag = torch.ops.aten.convolution_backward(gy.double().abs(), x.double().abs(), w.double(), None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False,
+                                              [0, 0, 0], 1, [False, True, False])[1]
+    err = (outs[0].double() - want).abs()
+    assert torch.all(err <= 1e-5 * mag + 1e-12), float((err / mag).max())

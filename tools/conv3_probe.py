@@ -33,6 +33,9 @@ for cin, cout, sp in [(18, 18, (32, 32, 128)), (18, 18, (64, 64, 128)), (6, 6, (
     w = torch.randn((cout, cin, 3, 3, 3), device=dev).contiguous(memory_format=torch.channels_last_3d)
     t_new = timeit(lambda: fe.conv3x3x3_small(x, w))
     t_ref = timeit(lambda: F.conv3d(x, w, None, 1, 1))
+    gy = torch.randn((B, cout) + sp, device=dev).contiguous(memory_format=torch.channels_last_3d)
+    t_wn = timeit(lambda: fe.conv3x3x3_small_weight_grad(gy, x, w))
+    t_wr = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1, [False, True, False]))
     flop = 2.0 * 27 * cin * cout * B * sp[0] * sp[1] * sp[2]
     print(json.dumps({"cin": cin, "cout": cout, "spatial": sp, "batch": B, "mdt_us": round(t_new, 1), "miopen_us": round(t_ref, 1),
-                      "mdt_TFLOPs": round(flop / t_new / 1e6, 1), "miopen_TFLOPs": round(flop / t_ref / 1e6, 1)}), flush=True)
+                      "wgrad_mdt_us": round(t_wn, 1), "wgrad_miopen_us": round(t_wr, 1), "mdt_TFLOPs": round(flop / t_new / 1e6, 1), "miopen_TFLOPs": round(flop / t_ref / 1e6, 1)}), flush=True)

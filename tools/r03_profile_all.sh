@@ -8,6 +8,9 @@ timeout 900 python -m pytest tests -q -m gpu > gpurun_out/r03_gpu_suite.log 2>&1
 tail -4 gpurun_out/r03_gpu_suite.log
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r03_bench_line.json 2> gpurun_out/r03_bench.err
 tail -c 7000 gpurun_out/r03_bench_line.json; tail -2 gpurun_out/r03_bench.err
+for flag in 0 1; do
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-h2d-leg --no-rccl-selftest --no-secondary --no-roofline --conv3-small $flag 2>/dev/null | python -c "import sys,json; l=[x for x in sys.stdin if x.startswith('{')][-1]; d=json.loads(l); print('A/B conv3_small=$flag', d['value'], d['ms_per_step'])" | tee -a gpurun_out/r03_ab_conv3_small.txt
+done
 OUT_NAME=r03_step_steady_state bash tools/prof_step.sh 5 400 | head -12
 for R in trainlike random; do
   T=$([ $R = random ] && echo survey_random || echo trainlike)
