@@ -344,6 +344,7 @@ def main():
     ap.add_argument("--stem-s2d", type=int, default=1, help="1 (default): stem convolution forward in space-to-depth form (utils/fused_epilogue._ConvStem221); 0: as is (A/B)")
     ap.add_argument("--wgrad-1x1", type=int, default=1, help="1 (default): weight gradients of the 1x1x1 convolutions with the fp32-MFMA kernel (csrc/conv1x1_wgrad.hip); 0: MIOpen backward-weights (A/B)")
     ap.add_argument("--stem-wgrad", type=int, default=1, help="1 (default): weight gradient of the one-channel 7x7x7 stem on the fp32-MFMA kernel (csrc/conv_stem_wgrad.hip); 0: MIOpen (A/B)")
+    ap.add_argument("--stem-fwd", type=int, default=1, help="1 (default): forward of the one-channel 7x7x7 stem on the fp32-MFMA kernel (csrc/conv_stem_fwd.hip); 0: MIOpen, space-to-depth form (A/B)")
     ap.add_argument("--conv3-small", type=int, default=1, help="1 (default): the few-channel 3x3x3 convolutions (18 -> 18 on the large maps) on the fp32-MFMA kernel (csrc/conv3x3x3_small.hip), forward and input gradient; 0: MIOpen (A/B)")
     ap.add_argument("--head-as-linear", type=int, default=1, help="1 (default): the classifier head's full-extent / 1x1x1 convolutions as GEMMs (models/mrcnn.py Classifier); 0: MIOpen convolutions (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
@@ -362,6 +363,11 @@ def main():
         if n_dev < args.gpus and args.backend == "nccl":
             raise SystemExit("bench.py: --gpus %d requested but this node exposes %d GPU(s); refusing to report a smaller run" % (args.gpus, n_dev))
         _self_launch(args.gpus)
+    # stdout carries the ONE JSON line and nothing else: libraries that write to fd 1 from C (the RCCL version banner, MIOpen
+    # notes; some only at exit, i.e. AFTER the line) are sent to stderr for the lifetime of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -392,6 +398,7 @@ def main():
     fused_epilogue.UPSAMPLE_CL = bool(args.upsample_cl)
     fused_epilogue.CONV3_SMALL = bool(args.conv3_small)
     fused_epilogue.STEM_WGRAD = bool(args.stem_wgrad)
+    fused_epilogue.STEM_FWD = bool(args.stem_fwd)
     from medicaldetectiontoolkit_amd.configs import Configs
     from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
     from medicaldetectiontoolkit_amd.models import mrcnn, retina_unet
@@ -496,7 +503,8 @@ def main():
                 out["secondary"] = secondary_configs()
             except Exception as e:
                 out["secondary"] = {"failed": repr(e)}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

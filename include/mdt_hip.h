@@ -416,6 +416,16 @@ size_t mdt_conv_stem_wgrad_workspace_bytes(int c_out, int k);
 int mdt_conv_stem_wgrad(const float *grad_out, const float *x_padded, float *grad_weight, int batch, int OY, int OX, int OZ,
                         int c_out, int k, int sy, int sx, int YP, int XP, int ZP, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- forward of the one-channel stem convolution (csrc/conv_stem_fwd.hip) -----------------------------------------------------
+ * out[b, oy, ox, oz][co] = (bias[co] +) sum_{ky, kx, kz} weight[co][ky, kx, kz] * x_padded[b, 2 oy + ky, 2 ox + kx, oz + kz]
+ * (optionally ReLU): C1 = conv(1 -> 18, ks 7, stride (2, 2, 1), pad 3) of models/backbone.py:66-68, which the reference gets from
+ * cuDNN through nn.Conv3d.  x_padded = the ONE-channel input zero-padded by 3 on every face, [B, YP, XP, ZP = OZ + 6], 8-byte
+ * aligned; out channels-last [B, OY, OX, OZ, c_out]; bias may be NULL.  Supported: k = 7, stride (2, 2), c_out <= 32, OX % 4 == 0,
+ * OZ in {32, 64, 128} (`..._supported` answers 1); otherwise MDT_ERR_UNSUPPORTED.  fp32 MFMA. */
+int mdt_conv_stem_forward_supported(int OY, int OX, int OZ, int c_out, int k, int sy, int sx);
+int mdt_conv_stem_forward(const float *x_padded, const float *weight, const float *bias, float *out, int batch, int OY, int OX, int OZ,
+                          int c_out, int k, int sy, int sx, int YP, int XP, int ZP, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,6 +108,128 @@ __global__ __launch_bounds__(SW_THREADS) void conv_stem_wgrad_partial_kernel(SWP
     }
 }
 
+// ---- second form (k = 7, stride (2, 2), OZ in {32, 64, 128}, OX % 4 == 0): the B operand from an LDS image ------------------------
+// The gathers of the first form go through the vector memory pipe (one 64-lane gather per MFMA: 6-10 cache lines each) and hold
+// it at 36 % of the MFMA bound.  Here a workgroup stages the 7 x 13 input lines of four neighbouring output columns in LDS
+// (as csrc/conv_stem_fwd.hip does: 7 contiguous runs of the padded volume, by LDS-DMA), every wave takes ONE output column and
+// ALL 11 tap tiles (176 accumulator registers), so one dY fragment load and 11 ds_read_b32 (address = per-lane tap offset +
+// compile-time voxel offset) feed 11 MFMAs.  The four waves' sums are added through LDS in a fixed order at the end.
+constexpr int SL_K = 7, SL_T = 343, SL_NT = 11, SL_NX = 4, SL_COLS = 2 * (SL_NX - 1) + SL_K, SL_GS = 4;
+
+template <int OZ>
+__global__ __launch_bounds__(SW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_stem_wgrad_lds_kernel(SWParams p)
+{
+    constexpr int ZP = OZ + SL_K - 1;
+    constexpr int RS = SL_COLS * ZP;
+    constexpr int STEPS = OZ / 2, GROUPS = STEPS / SL_GS;
+    static_assert(GROUPS % 2 == 0 && SL_GS % 2 == 0, "buffer parities must be compile-time");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *img = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ch = lane & 31, kk = lane >> 5;
+    // per-lane B bases: the tap of this lane in tile n (as an offset inside the image of this wave's column) + the K-step's voxel parity
+    const float *bbase[SL_NT];
+#pragma unroll
+    for (int n = 0; n < SL_NT; ++n) {
+        int t = n * 32 + ch;
+        if (t > SL_T - 1) t = SL_T - 1;                     // columns past the last tap read a valid address; never stored
+        const int ky = t / (SL_K * SL_K), rem = t - ky * SL_K * SL_K;
+        const int kx = rem / SL_K, kz = rem - kx * SL_K;
+        bbase[n] = img + ky * RS + (2 * wave + kx) * ZP + kz + kk;
+    }
+    const unsigned offa = (unsigned)(kk * p.Co + min(ch, p.Co - 1));
+    f32x16 acc[SL_NT];
+#pragma unroll
+    for (int n = 0; n < SL_NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+
+    const int oxg_n = p.OX / SL_NX;
+    const int passes = (int)(p.rows / SL_NX);
+    const int per = (passes + gridDim.x - 1) / gridDim.x;
+    const int pass_end = min(passes, (int)(blockIdx.x + 1) * per);
+    for (int pass = blockIdx.x * per; pass < pass_end; ++pass) {
+        const int oxg = pass % oxg_n;
+        const int r2 = pass / oxg_n;
+        const int oy = r2 % p.OY, b = r2 / p.OY;
+        __syncthreads();
+        {
+            constexpr int CH = (RS + 63) / 64;
+            const float *src0 = p.xp + (((long long)b * p.YP + (long long)p.sy * oy) * p.XP + (long long)p.sx * SL_NX * oxg) * ZP;
+            const long long ystride = (long long)p.XP * ZP;
+            for (int c = wave; c < SL_K * CH; c += SW_THREADS / 64) {
+                const int ky = c / CH, cc = c - ky * CH;
+                if (cc * 64 + lane < RS)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + ky * ystride + cc * 64 + lane),
+                                                     (__attribute__((address_space(3))) void *)(img + ky * RS + cc * 64), 4, 0, 0);
+            }
+        }
+        __syncthreads();
+        const float *arow = p.dy + ((((long long)b * p.OY + oy) * p.OX + oxg * SL_NX + wave) * OZ) * p.Co + offa;
+        float a[2][SL_GS], bv[2][SL_NT];
+        auto load_a = [&](int grp, float (&d)[SL_GS]) {
+#pragma unroll
+            for (int u = 0; u < SL_GS; ++u) d[u] = arow[(grp * SL_GS + u) * 2 * p.Co];
+        };
+        auto load_b = [&](int step, float (&d)[SL_NT]) {
+#pragma unroll
+            for (int n = 0; n < SL_NT; ++n) d[n] = bbase[n][2 * step];
+        };
+        load_a(0, a[0]);
+        load_b(0, bv[0]);
+        // two groups (8 K-steps, 88 MFMAs) per trip: buffer parities are compile-time, the code stays well inside the I-cache
+#pragma unroll 1
+        for (int g2 = 0; g2 < GROUPS; g2 += 2) {
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int grp = g2 + gg;
+                if (grp + 1 < GROUPS) load_a(grp + 1, a[(gg + 1) & 1]);
+#pragma unroll
+                for (int u = 0; u < SL_GS; ++u) {
+                    const int step = grp * SL_GS + u;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (step + 1 < STEPS) load_b(step + 1, bv[(u + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < SL_NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gg][u], bv[u & 1][n], acc[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // add the four waves' sums in a fixed order (wave 0 + 1 + 2 + 3) through LDS, then wave 0 writes the workgroup's partial
+    float *red = lds;                                       // [SL_NT * 16][64]
+    for (int w = 1; w < SW_THREADS / 64; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int n = 0; n < SL_NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(n * 16 + r) * 64 + lane] = acc[n][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int n = 0; n < SL_NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] = acc[n][r] + red[(n * 16 + r) * 64 + lane];
+        }
+    }
+    if (wave == 0) {
+        float *out = p.ws + (size_t)blockIdx.x * p.Co * p.T;
+#pragma unroll
+        for (int n = 0; n < SL_NT; ++n) {
+            const int t = n * 32 + ch;
+            if (t < p.T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (co < p.Co) out[(size_t)co * p.T + t] = acc[n][r];
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conv_stem_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dW, int n_elem, int n_part)
 {
     __shared__ float part[16][17];
@@ -147,6 +269,26 @@ inline int sw_wgs()
     return n;
 }
 
+// LDS-image form: one workgroup per resident slot (the register count decides how many fit a CU), one partial per workgroup
+template <int OZ>
+long long launch_lds(const SWParams &p, hipStream_t s)
+{
+    constexpr size_t img = (size_t)SL_K * SL_COLS * (OZ + SL_K - 1) * sizeof(float), red = (size_t)SL_NT * 16 * 64 * sizeof(float);
+    constexpr size_t lds = img > red ? img : red;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        (void)hipFuncSetAttribute((const void *)conv_stem_wgrad_lds_kernel<OZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_stem_wgrad_lds_kernel<OZ>, SW_THREADS, lds) != hipSuccess || n < 1) n = 1;
+        (void)hipGetLastError();
+        per_cu = n > 2 ? 2 : n;
+    }
+    long long wgs = (long long)per_cu * (sw_wgs() / 2);
+    if (wgs > p.rows / SL_NX) wgs = p.rows / SL_NX;
+    hipLaunchKernelGGL(conv_stem_wgrad_lds_kernel<OZ>, dim3((unsigned)wgs), dim3(SW_THREADS), lds, s, p);
+    return wgs;
+}
+
 }  // namespace
 
 extern "C" {
@@ -177,7 +319,13 @@ int mdt_conv_stem_wgrad(const float *grad_out, const float *x_padded, float *gra
     p.YP = YP; p.XP = XP; p.ZP = ZP; p.sy = sy; p.sx = sx; p.k = k; p.T = T; p.rows = rows;
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(conv_stem_wgrad_partial_kernel, dim3((unsigned)n_wg), dim3(SW_THREADS), 0, s, p);
+    static const bool use_lds = []() { const char *e = getenv("MDT_STEM_WGRAD"); return !(e && e[0] == 'v' && e[1] == '1'); }();
+    if (use_lds && k == SL_K && sy == 2 && sx == 2 && OX % SL_NX == 0 && ZP == OZ + SL_K - 1 && (OZ == 128 || OZ == 64 || OZ == 32)
+        && XP >= 2 * OX + SL_K - 2 && rows / SL_NX <= 0x7fffffffLL) {
+        n_wg = OZ == 128 ? launch_lds<128>(p, s) : OZ == 64 ? launch_lds<64>(p, s) : launch_lds<32>(p, s);
+    } else {
+        hipLaunchKernelGGL(conv_stem_wgrad_partial_kernel, dim3((unsigned)n_wg), dim3(SW_THREADS), 0, s, p);
+    }
     const int n_elem = c_out * T;
     hipLaunchKernelGGL(conv_stem_wgrad_reduce_kernel, dim3((unsigned)((n_elem + 15) / 16)), dim3(256), 0, s, p.ws, grad_weight, n_elem, (int)n_wg);
     const hipError_t e = hipGetLastError();

@@ -255,7 +255,7 @@ class _ConvStride1(Function):
 STEM_WGRAD = True   # module switch (A/B: bench.py --stem-wgrad 0)
 
 
-def stem_weight_grad(gy, x, w, stride):
+def stem_weight_grad(gy, x, w, stride, xp=None):
     """Weight gradient of a one-channel k x k x k convolution with stride (sy, sx, 1) and padding k // 2 on the fp32-MFMA kernel of
     csrc/conv_stem_wgrad.hip (MIOpen: 3.7 ms for the 7x7x7 stem on 8 x 128^3).  None when the layer is not of that form."""
     if not (STEM_WGRAD and gy.is_cuda and gy.dtype == torch.float32 and x.dtype == torch.float32 and x.dim() == 5 and int(x.shape[1]) == 1
@@ -271,7 +271,8 @@ def stem_weight_grad(gy, x, w, stride):
         return None
     if not gy.is_contiguous(memory_format=torch.channels_last_3d):
         gy = gy.contiguous(memory_format=torch.channels_last_3d)
-    xp = F.pad(x.reshape(B, int(x.shape[2]), int(x.shape[3]), int(x.shape[4])), (pad, pad, pad, pad, pad, pad)).contiguous()
+    if xp is None:      # (the forward kernel's padded copy is passed on when it ran)
+        xp = F.pad(x.reshape(B, int(x.shape[2]), int(x.shape[3]), int(x.shape[4])), (pad, pad, pad, pad, pad, pad)).contiguous()
     L = _lib.lib()
     wsb = L.mdt_conv_stem_wgrad_workspace_bytes(cout, k)
     ws = _workspace(wsb, gy.device)
@@ -281,6 +282,33 @@ def stem_weight_grad(gy, x, w, stride):
     if rc != 0:
         _lib.check(rc, "mdt_conv_stem_wgrad")
     return gw.view(w.shape)
+
+
+STEM_FWD = True     # module switch (A/B: bench.py --stem-fwd 0)
+
+
+def stem_forward(x, w, bias=None, relu=False):
+    """The one-channel 7 x 7 x 7 stride-(2, 2, 1) stem on the fp32-MFMA kernel of csrc/conv_stem_fwd.hip (MIOpen: 1.96 ms in
+    space-to-depth form on 8 x 128^3).  Returns (out channels-last, padded input) or None when the layer is not of that form."""
+    if not (STEM_FWD and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 5 and int(x.shape[1]) == 1
+            and int(w.shape[1]) == 1 and tuple(int(v) for v in w.shape[2:]) == (7, 7, 7) and _on_current_device(x)):
+        return None
+    B, _, Y, X, Z = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    if Y % 2 or X % 2:
+        return None
+    OY, OX = Y // 2, X // 2
+    L = _lib.lib()
+    if not L.mdt_conv_stem_forward_supported(OY, OX, Z, cout, 7, 2, 2):
+        return None
+    xp = F.pad(x.reshape(B, Y, X, Z), (3, 3, 3, 3, 3, 3)).contiguous()
+    out = torch.empty((B, cout, OY, OX, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+    wc = w.detach().reshape(cout, 343).contiguous()
+    rc = L.mdt_conv_stem_forward(xp.data_ptr(), wc.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), B, OY, OX, Z,
+                                 cout, 7, 2, 2, Y + 6, X + 6, Z + 6, 1 if relu else 0, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        _lib.check(rc, "mdt_conv_stem_forward")
+    return out, xp
 
 
 class _ConvStem221(Function):
@@ -293,6 +321,12 @@ class _ConvStem221(Function):
 
     @staticmethod
     def forward(ctx, x, w):
+        ctx.xp = None
+        r = stem_forward(x, w)
+        if r is not None:       # own kernel (the padded copy serves the weight gradient too)
+            ctx.save_for_backward(x, w)
+            ctx.xp = r[1]
+            return r[0]
         ctx.save_for_backward(x, w)
         k = int(w.shape[2])
         p = k // 2
@@ -309,7 +343,8 @@ class _ConvStem221(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         p = int(w.shape[2]) // 2
-        gw = stem_weight_grad(gy, x, w, (2, 2, 1)) if ctx.needs_input_grad[1] else None
+        gw = stem_weight_grad(gy, x, w, (2, 2, 1), xp=ctx.xp) if ctx.needs_input_grad[1] else None
+        ctx.xp = None
         need_w = bool(ctx.needs_input_grad[1]) and gw is None
         gx = None
         if ctx.needs_input_grad[0] or need_w:

@@ -300,11 +300,13 @@ def test_conv3x3x3_small_inside_autograd_matches_miopen(cuda):
 
 
 # ------------------------------------------------------------------ stem weight gradient (csrc/conv_stem_wgrad.hip)
-@pytest.mark.parametrize("case", [(2, 18, 7, (32, 32, 32)), (1, 18, 7, (16, 24, 16)), (2, 5, 3, (12, 8, 8)), (1, 32, 5, (8, 8, 24))],
+@pytest.mark.parametrize("case", [(2, 18, 7, (32, 32, 32)), (1, 18, 7, (16, 24, 16)), (2, 5, 3, (12, 8, 8)), (1, 32, 5, (8, 8, 24)),
+                                  (1, 18, 7, (8, 16, 128)), (2, 7, 7, (16, 8, 64)), (3, 32, 7, (4, 24, 128)), (1, 18, 7, (12, 12, 64))],
                          ids=lambda c: str(c))
 def test_stem_wgrad_vs_aten(case, cuda):
     """mdt_conv_stem_wgrad == aten.convolution_backward's weight gradient of a one-channel k^3 convolution with stride (2, 2, 1),
-    pad k // 2 (1e-5 of the summed magnitudes; deterministic)"""
+    pad k // 2 (1e-5 of the summed magnitudes; deterministic).  k = 7 with OZ in {32, 64, 128} and OX % 4 == 0 takes the LDS-image
+    kernel, everything else (OZ = 16, k = 3 / 5, OX = 6) the gather kernel"""
     from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
     B, cout, k, sp = case
     g = torch.Generator(device=cuda).manual_seed(cout * 10 + k)
@@ -322,6 +324,74 @@ def test_stem_wgrad_vs_aten(case, cuda):
     err = (got.double() - want).abs()
     assert torch.all(err <= 1e-5 * mag + 1e-12), float((err / mag).max())
     assert torch.equal(got, fe.stem_weight_grad(gy, x, w, (2, 2, 1)))
+
+
+# ------------------------------------------------------------------ stem forward (csrc/conv_stem_fwd.hip)
+STEM_FWD_CASES = [(2, 18, (32, 32, 128)), (1, 18, (16, 24, 64)), (2, 7, (8, 8, 32)), (1, 32, (12, 16, 128)), (3, 18, (6, 40, 64))]
+
+
+@pytest.mark.parametrize("case", STEM_FWD_CASES, ids=[str(c) for c in STEM_FWD_CASES])
+@pytest.mark.parametrize("epilogue", ["plain", "bias", "bias_relu"])
+def test_stem_forward_vs_conv3d(case, epilogue, cuda):
+    """mdt_conv_stem_forward == F.conv3d(x, w, bias, stride (2, 2, 1), padding 3) (+ ReLU) of the one-channel 7^3 stem, to
+    1e-5 of the summed magnitudes (fp32 MFMA, 343 terms in a fixed order: deterministic); borders on all six faces are in every case"""
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    B, cout, sp = case
+    g = torch.Generator(device=cuda).manual_seed(cout + sp[0])
+    x = torch.randn((B, 1) + sp, device=cuda, generator=g)
+    w = torch.randn((cout, 1, 7, 7, 7), device=cuda, generator=g) * 0.1
+    bias = torch.randn(cout, device=cuda, generator=g) if epilogue != "plain" else None
+    r = fe.stem_forward(x, w, bias, epilogue == "bias_relu")
+    assert r is not None, "shape should be supported"
+    got, xp = r
+    assert got.shape == (B, cout, sp[0] // 2, sp[1] // 2, sp[2]) and got.is_contiguous(memory_format=torch.channels_last_3d)
+    assert xp.shape == (B, sp[0] + 6, sp[1] + 6, sp[2] + 6)
+    want = F.conv3d(x.double(), w.double(), bias.double() if bias is not None else None, (2, 2, 1), 3)
+    if epilogue == "bias_relu":
+        want = torch.relu(want)
+    mag = F.conv3d(x.double().abs(), w.double().abs(), bias.double().abs() if bias is not None else None, (2, 2, 1), 3)
+    err = (got.double() - want).abs()
+    assert torch.all(err <= 1e-5 * mag + 1e-12), float((err / mag).max())
+    assert torch.equal(got, fe.stem_forward(x, w, bias, epilogue == "bias_relu")[0])
+
+
+def test_stem_forward_inside_autograd(cuda):
+    """_ConvStem221 on a supported shape runs the forward kernel and hands its padded copy to the weight-gradient kernel: output and
+    weight gradient equal to the strided convolution's; with the switch off the space-to-depth path gives the same"""
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    g = torch.Generator(device=cuda).manual_seed(3)
+    x0 = torch.randn((2, 1, 16, 16, 64), device=cuda, generator=g)
+    w0 = torch.randn((18, 1, 7, 7, 7), device=cuda, generator=g) * 0.05
+    gy = torch.randn((2, 18, 8, 8, 64), device=cuda, generator=g)
+    res = []
+    for on in (True, False):
+        fe.STEM_FWD = on
+        try:
+            w = w0.clone().requires_grad_(True)
+            y = fe._ConvStem221.apply(x0, w)
+            y.backward(gy)
+            res.append((y.detach().clone(), w.grad.clone()))
+        finally:
+            fe.STEM_FWD = True
+    w2 = w0.clone().requires_grad_(True)
+    y2 = F.conv3d(x0, w2, None, (2, 2, 1), 3)
+    y2.backward(gy)
+    for y, gw in res:
+        assert torch.allclose(y, y2, rtol=1e-4, atol=1e-4 * float(y2.abs().max()))
+        assert torch.allclose(gw, w2.grad, rtol=1e-4, atol=1e-4 * float(w2.grad.abs().max()))
+
+
+def test_stem_forward_unsupported_shapes_fall_back(cuda):
+    from medicaldetectiontoolkit_amd import _lib
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    L = _lib.lib()
+    assert L.mdt_conv_stem_forward_supported(64, 64, 128, 18, 7, 2, 2) == 1
+    assert L.mdt_conv_stem_forward_supported(64, 64, 96, 18, 7, 2, 2) == 0      # OZ not in {32, 64, 128}
+    assert L.mdt_conv_stem_forward_supported(64, 62, 128, 18, 7, 2, 2) == 0     # OX % 4
+    assert L.mdt_conv_stem_forward_supported(64, 64, 128, 40, 7, 2, 2) == 0
+    assert L.mdt_conv_stem_forward_supported(64, 64, 128, 18, 5, 2, 2) == 0
+    x = torch.randn((1, 1, 16, 16, 20), device=cuda)
+    assert fe.stem_forward(x, torch.randn((18, 1, 7, 7, 7), device=cuda)) is None
 
 
 @pytest.mark.parametrize("case", CONV3_CASES, ids=[str(c) for c in CONV3_CASES])

@@ -11,8 +11,10 @@ from collections import defaultdict
 
 def category(n):
     if "crop_" in n or "nms_" in n or "bias_act" in n or "bias_grad" in n or "anchor" in n or "decode" in n or "wbc" in n \
-            or "maxpool_k3" in n or "filter_flip" in n or "match_pass" in n:
+            or "maxpool_k3" in n or "filter_flip" in n or "match_pass" in n or "upsample2x_" in n or "zero_fill_kernel" in n or "nms2to3d" in n:
         return "mdt_hip (this repo)"
+    if "conv1x1_wgrad" in n or "conv3x3x3_small" in n or "conv_stem_wgrad" in n:
+        return "mdt_hip convolution kernels (this repo, fp32 MFMA)"
     if n.startswith("_ZN2ck") or "ck::" in n or "miopen" in n.lower() or "Cijk" in n or "gemm" in n.lower() or "batched_transpose" in n \
             or "naive_conv" in n or "SubTensor" in n or "Im2" in n or "Col2" in n or "igemm" in n:
         return "MIOpen / CK / GEMM convolutions"
@@ -33,7 +35,24 @@ def short(n):
     return re.sub(r"<.*", "", n)[:90]
 
 
+def recategorize(path, steps):
+    """Rebuild the per-category lines of an existing summary from its own per-kernel rows (after `category` learnt new kernel names)."""
+    text = open(path).read().splitlines()
+    head = [l for l in text if l.startswith("# window") or l.startswith("# idle") or l.startswith("# gap")]
+    body = text[text.index("Name,Calls,TotalDurationNs,AverageNs,Percentage"):]
+    cat = defaultdict(float)
+    for r in csv.DictReader(body):
+        cat[category(r["Name"])] += float(r["TotalDurationNs"])
+    tot = sum(cat.values())
+    lines = head[:1] + ["# %-52s %8.2f ms/step  %5.1f %% of kernel time" % (c, v / 1e6 / steps, 100.0 * v / tot)
+                        for c, v in sorted(cat.items(), key=lambda x: -x[1])] + head[1:] + body
+    open(path, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:12]))
+
+
 def main():
+    if sys.argv[1] == "--recategorize":      # python tools/steady_state.py --recategorize <summary.csv> <steps>
+        return recategorize(sys.argv[2], int(sys.argv[3]))
     path, steps, ms = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
     rows = list(csv.DictReader(open(path)))
     ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
@@ -74,7 +93,7 @@ def main():
     lines = ["# window: last %d timed steps = %.1f ms; kernels %d; GPU busy %.1f ms (%.1f %%); summed kernel time %.1f ms"
              % (steps, span / 1e6, len(win), busy / 1e6, 100.0 * busy / span, tot / 1e6)]
     for c, v in sorted(cat.items(), key=lambda x: -x[1]):
-        lines.append("# %-40s %8.2f ms/step  %5.1f %% of kernel time" % (c, v / 1e6 / steps, 100.0 * v / tot))
+        lines.append("# %-52s %8.2f ms/step  %5.1f %% of kernel time" % (c, v / 1e6 / steps, 100.0 * v / tot))
     lines += gap_lines
     lines.append("Name,Calls,TotalDurationNs,AverageNs,Percentage")
     for k, (c, v) in sorted(per.items(), key=lambda x: -x[1][1]):
