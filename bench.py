@@ -434,6 +434,7 @@ def main():
     t0 = time.time()
     for i in range(args.steps):
         training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+    host_issue = time.time() - t0      # the host has launched everything (it runs ahead of the GPU while the step is GPU-bound)
     barrier()
     elapsed = time.time() - t0
     prof, _roi_align_impl.PROFILE = _roi_align_impl.PROFILE, None
@@ -484,6 +485,7 @@ def main():
             "metric": "3D patches/sec (train), %s %s" % ("^3".join([str(patch[0]), ""]) if len(set(patch)) == 1 else "x".join(map(str, patch)),
                                                        "Mask R-CNN" if args.model == "mrcnn" else "Retina U-Net"), "value": round(patches / elapsed, 3), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host numpy batches, PCIe inclusive)" if args.host_batches else " (resident in HBM)"),
             "config": {"workload": "LIDC-shape 3D %s, %s fp32 patches, batch %d per GPU, random-init weights, Adam lr 1e-4" % (
                            "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),

@@ -609,8 +609,8 @@ class net(nn.Module):
         if "roi_masks_device" in batch:          # already resident in HBM (utils.synthetic_data.to_device)
             gt_masks = batch["roi_masks_device"]
         else:
-            masks_list = [torch.as_tensor(np.ascontiguousarray(m)) for m in batch["roi_masks"] if len(m) > 0]
-            gt_masks = mutils.upload(torch.cat(masks_list, 0), dev) if masks_list else None
+            # staged into pinned memory on a background thread while this thread launches the backbone; resolved below
+            gt_masks = mutils.StagedUpload([m for m in batch["roi_masks"] if len(m) > 0], dev)
 
         # all GT boxes / class ids go up in one pinned async copy BEFORE the backbone is launched: nothing in the step
         # waits for the stream afterwards, so the host keeps running ahead of the GPU through the glue
@@ -620,6 +620,8 @@ class net(nn.Module):
         # step (the reference runs it and drops the result)
         rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(
             img, with_masks=bool(is_validation and cf.return_masks_in_val))
+        if isinstance(gt_masks, mutils.StagedUpload):
+            gt_masks = gt_masks.get()
         (mrcnn_class_logits, mrcnn_pred_deltas, mrcnn_pred_mask, target_class_ids, mrcnn_target_deltas, target_mask,
          sample_proposals, s_valid, s_pos) = self.loss_samples_forward(gt_class_ids, gt_boxes, gt_masks, B, gt_dev=gt_dev)
 

@@ -287,20 +287,26 @@ def stem_weight_grad(gy, x, w, stride, xp=None):
 STEM_FWD = True     # module switch (A/B: bench.py --stem-fwd 0)
 
 
-def stem_forward(x, w, bias=None, relu=False):
-    """The one-channel 7 x 7 x 7 stride-(2, 2, 1) stem on the fp32-MFMA kernel of csrc/conv_stem_fwd.hip (MIOpen: 1.96 ms in
-    space-to-depth form on 8 x 128^3).  Returns (out channels-last, padded input) or None when the layer is not of that form."""
+def stem_forward_supported(x, w):
+    """the one-channel 7 x 7 x 7 stride-(2, 2, 1) pad-3 stem in a shape csrc/conv_stem_fwd.hip handles"""
     if not (STEM_FWD and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 5 and int(x.shape[1]) == 1
-            and int(w.shape[1]) == 1 and tuple(int(v) for v in w.shape[2:]) == (7, 7, 7) and _on_current_device(x)):
+            and int(w.shape[1]) == 1 and tuple(int(v) for v in w.shape[2:]) == (7, 7, 7) and _on_current_device(x)
+            and not torch.is_autocast_enabled()):
+        return False
+    Y, X, Z = (int(v) for v in x.shape[2:])
+    return Y % 2 == 0 and X % 2 == 0 and bool(_lib.lib().mdt_conv_stem_forward_supported(Y // 2, X // 2, Z, int(w.shape[0]), 7, 2, 2))
+
+
+def stem_forward(x, w, bias=None, relu=False):
+    """The one-channel 7 x 7 x 7 stride-(2, 2, 1) stem on the fp32-MFMA kernel of csrc/conv_stem_fwd.hip (810 us + a 35 us padding
+    copy on 8 x 128^3; MIOpen: 1976 us in space-to-depth form), optionally with the bias add and the ReLU in its epilogue.
+    Returns (out channels-last, padded input) or None when the layer is not of that form."""
+    if not stem_forward_supported(x, w):
         return None
     B, _, Y, X, Z = (int(v) for v in x.shape)
     cout = int(w.shape[0])
-    if Y % 2 or X % 2:
-        return None
     OY, OX = Y // 2, X // 2
     L = _lib.lib()
-    if not L.mdt_conv_stem_forward_supported(OY, OX, Z, cout, 7, 2, 2):
-        return None
     xp = F.pad(x.reshape(B, Y, X, Z), (3, 3, 3, 3, 3, 3)).contiguous()
     out = torch.empty((B, cout, OY, OX, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
     wc = w.detach().reshape(cout, 343).contiguous()
@@ -355,6 +361,44 @@ class _ConvStem221(Function):
         return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None)
 
 
+class _ConvStemBiasReLU(Function):
+    """relu(stem(x) + bias) with the bias add and the ReLU in the convolution kernel's epilogue (no separate pass over the
+    302 MB stem output); backward = the fused ReLU-mask / bias-gradient pass of csrc/epilogue.hip + the stem weight gradient"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        y, xp = stem_forward(x, w, bias.detach(), True)
+        ctx.save_for_backward(x, w, y)
+        ctx.xp = xp
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        mf = torch.channels_last_3d
+        if not gy.is_contiguous(memory_format=mf):
+            gy = gy.contiguous(memory_format=mf)
+        L = _lib.lib()
+        n, C = gy.numel(), int(gy.shape[1])
+        g = torch.empty_like(gy)
+        gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
+        ws = _workspace(4096 * C * 4 + 256, gy.device)
+        rc = L.mdt_bias_act_backward(g.data_ptr(), gy.data_ptr(), y.data_ptr(), gbias.data_ptr(), n, C, 1, 1, ws.data_ptr(), ws.numel(),
+                                     torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            _lib.check(rc, "mdt_bias_act_backward")
+        xp, ctx.xp = ctx.xp, None
+        gw = stem_weight_grad(g, x, w, (2, 2, 1), xp=xp) if ctx.needs_input_grad[1] else None
+        need_w = bool(ctx.needs_input_grad[1]) and gw is None
+        gx = None
+        if ctx.needs_input_grad[0] or need_w:
+            gx, gw2, _ = torch.ops.aten.convolution_backward(g, x, w, None, [2, 2, 1], [3, 3, 3], [1, 1, 1], False, [0, 0, 0], 1,
+                                                             [bool(ctx.needs_input_grad[0]), need_w, False])
+            if need_w:
+                gw = gw2
+        return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), gbias
+
+
 def _unit(t):
     return all(int(v) == 1 for v in t)
 
@@ -396,7 +440,11 @@ class ConvBiasReLU(nn.Sequential):
     """Sequential(conv, ReLU) of the reference's generator with the fused epilogue; keys '0.weight' / '0.bias'"""
 
     def forward(self, x, residual=None):
-        return bias_act(_conv(self[0], x), self[0].bias, residual, True)
+        conv = self[0]
+        if residual is None and ENABLED and STEM_SPACE_TO_DEPTH and conv.bias is not None and isinstance(conv, nn.Conv3d) and conv.groups == 1 \
+                and _unit(conv.dilation) and not isinstance(conv.padding, str) and _is_stem221(conv, x) and stem_forward_supported(x, conv.weight):
+            return _ConvStemBiasReLU.apply(x, conv.weight, conv.bias)
+        return bias_act(_conv(conv, x), conv.bias, residual, True)
 
 
 class _MaxPoolK3S221(Function):

@@ -67,14 +67,63 @@ def generate_pyramid_anchors(logger, cf, device=None, return_f32=False):
     return anchors
 
 
+_STAGE_POOL = None
+
+
+def _stage_pool():
+    global _STAGE_POOL
+    if _STAGE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _STAGE_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="mdt-stage")
+    return _STAGE_POOL
+
+
+def _fill_pinned(parts):
+    """ONE pinned block (torch's caching host allocator) holding the CPU tensors `parts` stacked along dim 0 -- no intermediate
+    torch.cat copy; copy_ of a large contiguous tensor is already spread over the intra-op threads and releases the GIL."""
+    n0 = sum(int(t.shape[0]) for t in parts)
+    pinned = torch.empty((n0,) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, pin_memory=True)
+    at = 0
+    for t in parts:
+        pinned[at:at + int(t.shape[0])].copy_(t)
+        at += int(t.shape[0])
+    return pinned
+
+
+def _as_cpu_tensor(a):
+    return a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+
+
 def upload(array_or_tensor, device):
     """host numpy array / CPU tensor -> device through PINNED staging memory with an asynchronous copy: a pageable
     upload waits for the stream (the host loses its run-ahead) and moves at a fraction of the PCIe rate.  The pinned block
     comes from torch's caching host allocator, which also keeps it alive until the copy has executed."""
-    t = array_or_tensor if torch.is_tensor(array_or_tensor) else torch.from_numpy(np.ascontiguousarray(array_or_tensor))
+    t = _as_cpu_tensor(array_or_tensor)
     if t.device.type == "cpu" and torch.device(device).type == "cuda":
         t = t.pin_memory()
     return t.to(device, non_blocking=True)
+
+
+class StagedUpload(object):
+    """Upload whose host half (stacking `parts` along dim 0 into pinned memory) runs on a background thread while the caller
+    keeps launching kernels; `.get(device)` -- called on the caller's thread, i.e. on ITS current stream -- waits for the
+    staging and enqueues the asynchronous copy.  Used for the GT masks of a training batch, which the step needs only after
+    the backbone, the RPN and the proposal layer have been launched (models/mrcnn.py train_forward)."""
+
+    def __init__(self, parts, device):
+        self.device = torch.device(device)
+        parts = [_as_cpu_tensor(p) for p in parts]
+        self.parts = parts
+        self.future = None
+        if parts and self.device.type == "cuda":
+            self.future = _stage_pool().submit(_fill_pinned, parts)
+
+    def get(self):
+        if not self.parts:
+            return None
+        if self.future is not None:
+            return self.future.result().to(self.device, non_blocking=True)
+        return torch.cat(self.parts, 0).to(self.device)
 
 
 # --------------------------------------------------------------------------- anchor <-> GT matching

@@ -381,6 +381,37 @@ def test_stem_forward_inside_autograd(cuda):
         assert torch.allclose(gw, w2.grad, rtol=1e-4, atol=1e-4 * float(w2.grad.abs().max()))
 
 
+def test_stem_conv_bias_relu_module_fused(cuda):
+    """ConvBiasReLU over the stem (models/backbone.py C1) takes the convolution kernel's bias + ReLU epilogue: output, weight and
+    bias gradients equal to relu(conv3d(x) + b) on torch ops; the switch off gives the unfused path with the same results"""
+    import torch.nn as nn
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    g = torch.Generator(device=cuda).manual_seed(11)
+    mod = fe.ConvBiasReLU(fe.ConvBias3d(1, 18, kernel_size=7, padding=3, stride=(2, 2, 1)), nn.ReLU(inplace=True)).to(cuda)
+    x = torch.randn((2, 1, 16, 24, 64), device=cuda, generator=g)
+    gy = torch.randn((2, 18, 8, 12, 64), device=cuda, generator=g)
+    w0, b0 = mod[0].weight.detach().clone(), mod[0].bias.detach().clone()
+    wr, br = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    yr = torch.relu(F.conv3d(x, wr, br, (2, 2, 1), 3))
+    yr.backward(gy)
+    for on in (True, False):
+        fe.STEM_FWD = on
+        try:
+            mod.zero_grad()
+            y = mod(x)
+            assert (type(y.grad_fn).__name__ == "_ConvStemBiasReLUBackward") == on
+            y.backward(gy)
+        finally:
+            fe.STEM_FWD = True
+        assert torch.allclose(y, yr, rtol=1e-4, atol=1e-4 * float(yr.abs().max()))
+        assert torch.allclose(mod[0].weight.grad, wr.grad, rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()))
+        assert torch.allclose(mod[0].bias.grad, br.grad, rtol=1e-4, atol=1e-4 * float(br.grad.abs().max()))
+    with torch.no_grad():
+        assert torch.allclose(mod(x), yr, rtol=1e-4, atol=1e-4 * float(yr.abs().max()))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not fe.stem_forward_supported(x, mod[0].weight)
+
+
 def test_stem_forward_unsupported_shapes_fall_back(cuda):
     from medicaldetectiontoolkit_amd import _lib
     from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe

@@ -40,3 +40,16 @@ rows.sort(reverse=True)
 print("self device time per step (us), calls per step, op, input shapes")
 for r in rows[:70]:
     print("%9.1f  %6.1f  %-38s %s" % r)
+
+# the glue: ops whose launches average < 40 us, grouped by op name over all shapes ("torch elementwise + fills")
+small = {}
+tot_small = 0.0
+for dt, cnt, key, shapes in rows:
+    if cnt > 0 and dt / cnt < 40.0 and key.startswith("aten::"):
+        a = small.setdefault(key, [0.0, 0.0])
+        a[0] += dt
+        a[1] += cnt
+        tot_small += dt
+print("\nsmall aten ops (< 40 us per call), by name: us per step, calls per step   [total %.0f us per step]" % tot_small)
+for key, (dt, cnt) in sorted(small.items(), key=lambda kv: -kv[1][0])[:40]:
+    print("%9.1f  %6.1f  %s" % (dt, cnt, key))
