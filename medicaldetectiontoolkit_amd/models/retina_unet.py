@@ -212,7 +212,7 @@ class net(nn.Module):
         loss = batch_class_loss + batch_bbox_loss
         seg_dice = seg_ce = None
         if seg_logits is not None:
-            var_seg = mutils.upload(batch["seg"], dev).long()
+            var_seg = mutils.upload(batch["seg"], dev, channel="seg").long()
             ohe = F.one_hot(var_seg[:, 0], cf.num_seg_classes).movedim(-1, 1).float()
             seg_dice = 1 - batch_dice(F.softmax(seg_logits, dim=1), ohe)
             seg_ce = F.cross_entropy(seg_logits, var_seg[:, 0])

@@ -78,11 +78,57 @@ def _stage_pool():
     return _STAGE_POOL
 
 
-def _fill_pinned(parts):
-    """ONE pinned block (torch's caching host allocator) holding the CPU tensors `parts` stacked along dim 0 -- no intermediate
-    torch.cat copy; copy_ of a large contiguous tensor is already spread over the intra-op threads and releases the GIL."""
+class PinnedStager(object):
+    """A ring of persistent pinned host buffers for ONE upload channel (the image of a batch, its GT masks, its seg map).
+    torch's caching host allocator hands a block out again only once the copy that used it has EXECUTED; a host that runs a step
+    or more ahead of the GPU therefore gets a fresh hipHostMalloc (page-locking 67 MB: 10-20 ms, plus the implicit device
+    synchronisation of hipHostFree) on every step -- measured 100-400 ms of host time per step with numpy batches
+    (profiles/r03_host_issue_probe.json).  Here a slot is reused after waiting for ITS OWN last copy (`depth` steps back), so the
+    host never runs more than `depth` uploads ahead and never allocates in steady state."""
+
+    def __init__(self, depth=3):
+        self.slots = [None] * depth
+        self.events = [None] * depth
+        self.at = 0
+
+    def acquire(self, nbytes):
+        k = self.at
+        self.at = (k + 1) % len(self.slots)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+            self.events[k] = None
+        buf = self.slots[k]
+        if buf is None or buf.numel() < nbytes:
+            buf = self.slots[k] = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, pin_memory=True)
+        return k, buf[:nbytes]
+
+    def release(self, k):
+        """call after the asynchronous copy out of slot k has been enqueued (records on the current stream)"""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+
+
+_STAGERS = {}
+
+
+def _stager(device, channel):
+    key = (str(torch.device(device)), channel)
+    st = _STAGERS.get(key)
+    if st is None:
+        st = _STAGERS[key] = PinnedStager()
+    return st
+
+
+def _as_cpu_tensor(a):
+    return a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _stack_into(raw, parts):
+    """the CPU tensors `parts` stacked along dim 0 into the pinned byte buffer `raw` (no intermediate torch.cat copy; copy_ of a
+    large contiguous tensor is spread over the intra-op threads and releases the GIL)"""
     n0 = sum(int(t.shape[0]) for t in parts)
-    pinned = torch.empty((n0,) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, pin_memory=True)
+    pinned = raw.view(parts[0].dtype).view((n0,) + tuple(parts[0].shape[1:]))
     at = 0
     for t in parts:
         pinned[at:at + int(t.shape[0])].copy_(t)
@@ -90,40 +136,55 @@ def _fill_pinned(parts):
     return pinned
 
 
-def _as_cpu_tensor(a):
-    return a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+_SMALL_UPLOAD = 1 << 20
 
 
-def upload(array_or_tensor, device):
+def upload(array_or_tensor, device, channel="data"):
     """host numpy array / CPU tensor -> device through PINNED staging memory with an asynchronous copy: a pageable
-    upload waits for the stream (the host loses its run-ahead) and moves at a fraction of the PCIe rate.  The pinned block
-    comes from torch's caching host allocator, which also keeps it alive until the copy has executed."""
+    upload waits for the stream (the host loses its run-ahead) and moves at a fraction of the PCIe rate.  Bulky arrays go
+    through the persistent ring of their `channel` (PinnedStager); small ones through torch's caching host allocator."""
     t = _as_cpu_tensor(array_or_tensor)
-    if t.device.type == "cpu" and torch.device(device).type == "cuda":
-        t = t.pin_memory()
-    return t.to(device, non_blocking=True)
+    if t.device.type != "cpu" or torch.device(device).type != "cuda":
+        return t.to(device, non_blocking=True)
+    nbytes = t.numel() * t.element_size()
+    if nbytes < _SMALL_UPLOAD or t.dim() == 0:
+        return t.pin_memory().to(device, non_blocking=True)
+    st = _stager(device, channel)
+    k, raw = st.acquire(nbytes)
+    d = _stack_into(raw, [t.contiguous()]).to(device, non_blocking=True)
+    st.release(k)
+    return d
 
 
 class StagedUpload(object):
     """Upload whose host half (stacking `parts` along dim 0 into pinned memory) runs on a background thread while the caller
-    keeps launching kernels; `.get(device)` -- called on the caller's thread, i.e. on ITS current stream -- waits for the
-    staging and enqueues the asynchronous copy.  Used for the GT masks of a training batch, which the step needs only after
-    the backbone, the RPN and the proposal layer have been launched (models/mrcnn.py train_forward)."""
+    keeps launching kernels; `.get()` -- called on the caller's thread, i.e. on ITS current stream -- waits for the staging
+    and enqueues the asynchronous copy.  Used for the GT masks of a training batch, which the step needs only after the
+    backbone, the RPN and the proposal layer have been launched (models/mrcnn.py train_forward)."""
 
-    def __init__(self, parts, device):
+    def __init__(self, parts, device, channel="masks"):
         self.device = torch.device(device)
-        parts = [_as_cpu_tensor(p) for p in parts]
-        self.parts = parts
-        self.future = None
-        if parts and self.device.type == "cuda":
-            self.future = _stage_pool().submit(_fill_pinned, parts)
+        self.parts = [_as_cpu_tensor(p).contiguous() for p in parts]
+        self.future = self.stager = None
+        if self.parts and self.device.type == "cuda":
+            self.stager = _stager(self.device, channel)
+            nbytes = sum(t.numel() * t.element_size() for t in self.parts)
+            self.future = _stage_pool().submit(self._stage, nbytes)
+
+    def _stage(self, nbytes):
+        with torch.cuda.device(self.device):       # the current device is per thread: a pool thread starts on device 0
+            k, raw = self.stager.acquire(nbytes)
+            return k, _stack_into(raw, self.parts)
 
     def get(self):
         if not self.parts:
             return None
-        if self.future is not None:
-            return self.future.result().to(self.device, non_blocking=True)
-        return torch.cat(self.parts, 0).to(self.device)
+        if self.future is None:
+            return torch.cat(self.parts, 0).to(self.device)
+        k, pinned = self.future.result()
+        d = pinned.to(self.device, non_blocking=True)
+        self.stager.release(k)
+        return d
 
 
 # --------------------------------------------------------------------------- anchor <-> GT matching
