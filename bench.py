@@ -298,6 +298,9 @@ def rccl_world1_selftest(net, opt, batch, dev, steps=3):
     dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, device_id=dev)
     try:
         sync = training.FlatGradAllReduce(net, force=True)
+        if isinstance(opt, training.FlatAdam):      # its gradient views must be the collective's buffer: a fresh one over `sync`
+            g = opt.param_groups[0]
+            opt = training.FlatAdam(net.parameters(), lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"], grad_sync=sync)
         res = net.train_forward(batch, monitor=False)
         sync.zero()
         sync.force = False
@@ -339,6 +342,7 @@ def main():
     ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the world-size-1 RCCL self-test after the timed loop")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra host-batch steps after the timed loop (profiling runs)")
     ap.add_argument("--fused-adam", type=int, default=0)
+    ap.add_argument("--flat-adam", type=int, default=1, help="1 (default): training.FlatAdam -- parameters, gradients and Adam moments in flat buffers, the update one launch of csrc/adam.hip; 0: torch.optim.Adam (A/B)")
     ap.add_argument("--fused-epilogue", type=int, default=1, help="1 (default): fused bias/residual/ReLU conv epilogues (csrc/epilogue.hip); 0: torch ops (A/B)")
     ap.add_argument("--conv-bwd-as-fwd", type=int, default=1, help="1 (default): input gradients of unit-stride convolutions as forward convolutions (utils/fused_epilogue._ConvStride1); 0: MIOpen backward-data (A/B)")
     ap.add_argument("--stem-s2d", type=int, default=1, help="1 (default): stem convolution forward in space-to-depth form (utils/fused_epilogue._ConvStem221); 0: as is (A/B)")
@@ -413,8 +417,8 @@ def main():
     torch.manual_seed(0)          # identical initial weights on every rank
     net = (mrcnn if args.model == "mrcnn" else retina_unet).net(cf, device=dev)
     torch.manual_seed(1000 + rank)
-    opt = training.build_optimizer(net, cf, fused=bool(args.fused_adam))
     sync = training.FlatGradAllReduce(net) if world > 1 else None
+    opt = training.build_optimizer(net, cf, fused=bool(args.fused_adam), flat=bool(args.flat_adam), grad_sync=sync)
     # rank-disjoint synthetic patch streams, generated before the timed region (the reference's loader runs in
     # background worker processes and is excluded from its own per-batch timing, exec.py:68-77)
     pool = [make_batch(patch, args.batch, seed=1000 * rank + i) for i in range(3)]

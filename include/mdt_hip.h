@@ -426,6 +426,13 @@ int mdt_conv_stem_forward_supported(int OY, int OX, int OZ, int c_out, int k, in
 int mdt_conv_stem_forward(const float *x_padded, const float *weight, const float *bias, float *out, int batch, int OY, int OX, int OZ,
                           int c_out, int k, int sy, int sx, int YP, int XP, int ZP, int relu, void *stream);
 
+/* ---- Adam over flat fp32 buffers (csrc/adam.hip) ------------------------------------------------------------------------------
+ * One step of torch.optim.Adam (exec.py:39: Adam(lr = cf.learning_rate[0], weight_decay = cf.weight_decay); no amsgrad) for n
+ * parameters whose values, gradients and moment estimates are four flat arrays: step >= 1 is the number of this update (bias
+ * corrections 1 - beta^step), weight_decay is the L2 term added to the gradient.  In place on param / exp_avg / exp_avg_sq. */
+int mdt_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, long long step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "mdt_conv3x3x3_small_forward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mdt_conv_stem_wgrad_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mdt_conv_stem_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]),
+    "mdt_adam_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong] + [c_float] * 5 + [c_longlong, c_void_p]),
     "mdt_conv_stem_forward_supported": (c_int, [c_int] * 7),
     "mdt_conv_stem_forward": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
     "mdt_conv3x3x3_small_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
@@ -100,9 +101,17 @@ def check(code, what):
         raise RuntimeError("%s failed: %s (code %d)" % (what, lib().mdt_error_string(code).decode(), code))
 
 
-def current_stream_ptr():
+def raw_stream(t=None):
+    """hipStream_t (as an int) of the calling thread's current stream on the device of tensor `t` (default: the current device).
+    One C call: `torch.cuda.current_stream().cuda_stream` builds a Stream object and costs ~10 us of host time, and the epilogue /
+    convolution helpers ask ~200 times per training step."""
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    idx = t.device.index if t is not None else None
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+
+
+def current_stream_ptr():
+    return c_void_p(raw_stream())
 
 
 def require_cuda(t, name):

@@ -5,11 +5,127 @@ import torch
 import torch.distributed as dist
 
 
-def build_optimizer(net, cf, fused=False):
+def build_optimizer(net, cf, fused=False, flat=False, grad_sync=None):
     """exec.py:39: Adam(lr=cf.learning_rate[0], weight_decay=cf.weight_decay); fused=True uses torch's single-kernel
-    multi-tensor implementation (same update rule)."""
+    multi-tensor implementation (same update rule); flat=True: FlatAdam (one launch of csrc/adam.hip over flat buffers)."""
+    if flat:
+        return FlatAdam(net.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay, grad_sync=grad_sync)
     kw = {"fused": True} if fused else {}
     return torch.optim.Adam(net.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay, **kw)
+
+
+def _view_like(flat, off, p):
+    """the n = p.numel() slots of `flat` from `off` on, seen with p's own shape AND strides (channels_last weights are dense,
+    permuted views: element k of the slice is the same storage slot k of p)"""
+    chunk = flat[off:off + p.numel()]
+    return chunk.as_strided(p.size(), p.stride()) if p.is_contiguous() is False and _dense(p) else chunk.view_as(p)
+
+
+class FlatAdam(torch.optim.Adam):
+    """torch.optim.Adam (exec.py:39) with the whole model in four flat fp32 buffers -- parameters, gradients, exp_avg, exp_avg_sq
+    (4.94 M values = 19.75 MB each) -- and the update as ONE launch of mdt_adam_flat (csrc/adam.hip) instead of ~20 multi-tensor
+    launches and 3.4 ms of host time per step (profiles/r03_host_profile.txt).
+
+    * every `p.data`, `p.grad`, `state[p]['exp_avg']`, `state[p]['exp_avg_sq']` is a VIEW (with p's strides) into the flat buffers,
+      in reverse parameter order (= FlatGradAllReduce's order, whose gradient buffer is adopted when one is passed), so
+      `state_dict()` / `load_state_dict()` keep torch.optim.Adam's format (checkpoints of the reference's Adam load unchanged);
+    * `zero_grad()` is one fill of the flat gradient buffer (gradients stay allocated: set_to_none is ignored);
+    * a parameter that received no gradient in a step sees a ZERO gradient (torch skips it): identical while it never had one
+      (the unused P1 convolutions of the reference FPN, backbone.py:112,118) and for weight_decay = 0 otherwise up to the decay of its
+      moments -- the same convention the multi-GPU path has (FlatGradAllReduce).  One step counter for all parameters.
+    * amsgrad / maximize / capturable / differentiable are not supported (the reference never sets them)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_sync=None):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdam: one parameter group (the reference's exec.py:39 passes net.parameters())")
+        self._grad_sync = grad_sync
+        self._flat = None           # (param, grad, exp_avg, exp_avg_sq)
+        self._steps = 0
+
+    def _build(self):
+        params = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        if not params:
+            raise ValueError("FlatAdam: no trainable parameter")
+        dev = params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 or not (p.is_contiguous() or _dense(p)) for p in params):
+            raise ValueError("FlatAdam: parameters must be dense fp32 tensors on one device")
+        n = sum(p.numel() for p in params)
+        gs = self._grad_sync
+        if gs is not None:
+            if gs.flat is None:
+                gs._build()
+            if len(gs.params) != len(params) or any(a is not b for a, b in zip(gs.params, params)):
+                raise ValueError("FlatAdam: grad_sync was built over a different parameter list")
+            fgrad = gs.flat
+        else:
+            fgrad = torch.zeros(n, dtype=torch.float32, device=dev)
+        fparam = torch.empty(n, dtype=torch.float32, device=dev)
+        fm = torch.zeros(n, dtype=torch.float32, device=dev)
+        fv = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in reversed(params):                       # backward order, as FlatGradAllReduce lays the gradients out
+                v = _view_like(fparam, off, p)
+                v.copy_(p)
+                old_state = self.state.get(p, {})
+                if gs is None:
+                    g = _view_like(fgrad, off, p)
+                    if p.grad is not None:
+                        g.copy_(p.grad)
+                    p.grad = None
+                p.data = v
+                if gs is None:
+                    p.grad = g
+                st = {"step": torch.tensor(float(self._steps)), "exp_avg": _view_like(fm, off, p), "exp_avg_sq": _view_like(fv, off, p)}
+                if "exp_avg" in old_state:                    # state loaded (or stepped by plain Adam) before the first flat step
+                    st["exp_avg"].copy_(old_state["exp_avg"])
+                    st["exp_avg_sq"].copy_(old_state["exp_avg_sq"])
+                    st["step"] = torch.tensor(float(old_state["step"]))
+                    self._steps = max(self._steps, int(float(old_state["step"])))
+                self.state[p] = st
+                off += p.numel()
+        self._params = params
+        self._flat = (fparam, fgrad, fm, fv)
+
+    def zero_grad(self, set_to_none=True):
+        if self._flat is None:
+            self._build()
+        if self._grad_sync is not None:
+            self._grad_sync.zero()
+        else:
+            self._flat[1].zero_()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat = None           # re-adopt the loaded moments at the next step (`_build` copies them into the flat buffers)
+        self._steps = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._flat is None:
+            self._build()
+        g = self.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+            raise ValueError("FlatAdam: amsgrad / maximize / capturable / differentiable are not supported")
+        for p in self._params:           # a dropped view (someone's zero_grad(set_to_none=True), p.grad = None) would silently freeze p
+            if p.grad is None:
+                raise RuntimeError("FlatAdam: a gradient view was dropped; clear gradients with FlatAdam.zero_grad()")
+        from . import _lib
+        fparam, fgrad, fm, fv = self._flat
+        self._steps += 1
+        with torch.cuda.device(fparam.device):
+            rc = _lib.lib().mdt_adam_flat(fparam.data_ptr(), fgrad.data_ptr(), fm.data_ptr(), fv.data_ptr(), fparam.numel(), float(g["lr"]),
+                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._steps,
+                                          _lib.raw_stream(fparam))
+        _lib.check(rc, "mdt_adam_flat")
+        for p in self._params:
+            self.state[p]["step"].fill_(float(self._steps))   # CPU scalars (torch.optim.Adam's own format)
+        return loss
 
 
 class FlatGradAllReduce(object):
@@ -122,7 +238,9 @@ def _dense(p):
 def train_step(net, optimizer, batch, grad_sync=None, monitor=False):
     """exec.py:68-74: results = net.train_forward(batch); zero_grad; loss.backward(); optimizer.step()."""
     results = net.train_forward(batch, monitor=monitor)
-    if grad_sync is not None:
+    if isinstance(optimizer, FlatAdam):
+        optimizer.zero_grad()            # one fill (and the bucket bookkeeping of its grad_sync, if any)
+    elif grad_sync is not None:
         grad_sync.zero()
     else:
         optimizer.zero_grad(set_to_none=True)

@@ -53,7 +53,7 @@ class _BiasAct(Function):
         if not _on_current_device(x):
             raise RuntimeError("fused epilogue: tensor is not on the current device (one process per GPU)")
         rc = _lib.lib().mdt_bias_act_forward(x.data_ptr(), x.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
-                                             x.numel(), x.shape[1], inner, 1 if relu else 0, torch.cuda.current_stream().cuda_stream)
+                                             x.numel(), x.shape[1], inner, 1 if relu else 0, _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_bias_act_forward")
         ctx.mark_dirty(x)
@@ -74,7 +74,7 @@ class _BiasAct(Function):
         wsb = (4096 * C * 4 + 256) if ctx.inner == 1 else L.mdt_bias_act_backward_workspace_bytes(n, C, ctx.inner)
         ws = _workspace(wsb, gy.device)
         rc = L.mdt_bias_act_backward(gx.data_ptr(), gy.data_ptr(), y.data_ptr() if y is not None else None, gbias.data_ptr(), n, C, ctx.inner,
-                                     1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+                                     1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_bias_act_backward")
         return gx, gbias, (gx if ctx.has_res else None), None, None, None
@@ -106,7 +106,7 @@ def flip_transpose_filter(w, mf):
         cout, cin = int(w.shape[0]), int(w.shape[1])
         out = torch.empty((cin, cout) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device, memory_format=mf)
         rc = _lib.lib().mdt_filter_flip_transpose(w.data_ptr(), out.data_ptr(), cout, cin, int(w.shape[2:].numel()),
-                                                  0 if mf == torch.contiguous_format else 1, torch.cuda.current_stream().cuda_stream)
+                                                  0 if mf == torch.contiguous_format else 1, _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_filter_flip_transpose")
         return out
@@ -150,7 +150,7 @@ def conv1x1_weight_grad(gy, x, w, force=False):
     ws = _workspace(wsb, gy.device)
     gw = torch.empty((cout, cin), dtype=torch.float32, device=gy.device)
     rc = L.mdt_conv1x1_wgrad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), V, cout, cin, ws.data_ptr(), ws.numel(),
-                             torch.cuda.current_stream().cuda_stream)
+                             _lib.raw_stream())
     if rc != 0:
         _lib.check(rc, "mdt_conv1x1_wgrad")
     return gw.view(w.shape)
@@ -181,7 +181,7 @@ def conv3x3x3_small(x, w):
         return None
     wt = w.permute(2, 3, 4, 1, 0).contiguous()                  # [27][C_in][C_out]
     y = torch.empty((B, cout, Y, X, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
-    rc = L.mdt_conv3x3x3_small_forward(x.data_ptr(), wt.data_ptr(), y.data_ptr(), B, Y, X, Z, cin, cout, torch.cuda.current_stream().cuda_stream)
+    rc = L.mdt_conv3x3x3_small_forward(x.data_ptr(), wt.data_ptr(), y.data_ptr(), B, Y, X, Z, cin, cout, _lib.raw_stream())
     if rc != 0:
         _lib.check(rc, "mdt_conv3x3x3_small_forward")
     return y
@@ -205,7 +205,7 @@ def conv3x3x3_small_weight_grad(gy, x, w):
     ws = _workspace(wsb, gy.device)
     gw = torch.empty((3, 3, 3, cin, cout), dtype=torch.float32, device=gy.device)
     rc = L.mdt_conv3x3x3_small_wgrad(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, Y, X, Z, cin, cout, ws.data_ptr(), ws.numel(),
-                                     torch.cuda.current_stream().cuda_stream)
+                                     _lib.raw_stream())
     if rc != 0:
         _lib.check(rc, "mdt_conv3x3x3_small_wgrad")
     return gw.permute(4, 3, 0, 1, 2)
@@ -278,7 +278,7 @@ def stem_weight_grad(gy, x, w, stride, xp=None):
     ws = _workspace(wsb, gy.device)
     gw = torch.empty((cout, k * k * k), dtype=torch.float32, device=gy.device)
     rc = L.mdt_conv_stem_wgrad(gy.data_ptr(), xp.data_ptr(), gw.data_ptr(), B, OY, OX, OZ, cout, k, int(stride[0]), int(stride[1]),
-                               int(xp.shape[1]), int(xp.shape[2]), int(xp.shape[3]), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+                               int(xp.shape[1]), int(xp.shape[2]), int(xp.shape[3]), ws.data_ptr(), ws.numel(), _lib.raw_stream())
     if rc != 0:
         _lib.check(rc, "mdt_conv_stem_wgrad")
     return gw.view(w.shape)
@@ -311,7 +311,7 @@ def stem_forward(x, w, bias=None, relu=False):
     out = torch.empty((B, cout, OY, OX, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
     wc = w.detach().reshape(cout, 343).contiguous()
     rc = L.mdt_conv_stem_forward(xp.data_ptr(), wc.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), B, OY, OX, Z,
-                                 cout, 7, 2, 2, Y + 6, X + 6, Z + 6, 1 if relu else 0, torch.cuda.current_stream().cuda_stream)
+                                 cout, 7, 2, 2, Y + 6, X + 6, Z + 6, 1 if relu else 0, _lib.raw_stream())
     if rc != 0:
         _lib.check(rc, "mdt_conv_stem_forward")
     return out, xp
@@ -384,7 +384,7 @@ class _ConvStemBiasReLU(Function):
         gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
         ws = _workspace(4096 * C * 4 + 256, gy.device)
         rc = L.mdt_bias_act_backward(g.data_ptr(), gy.data_ptr(), y.data_ptr(), gbias.data_ptr(), n, C, 1, 1, ws.data_ptr(), ws.numel(),
-                                     torch.cuda.current_stream().cuda_stream)
+                                     _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_bias_act_backward")
         xp, ctx.xp = ctx.xp, None
@@ -457,7 +457,7 @@ class _MaxPoolK3S221(Function):
         y = torch.empty((B, C, OY, OX, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
         arg = torch.empty((B, OY, OX, Z, C), dtype=torch.uint8, device=x.device)
         rc = _lib.lib().mdt_maxpool3d_k3s221_cl_forward(x.data_ptr(), y.data_ptr(), arg.data_ptr(), B, Y, X, Z, C,
-                                                        torch.cuda.current_stream().cuda_stream)
+                                                        _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_maxpool3d_k3s221_cl_forward")
         ctx.save_for_backward(arg)
@@ -472,7 +472,7 @@ class _MaxPoolK3S221(Function):
             gy = gy.contiguous(memory_format=torch.channels_last_3d)
         gx = torch.empty((B, C, Y, X, Z), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last_3d)
         rc = _lib.lib().mdt_maxpool3d_k3s221_cl_backward(gy.data_ptr(), arg.data_ptr(), gx.data_ptr(), B, Y, X, Z, C,
-                                                         torch.cuda.current_stream().cuda_stream)
+                                                         _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_maxpool3d_k3s221_cl_backward")
         return gx
@@ -513,7 +513,7 @@ class _Upsample2xYX(Function):
         mf = torch.channels_last_3d if nd == 3 else torch.channels_last
         shape = (B, C, 2 * Y, 2 * X) + ((Z,) if nd == 3 else ())
         y = torch.empty(shape, dtype=torch.float32, device=x.device, memory_format=mf)
-        rc = _lib.lib().mdt_upsample2x_yx_cl_forward(x.data_ptr(), y.data_ptr(), B, Y, X, Z * C, torch.cuda.current_stream().cuda_stream)
+        rc = _lib.lib().mdt_upsample2x_yx_cl_forward(x.data_ptr(), y.data_ptr(), B, Y, X, Z * C, _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_upsample2x_yx_cl_forward")
         ctx.dims = (B, C, Y, X, Z, nd)
@@ -526,7 +526,7 @@ class _Upsample2xYX(Function):
         if not gy.is_contiguous(memory_format=mf):
             gy = gy.contiguous(memory_format=mf)
         gx = torch.empty((B, C, Y, X) + ((Z,) if nd == 3 else ()), dtype=torch.float32, device=gy.device, memory_format=mf)
-        rc = _lib.lib().mdt_upsample2x_yx_cl_backward(gy.data_ptr(), gx.data_ptr(), B, Y, X, Z * C, torch.cuda.current_stream().cuda_stream)
+        rc = _lib.lib().mdt_upsample2x_yx_cl_backward(gy.data_ptr(), gx.data_ptr(), B, Y, X, Z * C, _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_upsample2x_yx_cl_backward")
         return gx

@@ -74,7 +74,7 @@ def _stage_pool():
     global _STAGE_POOL
     if _STAGE_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _STAGE_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="mdt-stage")
+        _STAGE_POOL = ThreadPoolExecutor(max_workers=6, thread_name_prefix="mdt-stage")
     return _STAGE_POOL
 
 
@@ -124,15 +124,30 @@ def _as_cpu_tensor(a):
     return a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
 
 
-def _stack_into(raw, parts):
-    """the CPU tensors `parts` stacked along dim 0 into the pinned byte buffer `raw` (no intermediate torch.cat copy; copy_ of a
-    large contiguous tensor is spread over the intra-op threads and releases the GIL)"""
+def _np_copy(dst, src):
+    """CPU tensor -> CPU tensor by numpy: a plain memcpy that releases the GIL.  (torch's copy_ runs on the OpenMP pool; called
+    from a second thread it spins up a second team of one thread per core next to the main thread's -- measured: the host side of
+    a step went from 70 to 190 ms, profiles/r03_host_issue_probe.json.)"""
+    np.copyto(dst.numpy(), src.numpy())
+
+
+def _stack_into(raw, parts, pool=None, split=2):
+    """the CPU tensors `parts` stacked along dim 0 into the pinned byte buffer `raw` (no intermediate torch.cat copy); with a
+    pool, parts of 32 MB and more are copied as `split` slices in parallel (one core moves 8-16 GB/s)"""
     n0 = sum(int(t.shape[0]) for t in parts)
     pinned = raw.view(parts[0].dtype).view((n0,) + tuple(parts[0].shape[1:]))
-    at = 0
+    at, jobs = 0, []
     for t in parts:
-        pinned[at:at + int(t.shape[0])].copy_(t)
+        dst = pinned[at:at + int(t.shape[0])]
         at += int(t.shape[0])
+        if pool is not None and t.numel() * t.element_size() >= (32 << 20):
+            fd, fs = dst.view(-1), t.view(-1)
+            step = (fs.numel() + split - 1) // split
+            jobs += [pool.submit(_np_copy, fd[i:i + step], fs[i:i + step]) for i in range(0, fs.numel(), step)]
+        else:
+            _np_copy(dst, t)
+    for j in jobs:
+        j.result()
     return pinned
 
 
@@ -151,7 +166,7 @@ def upload(array_or_tensor, device, channel="data"):
         return t.pin_memory().to(device, non_blocking=True)
     st = _stager(device, channel)
     k, raw = st.acquire(nbytes)
-    d = _stack_into(raw, [t.contiguous()]).to(device, non_blocking=True)
+    d = _stack_into(raw, [t.contiguous()], pool=_stage_pool()).to(device, non_blocking=True)
     st.release(k)
     return d
 
