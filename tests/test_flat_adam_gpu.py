@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _toy(cuda, seed=0):
     torch.manual_seed(seed)
-    net = nn.Sequential(nn.Conv3d(2, 5, 3, padding=1), nn.ReLU(), nn.Conv3d(5, 3, 1), nn.Flatten(), nn.Linear(3 * 4 * 4 * 4, 7)).to(cuda)
+    net = nn.Sequential(nn.Conv3d(2, 5, 3, padding=1), nn.ReLU(), nn.Conv3d(5, 3, 1), nn.Flatten(), nn.Linear(3 * 4 * 4 * 4, 6)).to(cuda)
     net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last_3d)     # dense, permuted strides
     return net
 

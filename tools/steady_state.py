@@ -1,7 +1,7 @@
 """Steady-state kernel breakdown of the timed training steps from a rocprofv3 --kernel-trace csv of bench.py.
 
 usage: python tools/steady_state.py <*_kernel_trace.csv> <steps> <ms_per_step> [out.csv]
-The window ends at the last optimizer (multi_tensor_apply) kernel of the trace -- run bench.py with --no-h2d-leg
+The window ends at the last optimizer (adam_flat_kernel / multi_tensor_apply) kernel of the trace -- run bench.py with --no-h2d-leg
 --no-rccl-selftest so that the last Adam launch belongs to the last timed step -- and spans steps * ms_per_step before it."""
 import csv
 import re
@@ -11,9 +11,9 @@ from collections import defaultdict
 
 def category(n):
     if "crop_" in n or "nms_" in n or "bias_act" in n or "bias_grad" in n or "anchor" in n or "decode" in n or "wbc" in n \
-            or "maxpool_k3" in n or "filter_flip" in n or "match_pass" in n or "upsample2x_" in n or "zero_fill_kernel" in n or "nms2to3d" in n:
+            or "maxpool_k3" in n or "filter_flip" in n or "match_pass" in n or "upsample2x_" in n or "zero_fill_kernel" in n or "nms2to3d" in n or "adam_flat" in n:
         return "mdt_hip (this repo)"
-    if "conv1x1_wgrad" in n or "conv3x3x3_small" in n or "conv_stem_wgrad" in n:
+    if "conv1x1_wgrad" in n or "conv3x3x3_small" in n or "conv_stem_wgrad" in n or "conv_stem_fwd" in n:
         return "mdt_hip convolution kernels (this repo, fp32 MFMA)"
     if n.startswith("_ZN2ck") or "ck::" in n or "miopen" in n.lower() or "Cijk" in n or "gemm" in n.lower() or "batched_transpose" in n \
             or "naive_conv" in n or "SubTensor" in n or "Im2" in n or "Col2" in n or "igemm" in n:
@@ -56,9 +56,9 @@ def main():
     path, steps, ms = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
     rows = list(csv.DictReader(open(path)))
     ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
-    adam = [e for s, e, n in ks if "multi_tensor_apply" in n]
+    adam = [e for s, e, n in ks if "multi_tensor_apply" in n or "adam_flat_kernel" in n]
     if not adam:
-        raise SystemExit("no optimizer (multi_tensor_apply) launch in the trace")
+        raise SystemExit("no optimizer (multi_tensor_apply / adam_flat_kernel) launch in the trace")
     t1 = max(adam)
     t0 = t1 - int(steps * ms * 1e6)
     win = [(s, e, n) for s, e, n in ks if s >= t0 and e <= t1]
