@@ -429,9 +429,10 @@ int mdt_conv_stem_forward(const float *x_padded, const float *weight, const floa
 /* ---- Adam over flat fp32 buffers (csrc/adam.hip) ------------------------------------------------------------------------------
  * One step of torch.optim.Adam (exec.py:39: Adam(lr = cf.learning_rate[0], weight_decay = cf.weight_decay); no amsgrad) for n
  * parameters whose values, gradients and moment estimates are four flat arrays: step >= 1 is the number of this update (bias
- * corrections 1 - beta^step), weight_decay is the L2 term added to the gradient.  In place on param / exp_avg / exp_avg_sq. */
-int mdt_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, long long step, void *stream);
+ * corrections 1 - beta^step), weight_decay is the L2 term added to the gradient; the hyper-parameters are doubles (derived scalars are
+ * formed in double and rounded to fp32 once, like torch's python-side arithmetic).  In place on param / exp_avg / exp_avg_sq. */
+int mdt_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, long long step, void *stream);
 
 #ifdef __cplusplus
 }

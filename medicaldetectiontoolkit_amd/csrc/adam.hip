@@ -46,23 +46,24 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
 
 }  // namespace
 
-extern "C" int mdt_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, long long step, void *stream)
+extern "C" int mdt_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, long long step, void *stream)
 {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return MDT_ERR_INVALID_ARGUMENT;
     if (n == 0) return MDT_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                          reinterpret_cast<uintptr_t>(exp_avg_sq);
     const long long n4 = (al & 15) == 0 ? n / 4 : 0;
-    // bias corrections in double on the host, as torch does (1 - beta ** step), then rounded to fp32 scalars
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    // hyper-parameters arrive as doubles (python floats) and every derived scalar -- 1 - beta, the bias corrections 1 - beta ** step,
+    // the step size -- is formed in double and rounded to fp32 once, as torch does (1 - 0.999f would be off by 1.3e-5)
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     AdamScalars a;
-    a.one_minus_b1 = (float)(1.0 - (double)beta1);
-    a.b2 = beta2;
-    a.one_minus_b2 = (float)(1.0 - (double)beta2);
-    a.eps = eps;
-    a.wd = weight_decay;
-    a.neg_step_size = (float)(-(double)lr / bc1);
+    a.one_minus_b1 = (float)(1.0 - beta1);
+    a.b2 = (float)beta2;
+    a.one_minus_b2 = (float)(1.0 - beta2);
+    a.eps = (float)eps;
+    a.wd = (float)weight_decay;
+    a.neg_step_size = (float)(-lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
     long long work = n4 > 0 ? n4 : n;
     if (n - 4 * n4 > work) work = n - 4 * n4;

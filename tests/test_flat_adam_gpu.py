@@ -43,8 +43,8 @@ def test_flat_adam_equals_torch_adam(wd, cuda):
     assert sa["param_groups"][0]["params"] == sb["param_groups"][0]["params"]
     for k in sa["state"]:
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 12.0
-        assert torch.allclose(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"], rtol=1e-5, atol=1e-9)
-        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+        assert torch.allclose(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"], rtol=5e-5, atol=1e-9)
+        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=5e-5, atol=1e-12)
 
 
 def test_flat_adam_state_dict_round_trip_and_adoption(cuda):
