@@ -29,7 +29,9 @@ class FlatAdam(torch.optim.Adam):
     * every `p.data`, `p.grad`, `state[p]['exp_avg']`, `state[p]['exp_avg_sq']` is a VIEW (with p's strides) into the flat buffers,
       in reverse parameter order (= FlatGradAllReduce's order, whose gradient buffer is adopted when one is passed), so
       `state_dict()` / `load_state_dict()` keep torch.optim.Adam's format (checkpoints of the reference's Adam load unchanged);
-    * `zero_grad()` is one fill of the flat gradient buffer (gradients stay allocated: set_to_none is ignored);
+    * gradients: with a FlatGradAllReduce (N > 1) they LIVE in its flat buffer (`p.grad` views; `zero_grad()` = one fill).  Without
+      one, `zero_grad()` sets them to None so that autograd hands its gradient tensors over without an accumulate-add per
+      parameter (130 tiny launches per step), and `step()` gathers them into the flat buffer with one `torch._foreach_copy_`;
     * a parameter that received no gradient in a step sees a ZERO gradient (torch skips it): identical while it never had one
       (the unused P1 convolutions of the reference FPN, backbone.py:112,118) and for weight_decay = 0 otherwise up to the decay of its
       moments -- the same convention the multi-GPU path has (FlatGradAllReduce).  One step counter for all parameters.
@@ -64,19 +66,14 @@ class FlatAdam(torch.optim.Adam):
         fm = torch.zeros(n, dtype=torch.float32, device=dev)
         fv = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
+        gviews = []
         with torch.no_grad():
             for p in reversed(params):                       # backward order, as FlatGradAllReduce lays the gradients out
                 v = _view_like(fparam, off, p)
                 v.copy_(p)
                 old_state = self.state.get(p, {})
-                if gs is None:
-                    g = _view_like(fgrad, off, p)
-                    if p.grad is not None:
-                        g.copy_(p.grad)
-                    p.grad = None
+                gviews.append(_view_like(fgrad, off, p))
                 p.data = v
-                if gs is None:
-                    p.grad = g
                 st = {"step": torch.tensor(float(self._steps)), "exp_avg": _view_like(fm, off, p), "exp_avg_sq": _view_like(fv, off, p)}
                 if "exp_avg" in old_state:                    # state loaded (or stepped by plain Adam) before the first flat step
                     st["exp_avg"].copy_(old_state["exp_avg"])
@@ -86,6 +83,9 @@ class FlatAdam(torch.optim.Adam):
                 self.state[p] = st
                 off += p.numel()
         self._params = params
+        self._rparams = list(reversed(params))
+        self._gviews = gviews                       # flat-gradient views, in `_rparams` order
+        self._gdirty = [False] * len(gviews)        # view holds a gradient of an earlier step
         self._flat = (fparam, fgrad, fm, fv)
 
     def zero_grad(self, set_to_none=True):
@@ -94,7 +94,8 @@ class FlatAdam(torch.optim.Adam):
         if self._grad_sync is not None:
             self._grad_sync.zero()
         else:
-            self._flat[1].zero_()
+            for p in self._params:
+                p.grad = None
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -112,11 +113,26 @@ class FlatAdam(torch.optim.Adam):
         g = self.param_groups[0]
         if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
             raise ValueError("FlatAdam: amsgrad / maximize / capturable / differentiable are not supported")
-        for p in self._params:           # a dropped view (someone's zero_grad(set_to_none=True), p.grad = None) would silently freeze p
-            if p.grad is None:
-                raise RuntimeError("FlatAdam: a gradient view was dropped; clear gradients with FlatAdam.zero_grad()")
         from . import _lib
         fparam, fgrad, fm, fv = self._flat
+        if self._grad_sync is not None:
+            for p in self._params:       # a dropped view (someone's zero_grad(set_to_none=True)) would silently freeze p
+                if p.grad is None:
+                    raise RuntimeError("FlatAdam: a gradient view was dropped; clear gradients with FlatAdam.zero_grad()")
+        else:                            # gather autograd's gradient tensors into the flat buffer: one multi-tensor copy
+            dst, src = [], []
+            for i, p in enumerate(self._rparams):
+                g_i = p.grad
+                if g_i is None:
+                    if self._gdirty[i]:              # last step's gradient must not be applied again
+                        self._gviews[i].zero_()
+                        self._gdirty[i] = False
+                elif g_i.data_ptr() != self._gviews[i].data_ptr():
+                    dst.append(self._gviews[i])
+                    src.append(g_i)
+                    self._gdirty[i] = True
+            if dst:
+                torch._foreach_copy_(dst, src)
         self._steps += 1
         with torch.cuda.device(fparam.device):
             rc = _lib.lib().mdt_adam_flat(fparam.data_ptr(), fgrad.data_ptr(), fm.data_ptr(), fv.data_ptr(), fparam.numel(), float(g["lr"]),

@@ -72,12 +72,41 @@ def test_flat_adam_state_dict_round_trip_and_adoption(cuda):
     oc.load_state_dict(copy.deepcopy(ob.state_dict()))            # and back into torch's Adam
 
 
-def test_flat_adam_refuses_dropped_gradient_views(cuda):
+def test_flat_adam_missing_gradient_is_a_zero_gradient(cuda):
+    """a parameter without a gradient in a step (p.grad None) is updated with a ZERO gradient (documented convention; torch skips
+    it): equal to torch.optim.Adam fed explicit zeros, and last step's gradient is not applied twice"""
+    a, b = _toy(cuda, 5), _toy(cuda, 5)
+    oa = torch.optim.Adam(a.parameters(), lr=1e-2)
+    ob = training.FlatAdam(b.parameters(), lr=1e-2)
+    x = torch.randn((2, 2, 4, 4, 4), device=cuda)
+    for it in range(4):
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad()
+            net(x).square().mean().backward()
+        if it >= 2:                      # the last layer gets no gradient in steps 2 and 3
+            for p in a[4].parameters():
+                p.grad = torch.zeros_like(p)
+            for p in b[4].parameters():
+                p.grad = None
+        oa.step()
+        ob.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6)
+
+
+def test_flat_adam_with_grad_sync_refuses_dropped_gradient_views(cuda):
+    """with a FlatGradAllReduce the gradients live in ITS flat buffer: a dropped view is an error, never a silent freeze"""
     net = _toy(cuda)
-    opt = training.FlatAdam(net.parameters(), lr=1e-3)
-    opt.zero_grad()
-    net(torch.randn((1, 2, 4, 4, 4), device=cuda)).sum().backward()
-    opt.step()
+    sync = training.FlatGradAllReduce(net)
+    opt = training.FlatAdam(net.parameters(), lr=1e-3, grad_sync=sync)
+    p0 = [p.detach().clone() for p in net.parameters()]
+    for _ in range(2):
+        opt.zero_grad()
+        net(torch.randn((1, 2, 4, 4, 4), device=cuda)).sum().backward()
+        sync.finish()                    # no process group: a no-op
+        opt.step()
+    assert all(p.grad.data_ptr() >= sync.flat.data_ptr() and p.grad.data_ptr() < sync.flat.data_ptr() + 4 * sync.flat.numel() for p in net.parameters())
+    assert any(not torch.equal(p, q) for p, q in zip(net.parameters(), p0))
     for p in net.parameters():
         p.grad = None
     with pytest.raises(RuntimeError, match="gradient view was dropped"):
