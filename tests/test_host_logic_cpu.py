@@ -55,3 +55,126 @@ def test_conv_reformulations_are_exact_identities_in_float64():
         g = torch.randn_like(y2)
         a, b = torch.autograd.grad(y1, (x, w), g), torch.autograd.grad(y2, (x, w), g)
         assert (y1 - y2).abs().max() < 1e-12 and (a[0] - b[0]).abs().max() < 1e-12 and (a[1] - b[1]).abs().max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 3: staging of numpy batches, flat views of the optimizer, profile post-processing (no GPU: pinned memory and events
+# are replaced by plain tensors / counters)
+class _FakeEvent(object):
+    waits = 0
+    records = 0
+
+    def record(self):
+        _FakeEvent.records += 1
+
+    def synchronize(self):
+        _FakeEvent.waits += 1
+
+
+def _patch_pinned(monkeypatch):
+    import torch
+    real_empty = torch.empty
+
+    def empty(*a, **k):
+        k.pop("pin_memory", None)
+        return real_empty(*a, **k)
+
+    monkeypatch.setattr(torch, "empty", empty)
+    monkeypatch.setattr(torch.cuda, "Event", _FakeEvent)
+    _FakeEvent.waits = _FakeEvent.records = 0
+
+
+def test_pinned_stager_reuses_slots_after_their_own_event(monkeypatch):
+    """ring of 3: a slot is handed out again only after waiting for the event recorded at its last release; buffers grow, never
+    shrink, and are not re-allocated for a smaller request"""
+    import torch
+    from medicaldetectiontoolkit_amd.utils import model_utils as mu
+    _patch_pinned(monkeypatch)
+    st = mu.PinnedStager(depth=3)
+    ptrs = []
+    for i in range(7):
+        k, raw = st.acquire(1000 + 10 * i)
+        assert raw.dtype == torch.uint8 and raw.numel() == 1000 + 10 * i
+        ptrs.append((k, raw.data_ptr()))
+        st.release(k)
+    assert [k for k, _ in ptrs] == [0, 1, 2, 0, 1, 2, 0]
+    assert _FakeEvent.records == 7 and _FakeEvent.waits == 4          # the first round finds no event to wait for
+    assert ptrs[3][1] == ptrs[0][1] and ptrs[6][1] == ptrs[0][1]      # 25 % head room: no re-allocation for slightly larger requests
+    k, raw = st.acquire(10)
+    assert raw.data_ptr() == ptrs[1][1]
+
+
+def test_stack_into_equals_cat_for_every_dtype_and_ragged_parts(monkeypatch):
+    import numpy as np
+    import torch
+    from medicaldetectiontoolkit_amd.utils import model_utils as mu
+    _patch_pinned(monkeypatch)
+    rng = np.random.default_rng(0)
+    for dtype in (np.uint8, np.float32, np.int64, np.float64):
+        parts = [torch.from_numpy(rng.integers(0, 200, size=(n, 1, 5, 6, 7)).astype(dtype)) for n in (3, 1, 4)]
+        nbytes = sum(p.numel() * p.element_size() for p in parts)
+        raw = torch.empty(nbytes + 64, dtype=torch.uint8)[:nbytes]
+        got = mu._stack_into(raw, parts)
+        assert got.dtype == parts[0].dtype and torch.equal(got, torch.cat(parts, 0))
+    # the parallel path (parts of 32 MB and more are split over the pool) gives the same bytes
+    big = torch.from_numpy(rng.standard_normal((9, 1, 100, 100, 100)).astype(np.float32))
+    raw = torch.empty(big.numel() * 4, dtype=torch.uint8)
+    assert torch.equal(mu._stack_into(raw, [big], pool=mu._stage_pool(), split=3), big)
+
+
+def test_staged_upload_and_upload_on_cpu_are_plain_copies():
+    """device 'cpu' (the CPU test tier): no pinned memory, no thread, same values; empty part lists give None like the
+    `masks_list` branch they replace"""
+    import numpy as np
+    import torch
+    from medicaldetectiontoolkit_amd.utils import model_utils as mu
+    parts = [np.arange(2 * 24, dtype=np.uint8).reshape(2, 1, 2, 3, 4), np.ones((1, 1, 2, 3, 4), dtype=np.uint8)]
+    su = mu.StagedUpload(parts, "cpu")
+    assert su.future is None and torch.equal(su.get(), torch.cat([torch.from_numpy(p) for p in parts], 0))
+    assert mu.StagedUpload([], "cpu").get() is None
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    assert torch.equal(mu.upload(a, "cpu"), torch.from_numpy(a))
+
+
+def test_flat_views_keep_shape_strides_and_slot_order():
+    """training._view_like: element k of a parameter's storage is slot off + k of the flat buffer, for contiguous and for dense
+    permuted (channels-last) parameters alike -- what lets Adam run elementwise over the flat buffers"""
+    import torch
+    from medicaldetectiontoolkit_amd import training
+    w_cl = torch.arange(5 * 2 * 27, dtype=torch.float32).reshape(5, 2, 3, 3, 3).contiguous(memory_format=torch.channels_last_3d)
+    w_c = torch.arange(7 * 3, dtype=torch.float32).reshape(7, 3)
+    assert training._dense(w_cl) and not w_cl.is_contiguous()
+    flat = torch.zeros(w_cl.numel() + w_c.numel() + 5)
+    v1 = training._view_like(flat, 3, w_cl)
+    v2 = training._view_like(flat, 3 + w_cl.numel(), w_c)
+    assert v1.shape == w_cl.shape and v1.stride() == w_cl.stride() and v2.stride() == w_c.stride()
+    v1.copy_(w_cl)
+    v2.copy_(w_c)
+    # storage order of the parameter == slot order in the flat buffer
+    assert torch.equal(flat[3:3 + w_cl.numel()], w_cl.permute(0, 2, 3, 4, 1).reshape(-1))
+    assert torch.equal(flat[3 + w_cl.numel():3 + w_cl.numel() + w_c.numel()], w_c.reshape(-1))
+    assert float(flat[:3].abs().sum()) == 0.0 and float(flat[-2:].abs().sum()) == 0.0
+    assert not training._dense(torch.zeros(4, 6)[:, ::2])
+
+
+def test_steady_state_categories_cover_this_repos_kernels():
+    """tools/steady_state.category: every kernel name of libmdt_hip lands in one of the two 'this repo' rows, MIOpen / CK / rocBLAS
+    names in the convolution row (the split the DESIGN tables quote)"""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("steady_state", os.path.join(root, "tools", "steady_state.py"))
+    ss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ss)
+    names = set()
+    csrc = os.path.join(root, "medicaldetectiontoolkit_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith(".hip"):
+            names |= set(re.findall(r"__global__[^;{]*?void\s+(\w+)\s*\(", open(os.path.join(csrc, f)).read()))
+    assert len(names) > 30
+    for n in names:
+        assert "this repo" in ss.category("(anonymous namespace)::" + n), n
+    for n in ("_ZN2ck16tensor_operation6device", "Cijk_Alik_Bljk_S_B_Bias_HA_S_SAV_UserArgs_MT256x48", "miopenSp3AsmConv"):
+        assert ss.category(n).startswith("MIOpen")
+    assert ss.category("void at::native::vectorized_elementwise_kernel<4, ...>").startswith("torch elementwise")
