@@ -113,7 +113,6 @@ class FlatAdam(torch.optim.Adam):
         g = self.param_groups[0]
         if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
             raise ValueError("FlatAdam: amsgrad / maximize / capturable / differentiable are not supported")
-        from . import _lib
         fparam, fgrad, fm, fv = self._flat
         if self._grad_sync is not None:
             for p in self._params:       # a dropped view (someone's zero_grad(set_to_none=True)) would silently freeze p
@@ -134,14 +133,19 @@ class FlatAdam(torch.optim.Adam):
             if dst:
                 torch._foreach_copy_(dst, src)
         self._steps += 1
-        with torch.cuda.device(fparam.device):
-            rc = _lib.lib().mdt_adam_flat(fparam.data_ptr(), fgrad.data_ptr(), fm.data_ptr(), fv.data_ptr(), fparam.numel(), float(g["lr"]),
-                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._steps,
-                                          _lib.raw_stream(fparam))
-        _lib.check(rc, "mdt_adam_flat")
+        self._update(fparam, fgrad, fm, fv, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                     float(g["weight_decay"]), self._steps)
         for p in self._params:
             self.state[p]["step"].fill_(float(self._steps))   # CPU scalars (torch.optim.Adam's own format)
         return loss
+
+    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, step):
+        """the one launch (csrc/adam.hip); no CPU implementation in the product -- the gloo tests substitute this method"""
+        from . import _lib
+        with torch.cuda.device(fparam.device):
+            rc = _lib.lib().mdt_adam_flat(fparam.data_ptr(), fgrad.data_ptr(), fm.data_ptr(), fv.data_ptr(), fparam.numel(), lr, beta1, beta2,
+                                          eps, weight_decay, step, _lib.raw_stream(fparam))
+        _lib.check(rc, "mdt_adam_flat")
 
 
 class FlatGradAllReduce(object):

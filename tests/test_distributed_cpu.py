@@ -83,6 +83,116 @@ def test_flat_grad_allreduce_and_gather_world2(tmp_path):
     assert got["shard"] == [0, 2, 4, 6]
 
 
+class _TorchMathFlatAdam(training.FlatAdam):
+    """FlatAdam with the HIP launch replaced by the same arithmetic in torch ops: the flat-buffer plumbing (views, ordering,
+    adoption of the collective's gradient buffer, state dict) is what these CPU tests exercise; the kernel itself is pinned
+    against torch.optim.Adam on the GPU (tests/test_flat_adam_gpu.py)."""
+
+    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, step):
+        g = fgrad + weight_decay * fparam if weight_decay != 0 else fgrad
+        fm.lerp_(g, 1 - beta1)
+        fv.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        denom = (fv.sqrt() / (1 - beta2 ** step) ** 0.5).add_(eps)
+        fparam.addcdiv_(fm, denom, value=-lr / (1 - beta1 ** step))
+
+
+def _adam_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = Tiny()
+    sync = training.FlatGradAllReduce(net, n_buckets=2)
+    opt = _TorchMathFlatAdam(net.parameters(), lr=1e-2, grad_sync=sync)
+    torch.manual_seed(100 + rank)
+    for it in range(3):
+        x = torch.randn(5, 4)
+        loss = net(x, use_second=True)          # forward BEFORE zero_grad, as training.train_step does (the first zero_grad re-homes p.data)
+        opt.zero_grad()
+        loss.backward()
+        sync.finish()
+        opt.step()
+    fparam, fgrad, fm, fv = opt._flat
+    ok_views = all(p.data.untyped_storage().data_ptr() == fparam.untyped_storage().data_ptr() and
+                   p.grad.untyped_storage().data_ptr() == sync.flat.untyped_storage().data_ptr() for p in net.parameters())
+    params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    both = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(both, params)
+    if rank == 0:
+        torch.save({"params": {n: p.detach().clone() for n, p in net.named_parameters()}, "ok_views": ok_views, "fgrad_is_sync": fgrad is sync.flat,
+                    "ranks_equal": bool(torch.equal(both[0], both[1])), "state": opt.state_dict()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_adam_over_flat_grad_allreduce_world2(tmp_path):
+    """two gloo ranks, three steps of FlatAdam over FlatGradAllReduce's gradient buffer == torch.optim.Adam on the averaged
+    gradients in one process; both ranks end with identical parameters; the state dict has torch.optim.Adam's layout"""
+    out = str(tmp_path / "adam_r0.pt")
+    mp.spawn(_adam_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    assert got["ok_views"] and got["fgrad_is_sync"] and got["ranks_equal"]
+    torch.manual_seed(0)
+    ref = Tiny()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    gens = []
+    for rank in range(2):
+        torch.manual_seed(100 + rank)
+        gens.append([torch.randn(5, 4) for _ in range(3)])
+    for it in range(3):
+        sums = {n: torch.zeros_like(p) for n, p in ref.named_parameters()}
+        for rank in range(2):
+            ref.zero_grad()
+            ref(gens[rank][it], use_second=True).backward()
+            for n, p in ref.named_parameters():
+                if p.grad is not None:
+                    sums[n] += p.grad
+        for n, p in ref.named_parameters():
+            p.grad = sums[n] / 2 if n.startswith(("used", "sometimes")) else None     # `never` gets no gradient: torch skips it
+        opt.step()
+    for n, p in ref.named_parameters():
+        assert torch.allclose(got["params"][n], p.detach(), rtol=1e-5, atol=1e-7), n
+    st = got["state"]
+    assert len(st["state"]) == 6 and all(float(v["step"]) == 3.0 and set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in st["state"].values())
+    fresh = torch.optim.Adam(Tiny().parameters(), lr=1e-2)
+    fresh.load_state_dict(st)                    # loads into torch's own Adam
+
+
+def test_flat_adam_single_process_gathers_autograd_gradients():
+    """N = 1 form: zero_grad() sets gradients to None, step() gathers what autograd produced into the flat buffer; equal to
+    torch.optim.Adam, also when a parameter has no gradient in some step (zero-gradient convention)"""
+    torch.manual_seed(0)
+    a, b = Tiny(), Tiny()
+    b.load_state_dict(a.state_dict())
+    oa, ob = torch.optim.Adam(a.parameters(), lr=1e-2), _TorchMathFlatAdam(b.parameters(), lr=1e-2)
+    torch.manual_seed(5)
+    for it in range(4):
+        x = torch.randn(5, 4)
+        for net, opt in ((a, oa), (b, ob)):
+            loss = net(x, use_second=(it != 2))
+            opt.zero_grad()
+            loss.backward()
+        if it == 2:
+            assert b.sometimes.weight.grad is None
+            for p in a.sometimes.parameters():
+                p.grad = torch.zeros_like(p)          # torch would skip a None gradient; the flat form applies a zero one
+        oa.step()
+        ob.step()
+    assert all(p.grad is not None and p.grad.untyped_storage().data_ptr() != ob._flat[1].untyped_storage().data_ptr() for p in b.used.parameters())
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7), n
+    import copy
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))   # adoption of a loaded state at the next step (torch's load aliases same-device tensors)
+    x = torch.randn(5, 4)
+    for net, opt in ((a, oa), (b, ob)):
+        loss = net(x, use_second=True)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7), n
+
+
 def test_single_process_helpers_are_identity():
     t = torch.arange(6.0).view(2, 3)
     assert mdist.gather_rows(t) is t
