@@ -21,7 +21,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
-from ..cuda_functions import _nms_impl
 from ..cuda_functions._roi_align_impl import pyramid_crop_and_resize
 from ..cuda_functions.roi_align_2D.roi_align.crop_and_resize import CropAndResizeFunction as ra2D
 from ..cuda_functions.roi_align_3D.roi_align.crop_and_resize import CropAndResizeFunction as ra3D

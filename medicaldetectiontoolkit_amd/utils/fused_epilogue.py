@@ -3,9 +3,15 @@ residual / top-down add and the ReLU in ONE pass over the activation, and a back
 reduces the bias gradient in one pass (deterministic).  The convolution itself stays on MIOpen (torch, bias=None).
 
 The modules keep the reference's Sequential layout so state_dict keys are unchanged
-(utils/model_utils.py:732-781: `conv` -> Sequential(conv[, norm][, relu]) or a bare conv when relu is None)."""
-import ctypes
+(utils/model_utils.py:732-781: `conv` -> Sequential(conv[, norm][, relu]) or a bare conv when relu is None).
 
+Also here, because they hang off the same modules (each with a module switch for A/B runs and a test against its torch op):
+  * which convolution problem is posed: input gradients of unit-stride layers as forward convolutions (`_ConvStride1`), the stem in
+    space-to-depth form (`_ConvStem221`), channels-last max pooling and x2 up-sampling (csrc/pool.hip, csrc/upsample.hip);
+  * the layers MIOpen is 2-9x off its bound on, as fp32-MFMA kernels of this repo: 1x1x1 weight gradients
+    (`conv1x1_weight_grad`, csrc/conv1x1_wgrad.hip), few-channel 3x3x3 layers forward / input gradient / weight gradient
+    (`conv3x3x3_small*`, csrc/conv3x3x3_small.hip), the one-channel 7x7x7 stem forward with bias + ReLU epilogue and its weight
+    gradient (`stem_forward`, `_ConvStemBiasReLU`, `stem_weight_grad`; csrc/conv_stem_fwd.hip, csrc/conv_stem_wgrad.hip)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

@@ -22,7 +22,6 @@ for i in range(4):
     training.train_step(net, opt, pool[i % 2], monitor=False)
 torch.cuda.synchronize()
 # phase split without a profiler: forward+loss / backward / optimizer, host time only (no syncs inside)
-import types
 n = 6
 t_f = t_b = t_o = 0.0
 for i in range(n):
