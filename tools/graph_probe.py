@@ -2,7 +2,9 @@
 does torch.cuda.make_graphed_callables capture it with this repo's ctypes-launched kernels and MIOpen inside, are outputs and
 parameter gradients identical to eager, and what does it do to the HOST time of the segment (the step needs 38 ms
 of host time per 43 ms of GPU time)?  NOT part of the product; written at the end of round 3 to be run first thing in round 4.
-One JSON line.  usage: python tools/graph_probe.py [steps]"""
+One JSON line.  usage: python tools/graph_probe.py [steps]
+First run (end of round 3, profiles/r03_graph_probe_first_try.json): eager segment 39.7 ms GPU / 29.3 ms host of the 43 / 38 ms step;
+capture stopped at the FPN's two unused parameters (allow_unused_input was off) -- fixed here, not yet re-run."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from medicaldetectiontoolkit_amd import miopen_env
@@ -67,7 +69,7 @@ rec = {"segment": "image -> FPN -> RPN (+ row-major pyramid copies), fwd + bwd, 
 rec["eager_host_ms"], rec["eager_ms"] = timed(seg, img, steps)
 ref_out, ref_grad = run(seg, img)
 try:
-    graphed = torch.cuda.make_graphed_callables(seg, (img,), num_warmup_iters=3)
+    graphed = torch.cuda.make_graphed_callables(seg, (img,), num_warmup_iters=3, allow_unused_input=True)   # P1_conv1/2 are never used (backbone.py:112,118)
     rec["graphed_host_ms"], rec["graphed_ms"] = timed(graphed, img, steps)
     img2 = torch.randn_like(img)               # new input values through the static input buffer
     o_e, g_e = run(seg, img2)
