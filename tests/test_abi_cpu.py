@@ -93,3 +93,37 @@ def test_product_package_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 for bad in ("import oracle", "from oracle", "libmdt_oracle", "oracle/_ref"):
                     assert bad not in text, (os.path.join(dirpath, f), bad)
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """every prototype of include/mdt_hip.h has a ctypes signature in _lib._SIGNATURES with the same arity and, argument by
+    argument, the same class of type (pointer / int / long long / size_t / float / double): a wrong table passes pointers as
+    32-bit ints or shifts every later argument -- found once on the GPU box, now found here"""
+    import ctypes
+    import re
+    from medicaldetectiontoolkit_amd import _lib
+    header = open(os.path.join(ROOT, "include", "mdt_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = re.findall(r"\b(int|size_t|void|const char \*)\s*(mdt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, re.S)
+    assert len(protos) >= 50
+
+    def kind(decl):
+        decl = decl.strip()
+        if "*" in decl:
+            return "ptr"
+        base = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*$", "", decl).strip() or decl      # drop the parameter name
+        base = base.replace("const", "").strip()
+        return {"int": "int", "long long": "longlong", "size_t": "size_t", "float": "float", "double": "double"}[base]
+
+    ctype_kind = {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int: "int", ctypes.c_longlong: "longlong", ctypes.c_size_t: "size_t",
+                  ctypes.c_float: "float", ctypes.c_double: "double"}
+    ret_kind = {"int": ctypes.c_int, "size_t": ctypes.c_size_t, "void": None, "const char *": ctypes.c_char_p}
+    for ret, name, args in protos:
+        assert name in _lib._SIGNATURES, name
+        restype, argtypes = _lib._SIGNATURES[name]
+        assert restype is ret_kind[ret], (name, ret, restype)
+        decls = [] if args.strip() in ("", "void") else [a for a in args.split(",")]
+        assert len(decls) == len(argtypes), (name, len(decls), len(argtypes))
+        for i, (d, t) in enumerate(zip(decls, argtypes)):
+            assert kind(d) == ctype_kind[t], (name, i, d.strip(), t)
+    assert set(_lib._SIGNATURES) == {n for _, n, _ in protos}
