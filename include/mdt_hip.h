@@ -342,6 +342,22 @@ int mdt_anchor_match(const double *anchors, int n_anchors, int dim,
                      int *matches, int *iou_argmax, double *iou_max, int *gt_best_anchor,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The same matching for a whole batch in ONE launch pair, with the GT counts read on the DEVICE: replaces the per-element loop of
+ * models/mrcnn.py:894 / models/retina_unet.py:408-420 (one gt_anchor_matching call per batch element on the host).
+ *   gt_boxes [batch, gmax, 2*dim] f64 (rows >= n_gt[e] are ignored), gt_class_ids [batch, gmax] i32 or NULL,
+ *   n_gt_dev [batch] i32 DEVICE array (0 = "gt_boxes is None": every anchor of the element is negative, :524-526),
+ *   matches / iou_argmax [batch, A] i32, iou_max [batch, A] f64 or NULL, gt_best_anchor [batch, gmax] i32.
+ * No host-side count enters the launch, so a training step that calls it can be captured in a hipGraph.
+ * workspace: mdt_anchor_match_batched_workspace_bytes(A, batch, gmax).
+ */
+size_t mdt_anchor_match_batched_workspace_bytes(int n_anchors, int batch, int gmax);
+int mdt_anchor_match_batched(const double *anchors, int n_anchors, int dim, int batch,
+                             const double *gt_boxes, const int *gt_class_ids, const int *n_gt_dev, int gmax,
+                             double neg_thresh, double pos_thresh,
+                             int *matches, int *iou_argmax, double *iou_max, int *gt_best_anchor,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Weighted box clustering                                                    */
 /* ------------------------------------------------------------------------- */

@@ -67,6 +67,9 @@ _SIGNATURES = {
     "mdt_generate_anchors": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "mdt_anchor_match_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mdt_anchor_match": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_anchor_match_batched_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mdt_anchor_match_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
     "mdt_nms_2to3d_workspace_bytes": (c_size_t, [c_int]),
     "mdt_nms_2to3d": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_wbc_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -94,6 +97,33 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+_COUNTED = None     # {symbol: original ctypes function} while count_calls() is on
+CALLS = {}          # symbol -> number of calls since count_calls(True)
+
+
+def count_calls(enable=True):
+    """Test / diagnosis hook: count the calls of every C-ABI entry point by name (`CALLS`), so a test can assert that a use-rule really
+    dispatched the kernel it claims (e.g. mdt_conv3x3x3_small_forward inside the assembled training step) instead of silently
+    routing back to MIOpen.  Off by default: the ctypes functions are called directly, without a Python wrapper in between."""
+    global _COUNTED
+    handle = lib()
+    if enable and _COUNTED is None:
+        CALLS.clear()
+        _COUNTED = {}
+        for name in _SIGNATURES:
+            fn = getattr(handle, name)
+            _COUNTED[name] = fn
+
+            def counted(*a, _fn=fn, _name=name):
+                CALLS[_name] = CALLS.get(_name, 0) + 1
+                return _fn(*a)
+            setattr(handle, name, counted)
+    elif not enable and _COUNTED is not None:
+        for name, fn in _COUNTED.items():
+            setattr(handle, name, fn)
+        _COUNTED = None
 
 
 def check(code, what):

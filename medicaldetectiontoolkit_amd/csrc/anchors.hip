@@ -90,18 +90,38 @@ __device__ __forceinline__ double box_vol(const double *b)
 
 // pass 1: per anchor max / argmax over GT, step-1 and step-3 labels; per block and
 // per GT the best (iou, first anchor index) into `part`.
+// Batched form (blockIdx.y = batch element): the element's GT rows start at gt + e * gmax * 2 DIM, its count is read from
+// n_gt_dev[e] ON THE DEVICE (so the launch does not depend on host-side GT counts: the training step is capturable in a hipGraph
+// and needs no per-element launches); n_gt_dev == NULL is the single-problem form with the host count G (= gmax).
 template <int DIM>
 __global__ __launch_bounds__(MATCH_THREADS) void match_pass1_kernel(
     const double *__restrict__ anchors, int A, const double *__restrict__ gt, const int *__restrict__ gt_cls,
-    int G, double neg_thresh, double pos_thresh,
+    int G, const int *__restrict__ n_gt_dev, int gmax, double neg_thresh, double pos_thresh,
     int *__restrict__ matches, int *__restrict__ iou_argmax, double *__restrict__ iou_max,
     double *__restrict__ part_val, int *__restrict__ part_idx)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *s_gt = reinterpret_cast<double *>(smem_raw);           // [G][2*DIM]
-    double *s_vol = s_gt + (size_t)G * 2 * DIM;                     // [G]
-    double *s_red_v = s_vol + G;                                    // [MATCH_THREADS/64]
+    double *s_gt = reinterpret_cast<double *>(smem_raw);           // [gmax][2*DIM]
+    double *s_vol = s_gt + (size_t)gmax * 2 * DIM;                  // [gmax]
+    double *s_red_v = s_vol + gmax;                                 // [MATCH_THREADS/64]
     int *s_red_i = reinterpret_cast<int *>(s_red_v + MATCH_THREADS / 64);
+    {
+        const size_t e = blockIdx.y;
+        gt += e * (size_t)gmax * 2 * DIM;
+        if (gt_cls) gt_cls += e * (size_t)gmax;
+        matches += e * (size_t)A;
+        iou_argmax += e * (size_t)A;
+        iou_max += e * (size_t)A;
+        part_val += e * (size_t)gridDim.x * gmax;
+        part_idx += e * (size_t)gridDim.x * gmax;
+        if (n_gt_dev) G = min(max(n_gt_dev[e], 0), gmax);
+    }
+    if (G == 0) {   // "gt_boxes is None": every anchor negative (model_utils.py:524-526)
+        const int per = (A + gridDim.x - 1) / gridDim.x;
+        const int b0 = blockIdx.x * per, b1 = min(A, b0 + per);
+        for (int a = b0 + threadIdx.x; a < b1; a += MATCH_THREADS) { matches[a] = -1; iou_argmax[a] = 0; iou_max[a] = 0.0; }
+        return;
+    }
 
     for (int t = threadIdx.x; t < G * 2 * DIM; t += MATCH_THREADS) s_gt[t] = gt[t];
     __syncthreads();
@@ -168,12 +188,22 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_pass1_kernel(
 // pass 2 (one block): reduce partials per GT (all threads), then apply step 2 (model_utils.py:556-559)
 // in GT order, not overriding step-3 positives (:562-563 runs after step 2).
 __global__ __launch_bounds__(256) void match_pass2_kernel(
-    const double *__restrict__ part_val, const int *__restrict__ part_idx, int n_blocks, int G,
-    const int *__restrict__ gt_cls, double pos_thresh, const double *__restrict__ iou_max,
+    const double *__restrict__ part_val, const int *__restrict__ part_idx, int n_blocks, int G, const int *__restrict__ n_gt_dev, int gmax,
+    int A, const int *__restrict__ gt_cls, double pos_thresh, const double *__restrict__ iou_max,
     int *__restrict__ matches, int *__restrict__ gt_best)
 {
     __shared__ double s_v[4];
     __shared__ int s_i[4];
+    {
+        const size_t e = blockIdx.x;      // one block per batch element
+        part_val += e * (size_t)n_blocks * gmax;
+        part_idx += e * (size_t)n_blocks * gmax;
+        if (gt_cls) gt_cls += e * (size_t)gmax;
+        iou_max += e * (size_t)A;
+        matches += e * (size_t)A;
+        gt_best += e * (size_t)gmax;
+        if (n_gt_dev) G = min(max(n_gt_dev[e], 0), gmax);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int g = 0; g < G; ++g) {
         double bv = -1.0;
@@ -296,12 +326,53 @@ int mdt_anchor_match(const double *anchors, int n_anchors, int dim,
     const size_t lds = ((size_t)n_gt * (2 * dim + 1) + MATCH_THREADS / 64) * sizeof(double) + (MATCH_THREADS / 64) * sizeof(int);
     if (lds > 60 * 1024) return MDT_ERR_UNSUPPORTED;
     if (dim == 3) hipLaunchKernelGGL(match_pass1_kernel<3>, dim3(nb), dim3(MATCH_THREADS), lds, s, anchors, n_anchors, gt_boxes,
-                           gt_class_ids, n_gt, neg_thresh, pos_thresh, matches, iou_argmax, iou_max_buf, part_val, part_idx);
+                           gt_class_ids, n_gt, (const int *)nullptr, n_gt, neg_thresh, pos_thresh, matches, iou_argmax, iou_max_buf, part_val, part_idx);
     else hipLaunchKernelGGL(match_pass1_kernel<2>, dim3(nb), dim3(MATCH_THREADS), lds, s, anchors, n_anchors, gt_boxes,
-                           gt_class_ids, n_gt, neg_thresh, pos_thresh, matches, iou_argmax, iou_max_buf, part_val, part_idx);
+                           gt_class_ids, n_gt, (const int *)nullptr, n_gt, neg_thresh, pos_thresh, matches, iou_argmax, iou_max_buf, part_val, part_idx);
     if (check_launch() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
-    (void)hipGetLastError(); hipLaunchKernelGGL(match_pass2_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, nb, n_gt, gt_class_ids,
-                       pos_thresh, iou_max_buf, matches, gt_best_anchor);
+    (void)hipGetLastError(); hipLaunchKernelGGL(match_pass2_kernel, dim3(1), dim3(256), 0, s, part_val, part_idx, nb, n_gt, (const int *)nullptr, n_gt,
+                       n_anchors, gt_class_ids, pos_thresh, iou_max_buf, matches, gt_best_anchor);
+    return check_launch();
+}
+
+size_t mdt_anchor_match_batched_workspace_bytes(int n_anchors, int batch, int gmax)
+{
+    if (n_anchors <= 0 || gmax <= 0 || batch <= 0) return 16;
+    const size_t nb = (size_t)match_blocks(n_anchors);
+    size_t bytes = (size_t)batch * nb * gmax * (sizeof(double) + sizeof(int));   // part_val, part_idx per element
+    bytes = (bytes + 15) & ~(size_t)15;
+    bytes += (size_t)batch * n_anchors * sizeof(double);                          // iou_max when the caller passes NULL
+    return (bytes + 255) & ~(size_t)255;
+}
+
+int mdt_anchor_match_batched(const double *anchors, int n_anchors, int dim, int batch,
+                             const double *gt_boxes, const int *gt_class_ids, const int *n_gt_dev, int gmax,
+                             double neg_thresh, double pos_thresh,
+                             int *matches, int *iou_argmax, double *iou_max, int *gt_best_anchor,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    (void)hipGetLastError();
+    if (n_anchors < 0 || batch < 0 || gmax < 1 || (dim != 2 && dim != 3) || !matches || !iou_argmax || !gt_boxes || !n_gt_dev || !gt_best_anchor)
+        return MDT_ERR_INVALID_ARGUMENT;
+    if (n_anchors == 0 || batch == 0) return MDT_OK;
+    if (batch > 65535) return MDT_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < mdt_anchor_match_batched_workspace_bytes(n_anchors, batch, gmax)) return MDT_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = match_blocks(n_anchors);
+    char *ws = reinterpret_cast<char *>(workspace);
+    double *part_val = reinterpret_cast<double *>(ws);
+    int *part_idx = reinterpret_cast<int *>(ws + (size_t)batch * nb * gmax * sizeof(double));
+    const size_t off = ((size_t)batch * nb * gmax * (sizeof(double) + sizeof(int)) + 15) & ~(size_t)15;
+    double *iou_max_buf = iou_max ? iou_max : reinterpret_cast<double *>(ws + off);
+    const size_t lds = ((size_t)gmax * (2 * dim + 1) + MATCH_THREADS / 64) * sizeof(double) + (MATCH_THREADS / 64) * sizeof(int);
+    if (lds > 60 * 1024) return MDT_ERR_UNSUPPORTED;
+    if (dim == 3) hipLaunchKernelGGL(match_pass1_kernel<3>, dim3(nb, batch), dim3(MATCH_THREADS), lds, s, anchors, n_anchors, gt_boxes,
+                           gt_class_ids, gmax, n_gt_dev, gmax, neg_thresh, pos_thresh, matches, iou_argmax, iou_max_buf, part_val, part_idx);
+    else hipLaunchKernelGGL(match_pass1_kernel<2>, dim3(nb, batch), dim3(MATCH_THREADS), lds, s, anchors, n_anchors, gt_boxes,
+                           gt_class_ids, gmax, n_gt_dev, gmax, neg_thresh, pos_thresh, matches, iou_argmax, iou_max_buf, part_val, part_idx);
+    if (check_launch() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
+    (void)hipGetLastError(); hipLaunchKernelGGL(match_pass2_kernel, dim3(batch), dim3(256), 0, s, part_val, part_idx, nb, gmax, n_gt_dev, gmax,
+                       n_anchors, gt_class_ids, pos_thresh, iou_max_buf, matches, gt_best_anchor);
     return check_launch();
 }
 

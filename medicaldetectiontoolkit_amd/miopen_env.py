@@ -8,35 +8,81 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CACHE_DIR = os.path.join(HERE, "miopen_cache")
 
 
-def _cleanup(path, pid):
+def _tree_hash(d):
+    """identity of the committed cache: names, sizes and mtimes-independent content hash of the find-db text files (the kernel
+    cache is derived data)"""
+    import hashlib
+    h = hashlib.sha256()
+    db = os.path.join(d, "db")
+    for name in sorted(os.listdir(db)) if os.path.isdir(db) else []:
+        h.update(name.encode())
+        try:
+            with open(os.path.join(db, name), "rb") as f:
+                h.update(f.read())
+        except OSError:
+            pass
+    return h.hexdigest()[:12]
+
+
+def _sweep_stale_pid_copies():
+    """round-3 scheme left one /tmp/mdt_miopen_cache_u<uid>_rank<k>_pid<pid> per process; ranks torn down with SIGTERM never ran
+    their atexit handler.  Remove the copies whose process is gone."""
+    import re
     import shutil
-    if os.getpid() == pid:        # forked children (mp.spawn uses spawn, DataLoader may fork) must not delete the parent's copy
-        shutil.rmtree(path, ignore_errors=True)
+    import tempfile
+    tmp = tempfile.gettempdir()
+    try:
+        names = os.listdir(tmp)
+    except OSError:
+        return
+    for name in names:
+        m = re.match(r"mdt_miopen_cache_u%d_rank\w+_pid(\d+)$" % os.getuid(), name)
+        if m and not os.path.exists("/proc/%s" % m.group(1)):
+            shutil.rmtree(os.path.join(tmp, name), ignore_errors=True)
+
+
+def _overlay_root():
+    for base in (os.environ.get("XDG_CACHE_HOME"), os.path.join(os.path.expanduser("~"), ".cache")):
+        if base:
+            try:
+                os.makedirs(os.path.join(base, "mdt_miopen"), exist_ok=True)
+                if os.access(os.path.join(base, "mdt_miopen"), os.W_OK):
+                    return os.path.join(base, "mdt_miopen")
+            except OSError:
+                pass
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), "mdt_miopen_u%d" % os.getuid())
 
 
 def setup(cache_dir=None):
     d = cache_dir or os.environ.get("MDT_MIOPEN_CACHE", CACHE_DIR)
     if cache_dir is None and "MDT_MIOPEN_CACHE" not in os.environ and not os.environ.get("MDT_MIOPEN_CACHE_INPLACE"):
-        # every process works on its OWN copy of the in-tree cache (seeded from it): N ranks never write the same
-        # find-db / kernel-cache files concurrently, and a run never dirties the committed files.
-        # MDT_MIOPEN_CACHE_INPLACE=1 writes into the tree (to refresh the committed cache after a new find).
-        # The copy is private to THIS process (pid in the name, removed at exit) and made atomically (copy to a scratch
-        # name, then rename): a refreshed in-tree cache is never shadowed by a stale temp copy, an interrupted copy is
-        # never taken for a valid cache, and two independent single-GPU processes (pytest + bench) never share files.
-        import atexit
+        # The committed cache is never written (a run does not dirty the tree) and N ranks never share files: each rank works on
+        # a PERSISTENT per-user overlay  <cache root>/mdt_miopen/<hash of the committed find-db>/rank<k>, seeded from the tree by
+        # copy-then-rename (an interrupted copy is never taken for a cache).  Persistent, because a find result for a shape the
+        # committed db lacks (a user's own patch size, a new layer) must survive the process -- the round-3 per-pid copies were
+        # deleted at exit, so every start repeated the ~1 min find (ADVICE r3); keyed by the tree's hash, so a refreshed
+        # committed cache is never shadowed by a stale overlay.  MIOpen's own file locking covers two processes of one rank
+        # (pytest + bench).  MDT_MIOPEN_CACHE_INPLACE=1 writes into the tree (to refresh the committed cache after a new find).
         import shutil
         import tempfile
         rank = os.environ.get("RANK", "0")
-        dst = os.path.join(tempfile.gettempdir(), "mdt_miopen_cache_u%d_rank%s_pid%d" % (os.getuid(), rank, os.getpid()))
+        _sweep_stale_pid_copies()
         try:
             if os.path.isdir(d):
+                root = os.path.join(_overlay_root(), _tree_hash(d))
+                dst = os.path.join(root, "rank%s" % rank)
                 if not os.path.isdir(dst):
-                    scratch = tempfile.mkdtemp(prefix="mdt_miopen_cache_tmp_")
+                    os.makedirs(root, exist_ok=True)
+                    scratch = tempfile.mkdtemp(prefix="seed_", dir=root)
                     shutil.copytree(d, os.path.join(scratch, "c"))
-                    os.rename(os.path.join(scratch, "c"), dst)
+                    try:
+                        os.rename(os.path.join(scratch, "c"), dst)
+                    except OSError:          # another process of this rank won the race: use its copy
+                        pass
                     shutil.rmtree(scratch, ignore_errors=True)
-                    atexit.register(_cleanup, dst, os.getpid())
-                d = dst
+                if os.path.isdir(dst):
+                    d = dst
         except OSError:
             pass
     try:
@@ -52,6 +98,7 @@ def setup(cache_dir=None):
     for key, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "kernels")):
         # a value inherited from a parent process that ran setup() (mp.spawn workers, bench.py's self-launched ranks) points
         # at the PARENT's private copy: replace it; a value the user exported is respected
-        if key not in os.environ or "mdt_miopen_cache_" in os.environ[key]:
+        v = os.environ.get(key)
+        if v is None or "/mdt_miopen/" in v or "/mdt_miopen_u" in v or "mdt_miopen_cache_u" in v:
             os.environ[key] = os.path.join(d, sub)
     return d

@@ -244,6 +244,33 @@ def anchor_match_labels(anchors, gt_boxes, gt_class_ids, neg_thresh, pos_thresh)
     return matches, argmax, iou_max, gt_best[:G]
 
 
+def anchor_match_labels_batched(anchors, gt_boxes, n_gt, gt_class_ids=None, neg_thresh=0.01, pos_thresh=0.5):
+    """anchor_match_labels for a whole batch in ONE launch pair (mdt_anchor_match_batched), the per-element GT counts read on the
+    device: replaces the loop over batch elements of models/mrcnn.py:894 / retina_unet.py:408 -- and, because no host-side count
+    enters the launch, keeps the training step free of host-dependent launch parameters (capturable in a hipGraph).
+    anchors [A, 2*dim] f64; gt_boxes [B, Gmax, 2*dim] f64 (rows >= n_gt[b] ignored); n_gt [B] i32 DEVICE tensor;
+    gt_class_ids [B, Gmax] i32 or None.  Returns matches [B, A] i32, iou_argmax [B, A] i32."""
+    L = _lib.lib()
+    dev = anchors.device
+    A, dim = anchors.size(0), anchors.size(1) // 2
+    B, gmax = int(gt_boxes.shape[0]), int(gt_boxes.shape[1])
+    anchors = anchors.contiguous()
+    gt_boxes = gt_boxes.to(dtype=torch.float64).contiguous()
+    n_gt = n_gt.to(dtype=torch.int32).contiguous()
+    cls = gt_class_ids.to(dtype=torch.int32).contiguous() if gt_class_ids is not None else None
+    matches = torch.empty((B, A), dtype=torch.int32, device=dev)
+    argmax = torch.empty((B, A), dtype=torch.int32, device=dev)
+    gt_best = torch.empty((B, gmax), dtype=torch.int32, device=dev)
+    wsb = L.mdt_anchor_match_batched_workspace_bytes(A, B, gmax)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.mdt_anchor_match_batched(_lib.ptr(anchors), A, dim, B, _lib.ptr(gt_boxes), _lib.ptr(cls), _lib.ptr(n_gt), gmax,
+                                        ctypes.c_double(neg_thresh), ctypes.c_double(pos_thresh), _lib.ptr(matches), _lib.ptr(argmax),
+                                        None, _lib.ptr(gt_best), _lib.ptr(ws), wsb, _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_anchor_match_batched")
+    return matches, argmax
+
+
 def anchor_delta_targets(anchors, gt_boxes, std_dev):
     """Delta targets of matched (anchor, gt) rows, utils/model_utils.py:575-617 (float64)."""
     dim = anchors.size(1) // 2

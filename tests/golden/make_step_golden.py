@@ -10,7 +10,10 @@ retina_unet.compute_class_loss (20 -> 1; the call site does not pass it, retina_
 
 Two passes for Mask R-CNN: (1) `forward` only, to read the proposals the name-seeded weights produce; two of them per
 batch element become the GT boxes (rounded to integers) so that detection_target_layer finds positive RoIs; (2) the step.
-Run once in the build container:  timeout 1800 python tests/golden/make_step_golden.py"""
+Run once in the build container:  timeout 1800 python tests/golden/make_step_golden.py [small|large]
+`large` (round 4) = patch 128 x 128 x 64, batch 1 -> step_reference_large.npz: the C2 map has 65 536 voxels, the size from which this
+repo's fp32-MFMA convolution kernels are dispatched, so the assembled-step parity covers them (tests/test_step_parity_gpu.py asserts
+the dispatch)."""
 import importlib.util
 import logging
 import os
@@ -129,14 +132,16 @@ def grad_norms(net):
     return {k: float(np.sqrt(sum(v))) for k, v in mods.items()}
 
 
-def main():
+def main(case="small"):
     log = logging.getLogger("step_golden")
     log.addHandler(logging.NullHandler())
     out = {}
-    img = si.make_image()
+    img = si.make_image(case=case)
+    nb = si.CASES[case][1]
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
     # ------------------------------------------------------------------ Mask R-CNN
-    cf = si.make_cf("mrcnn")
+    cf = si.make_cf("mrcnn", case)
     cf.backbone_path = os.path.join(REF, "models/backbone.py")
     net = mr.net(cf, log)
     si.fill_by_name(net)
@@ -146,7 +151,7 @@ def main():
     props = net.rpn_rois_batch_info.numpy()                     # normalised (y1, x1, y2, x2, z1, z2, batch_ix)
     scale = np.asarray(cf.scale, dtype=np.float64)
     gt_boxes, gt_labels = [], []
-    for b in range(si.B):
+    for b in range(nb):
         pb = props[props[:, -1] == b][:, :6] * scale
         lo_cols, hi_cols = [0, 1, 4], [2, 3, 5]
         pb[:, lo_cols] = np.floor(pb[:, lo_cols])               # outward rounding: the GT box contains its proposal
@@ -164,7 +169,7 @@ def main():
                 break
         gt_boxes.append(pb[chosen].astype(np.float32))
         gt_labels.append(np.array([1, 2][:len(chosen)] if b == 0 else [2, 1][:len(chosen)], dtype=np.int64))
-    for b in range(si.B):
+    for b in range(nb):
         out["gt_boxes_%d" % b] = gt_boxes[b]
         out["gt_labels_%d" % b] = gt_labels[b]
     batch = si.make_batch(img, gt_boxes, gt_labels)
@@ -175,7 +180,7 @@ def main():
     with torch04():
         res = net.train_forward(batch)
     for k, r in rec.items():      # RPN terms: sum_b loss_b / B (mrcnn.py:911-912); head terms: one call each
-        out["mrcnn_term_" + k] = np.float64(sum(r.vals) / (si.B if k.startswith("rpn") else 1))
+        out["mrcnn_term_" + k] = np.float64(sum(r.vals) / (nb if k.startswith("rpn") else 1))
     net.zero_grad()
     res["torch_loss"].backward()
     ls = res["logger_string"]
@@ -193,8 +198,11 @@ def main():
                                                 sum(1 for bl in res["boxes"] for bx in bl if bx["box_type"] == "neg_anchor")])
     print("mrcnn:", ls, out["mrcnn_n_pos_neg_rois"], out["mrcnn_n_pos_neg_anchors"])
 
+    if case == "bench":       # the benchmarked configuration: Mask R-CNN only
+        np.savez_compressed(os.path.join(HERE, "step_reference_%s.npz" % case), **out)
+        return
     # ------------------------------------------------------------------ Retina U-Net (K = 3 class logits, dice + CE seg loss)
-    cfr = si.make_cf("retina_unet")
+    cfr = si.make_cf("retina_unet", case)
     cfr.backbone_path = os.path.join(REF, "models/backbone.py")
     ru.compute_class_loss.__defaults__ = (1,)                   # shem_poolsize default 20 -> 1 (deterministic SHEM)
     netr = ru.net(cfr, log)
@@ -206,7 +214,7 @@ def main():
     with torch04():
         resr = netr.train_forward(batch)
     for k, r in recr.items():
-        out["retina_term_" + k] = np.float64(sum(r.vals) / si.B)
+        out["retina_term_" + k] = np.float64(sum(r.vals) / nb)
     out["retina_term_seg_dice"] = np.float64(1.0 - dice.vals[0])
     out["retina_term_seg_ce"] = np.float64(2.0 * (resr["torch_loss"].item() - out["retina_term_class"] - out["retina_term_bbox"]) - out["retina_term_seg_dice"])
     netr.zero_grad()
@@ -219,10 +227,10 @@ def main():
     out["retina_n_pos_neg_anchors"] = np.array([sum(1 for bl in resr["boxes"] for bx in bl if bx["box_type"] == "pos_anchor"),
                                                  sum(1 for bl in resr["boxes"] for bx in bl if bx["box_type"] == "neg_anchor")])
     print("retina:", resr["logger_string"], out["retina_n_pos_neg_anchors"])
-    np.savez_compressed(os.path.join(HERE, "step_reference.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "step_reference.npz" if case == "small" else "step_reference_%s.npz" % case), **out)
     for k, v in out.items():
         print(k, np.asarray(v).shape, v if np.asarray(v).size < 8 else "")
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "small")

@@ -4,7 +4,13 @@ backward of /root/reference/models/mrcnn.py:801-1082 and /root/reference/models/
 the CPU with name-seeded shared weights (tests/golden/make_step_golden.py).  Here the same batch goes through this repo's
 `train_forward` on the GPU (HIP RoIAlign / NMS / matching kernels, MIOpen convolutions, re-designed glue).
 
-Bars: every loss term 1e-4 relative (+1e-6 absolute), sampled-set sizes equal, module gradient norms 1e-3 relative."""
+Bars: every loss term 1e-4 relative (+1e-6 absolute), sampled-set sizes equal, module gradient norms 1e-3 relative.
+
+Round 4: two more cases whose C2 maps are large enough for this repo's fp32-MFMA convolution kernels to be
+DISPATCHED (utils/fused_epilogue.py use-rules: >= 65 536 voxels) -- `large` = 128 x 128 x 64, batch 1 (both models) and `bench` =
+THE BENCHMARKED CONFIGURATION, 128^3, batch 8 (Mask R-CNN; BASELINE config 3).  The tests count the C-ABI calls (`_lib.count_calls`)
+and fail if conv3x3x3_small forward / input gradient / weight gradient, conv1x1_wgrad or the stem pair did not run, i.e. if a
+use-rule silently routed the layer back to MIOpen."""
 import os
 
 import numpy as np
@@ -14,13 +20,24 @@ import torch
 from tests.golden import step_inputs as si
 
 pytestmark = pytest.mark.gpu
-GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step_reference.npz"), allow_pickle=False)
+_GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLD = np.load(os.path.join(_GDIR, "step_reference.npz"), allow_pickle=False)
+GOLDS = {"small": GOLD, "large": np.load(os.path.join(_GDIR, "step_reference_large.npz"), allow_pickle=False),
+         "bench": np.load(os.path.join(_GDIR, "step_reference_bench.npz"), allow_pickle=False)}
 
 
-def _batch():
-    gt_boxes = [GOLD["gt_boxes_%d" % b] for b in range(si.B)]
-    gt_labels = [GOLD["gt_labels_%d" % b] for b in range(si.B)]
-    return si.make_batch(si.make_image(), gt_boxes, gt_labels)
+def _batch(case="small"):
+    gold, nb = GOLDS[case], si.CASES[case][1]
+    gt_boxes = [gold["gt_boxes_%d" % b] for b in range(nb)]
+    gt_labels = [gold["gt_labels_%d" % b] for b in range(nb)]
+    return si.make_batch(si.make_image(case=case), gt_boxes, gt_labels)
+
+
+# the fp32-MFMA convolution kernels of this repo and the least number of calls one training step of the backbone must make:
+# C2 has three ResBlocks: conv2 (18 -> 18, 3x3x3) forward x3 + input gradient x3 on the same kernel, weight gradient x3; the 1x1x1
+# layers conv1 / conv3 / downsample of C2 (+ P2_conv1) weight gradients; the one-channel stem forward and weight gradient
+MFMA_CALLS = {"mdt_conv3x3x3_small_forward": 6, "mdt_conv3x3x3_small_wgrad": 3, "mdt_conv1x1_wgrad": 6, "mdt_conv_stem_forward": 1,
+              "mdt_conv_stem_wgrad": 1}
 
 
 def _grad_norms(net):
@@ -57,6 +74,85 @@ def test_mrcnn_train_forward_matches_reference_step(channels_last, cuda):
     res["torch_loss"].backward()
     for k, v in _grad_norms(net).items():
         _close(v, float(GOLD["mrcnn_gradnorm_" + k]), 1e-3, "mrcnn grad norm of " + k)
+
+
+@pytest.mark.parametrize("case", ["large", "bench"])
+def test_mrcnn_step_matches_reference_with_mfma_conv_kernels_dispatched(case, cuda):
+    """the assembled Mask R-CNN step at sizes where conv3x3x3_small / conv1x1_wgrad / conv_stem_* RUN (`bench` = 128^3, batch 8:
+    the configuration bench.py times), against the reference's own train_forward + backward on the CPU"""
+    from medicaldetectiontoolkit_amd import _lib, miopen_env
+    miopen_env.setup()
+    from medicaldetectiontoolkit_amd.models import mrcnn
+    gold = GOLDS[case]
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True           # as bench.py: the exhaustive find, not the immediate-mode naive solvers
+    try:
+        cf = si.make_cf("mrcnn", case)
+        cf.channels_last = True
+        net = mrcnn.net(cf, device=cuda)
+        si.fill_by_name(net)
+        torch.manual_seed(0)
+        _lib.count_calls(True)
+        try:
+            res = net.train_forward(_batch(case), monitor=True)
+            net.zero_grad()
+            res["torch_loss"].backward()
+            torch.cuda.synchronize()
+            calls = dict(_lib.CALLS)
+        finally:
+            _lib.count_calls(False)
+    finally:
+        torch.backends.cudnn.benchmark = prev
+    for name, least in MFMA_CALLS.items():
+        assert calls.get(name, 0) >= least, "%s ran %d time(s), expected >= %d: a use-rule routed the layer back to MIOpen (%s)" % (
+            name, calls.get(name, 0), least, {k: v for k, v in calls.items() if "conv" in k})
+    terms = {k: float(v) for k, v in res["loss_terms"].items()}
+    for k in ("rpn_class", "rpn_bbox", "mrcnn_class", "mrcnn_bbox", "mrcnn_mask"):
+        _close(terms[k], float(gold["mrcnn_term_" + k]), 1e-4, "mrcnn[%s] %s" % (case, k))
+    _close(float(res["torch_loss"]), float(gold["mrcnn_loss"]), 1e-4, "mrcnn[%s] total loss" % case)
+    n_valid, n_pos = [int(v) for v in res["sample_counts"]]
+    assert [n_pos, n_valid - n_pos] == gold["mrcnn_n_pos_neg_rois"].tolist()
+    boxes = [bx for bl in res["boxes"] for bx in bl]
+    assert [sum(1 for bx in boxes if bx["box_type"] == t) for t in ("pos_anchor", "neg_anchor")] == gold["mrcnn_n_pos_neg_anchors"].tolist()
+    for k, v in _grad_norms(net).items():
+        _close(v, float(gold["mrcnn_gradnorm_" + k]), 1e-3, "mrcnn[%s] grad norm of %s" % (case, k))
+
+
+def test_retina_unet_large_step_matches_reference_with_mfma_conv_kernels_dispatched(cuda):
+    """Retina U-Net at 128 x 128 x 64, batch 1 (decoder up to P0 at full resolution): same bars, same dispatch assertion"""
+    from medicaldetectiontoolkit_amd import _lib, miopen_env
+    miopen_env.setup()
+    from medicaldetectiontoolkit_amd.models import retina_unet
+    gold = GOLDS["large"]
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        cf = si.make_cf("retina_unet", "large")
+        cf.channels_last = True
+        net = retina_unet.net(cf, device=cuda)
+        si.fill_by_name(net)
+        torch.manual_seed(0)
+        _lib.count_calls(True)
+        try:
+            res = net.train_forward(_batch("large"), monitor=True)
+            net.zero_grad()
+            res["torch_loss"].backward()
+            torch.cuda.synchronize()
+            calls = dict(_lib.CALLS)
+        finally:
+            _lib.count_calls(False)
+    finally:
+        torch.backends.cudnn.benchmark = prev
+    for name in ("mdt_conv3x3x3_small_forward", "mdt_conv3x3x3_small_wgrad", "mdt_conv1x1_wgrad"):
+        assert calls.get(name, 0) >= MFMA_CALLS[name], (name, calls)
+    terms = {k: float(v) for k, v in res["loss_terms"].items()}
+    for k in ("class", "bbox", "seg_dice", "seg_ce"):
+        _close(terms[k], float(gold["retina_term_" + k]), 1e-4, "retina[large] " + k)
+    _close(float(res["torch_loss"]), float(gold["retina_loss"]), 1e-4, "retina[large] total loss")
+    boxes = [bx for bl in res["boxes"] for bx in bl]
+    assert [sum(1 for bx in boxes if bx["box_type"] == t) for t in ("pos_anchor", "neg_anchor")] == gold["retina_n_pos_neg_anchors"].tolist()
+    for k, v in _grad_norms(net).items():
+        _close(v, float(gold["retina_gradnorm_" + k]), 1e-3, "retina[large] grad norm of " + k)
 
 
 def test_retina_unet_train_forward_matches_reference_step(cuda):
