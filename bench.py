@@ -9,6 +9,10 @@ patches (LIDC-shape config 3), one process per GPU, plus the RoIAlign-3D-backwar
 
 A "step" = exec.py:68-74 of the reference: net.train_forward(batch) [incl. H2D of the batch], zero_grad,
 backward, (gradient all-reduce over RCCL when N > 1), Adam step; per-GPU batch = 8 patches (weak scaling).
+Since round 4 the device half of the step is ONE hipGraph replay (training.GraphedTrainStep; `--graph 0` = the eager step, which
+is also timed as an A/B leg in every line: `eager_step`).  `exec_equivalent` is the step as exec.py consumes it: host numpy batches
+(uploaded behind the previous step by training.DevicePrefetcher), the monitoring read-out (`logger_string`, `boxes`,
+`monitor_values`) taken every step, the mask head over the detections run like the reference does (mrcnn.py:1046-1048).
 Rank 0 prints ONE JSON line.  `roofline` is the dominant custom kernel (RoIAlign-3D backward on the P2 level):
 algorithmic bytes / event-timed duration of the C-ABI op with 48 RoIs of the SURVEY.md 8(d) box distribution on the
 level, measured after the timed training loop; `roofline.variants` carries the cache-cold run, the train-realistic
@@ -49,7 +53,7 @@ def cpu_baseline(cf, anchors, seconds_budget=25.0):
     from medicaldetectiontoolkit_amd.models.mrcnn import RPN, Classifier, Mask
     from medicaldetectiontoolkit_amd.utils.model_utils import NDConvGenerator
     from oracle import host_numpy, oracle
-    from tests.helpers import nms_boxes, random_boxes_3d
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import nms_boxes, random_boxes_3d
     threads = torch.get_num_threads()
     t_start = time.time()
     conv = NDConvGenerator(cf.dim)
@@ -107,13 +111,16 @@ def cpu_baseline(cf, anchors, seconds_budget=25.0):
                       % ("x".join(map(str, cf.patch_size)), t_conv, cf.pre_nms_limit, t_ops, anchors.shape[0], t_match, t_heads, time.time() - t_start)}
 
 
-def _time_op(fn, launches, warmup=10):
-    """event-bracketed launches on the current stream (the stream the kernels are launched on); seconds per launch"""
+def _time_op(fn, launches, warmup=10, pre=None):
+    """event-bracketed launches on the current stream (the stream the kernels are launched on); seconds per launch.  `pre` runs before
+    every launch OUTSIDE the event bracket (used to put the op's small inputs into the cache state they have inside the step)"""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
     for a, b in ev:
+        if pre is not None:
+            pre()
         a.record()
         fn()
         b.record()
@@ -124,8 +131,8 @@ def _time_op(fn, launches, warmup=10):
 
 def _pyramid_case(rng, cf, batch, n_per_level):
     """48 sampled RoIs routed to the four levels like the level rule of mrcnn.py:403 would (box side ~ anchor scale of the
-    level): tests/helpers.trainlike_rois_3d per level, shuffled row order"""
-    from tests.helpers import trainlike_rois_3d
+    level): utils/synthetic_data.trainlike_rois_3d per level, shuffled row order"""
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import trainlike_rois_3d
     per = []
     for li, n in enumerate(n_per_level):
         side = float(cf.rpn_anchor_scales["xy"][li][0])
@@ -137,7 +144,7 @@ def _pyramid_case(rng, cf, batch, n_per_level):
             np.concatenate([q[2] for q in per])[order])
 
 
-def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
+def roialign_bwd_roofline(cf, batch, dev, in_step_prof, in_step_prof48=None, launches=60):
     """Roofline of the dominant custom kernel, RoIAlign-3D backward: algorithmic bytes (every gradient
     map written once + the pooled gradients read once + 28 B per RoI) / event-timed duration of the C-ABI op, measured
     after the training loop.  pool (14,14,5), N = 48 valid RoIs.
@@ -148,7 +155,7 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
                  RoIs per element around one object, level-sized boxes) warm and cold, all four pyramid levels in ONE launch
                  with the 48 RoIs routed 24/12/8/4 (warm and cold), and the op as it ran inside the timed training steps."""
     from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
-    from tests.helpers import random_boxes_3d, trainlike_rois_3d
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import random_boxes_3d, trainlike_rois_3d
     shapes = [(batch, cf.end_filts) + tuple(int(v) for v in sh) for sh in cf.backbone_shapes]
     shape = shapes[0]
     crop = tuple(cf.mask_pool_size)
@@ -178,13 +185,18 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
         r["traffic"] = t["hbm_bytes"] if t else None
         return r
 
-    def single(boxes, ind, cold, tkey=None):
+    def single(boxes, ind, cold, tkey=None, touch=False):
         bx, bi = torch.from_numpy(boxes).to(dev), torch.from_numpy(ind).to(dev)
 
         def fn():
             state["k"] += 1
             _roi_align_impl.crop_backward(g, bx, bi, shape, out=rot[state["k"] % n_rot if cold else 0])
-        return rec_of(*_time_op(fn, launches), alg, n, tkey)
+
+        def pre():       # what the step does right before this op: the mask head's backward has just WRITTEN g, the boxes were just read
+            g.add_(0.0)
+            bx.add_(0.0)
+            bi.add_(0)
+        return rec_of(*_time_op(fn, launches, pre=pre if touch else None), alg, n, tkey)
 
     def pyramid(cold):
         bx, bi, lv = torch.from_numpy(pb).to(dev), torch.from_numpy(pi).to(dev), torch.from_numpy(pl).to(dev)
@@ -204,10 +216,17 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
         return {"achieved": round(byts / mean_s / 1e9, 1), "frac": round(byts / mean_s / HBM_PEAK_BPS, 4), "avg_us": round(mean_s * 1e6, 2),
                 "median_us": round(med_s * 1e6, 2), "launches": launches, "bytes": int(byts)}
 
-    head = single(rb, ri, False, "survey_random_48_rois")
+    warm = single(rb, ri, False, "survey_random_48_rois")
+    # HEADLINE (round 4, ADVICE r3 / VERDICT r3 item 3): the cache state the op has inside a training step -- the 151 MB gradient map
+    # is fresh memory (4 rotating output buffers = 604 MB > the 256 MiB Infinity Cache: every launch writes lines the cache does not
+    # hold), while the pooled gradients `g` and the boxes were produced microseconds earlier (touched right before the launch,
+    # outside the event bracket).  The same-buffer (cache-warm) and everything-cold figures are variants.
+    head = single(rb, ri, True, "survey_random_48_rois", touch=True)
     variants = {
+        "P2_survey_8d_random_boxes_same_output_buffer_cache_warm": warm,
         "P2_survey_8d_random_boxes_cache_cold": single(rb, ri, True),
         "P2_train_realistic_placement": single(tb, ti, False, "trainlike_48_rois"),
+        "P2_train_realistic_placement_step_cache_state": single(tb, ti, True, touch=True),
         "P2_train_realistic_placement_cache_cold": single(tb, ti, True),
         "all_four_levels_one_launch_48_rois": pyramid(False),
         "all_four_levels_one_launch_48_rois_cache_cold": pyramid(True),
@@ -217,20 +236,23 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, launches=60):
     # the op as it ran inside the timed steps: ONE launch for all four pyramid levels (mdt_pyramid_roi_align_backward), so
     # the algorithmic bytes are the four gradient maps + the pooled gradients of the RoIs the level rule kept; fresh output
     # maps from the allocator after 50 ms of convolutions: cache-cold by construction
-    recs = [(a.elapsed_time(b) * 1e-3, m) for a, b, m in (in_step_prof or []) if m.get("mode") == "pyramid" and m["crop"] == crop]
-    if recs:
-        maps_bytes = 4.0 * sum(int(np.prod(sh)) for sh in recs[0][1]["levels"])
-        byts = [maps_bytes + 4.0 * int(m["n_valid"].item()) * cf.end_filts * P + 36.0 * m["n_rows"] for _, m in recs]
-        dur = float(np.mean([d for d, _ in recs]))
-        variants["in_training_step_all_levels_one_launch"] = {
-            "achieved": round(float(np.mean(byts)) / dur / 1e9, 1), "frac": round(float(np.mean(byts)) / dur / HBM_PEAK_BPS, 4),
-            "avg_us": round(dur * 1e6, 2), "launches": len(recs), "alg_bytes_per_launch": int(np.mean(byts)),
-            "rois": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
+    for key, pr in (("in_training_step_all_levels_one_launch", in_step_prof),
+                    ("in_training_step_all_levels_one_launch_rois_heads_full", in_step_prof48)):
+        recs = [(a.elapsed_time(b) * 1e-3, m) for a, b, m in (pr or []) if m.get("mode") == "pyramid" and m["crop"] == crop]
+        if recs:
+            maps_bytes = 4.0 * sum(int(np.prod(sh)) for sh in recs[0][1]["levels"])
+            byts = [maps_bytes + 4.0 * int(m["n_valid"].item()) * cf.end_filts * P + 36.0 * m["n_rows"] for _, m in recs]
+            dur = float(np.mean([d for d, _ in recs]))
+            variants[key] = {
+                "achieved": round(float(np.mean(byts)) / dur / 1e9, 1), "frac": round(float(np.mean(byts)) / dur / HBM_PEAK_BPS, 4),
+                "avg_us": round(dur * 1e6, 2), "launches": len(recs), "alg_bytes_per_launch": int(np.mean(byts)),
+                "rois": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
     out = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": head["frac"], "traffic": head["traffic"],
            "traffic_source": ("OFFLINE measurement, not part of this run: profiles/r03_pmc/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes "
                               "of this op, tools/gpu_pmc.sh)") if head["traffic"] else None,
            "kernel": "crop_bwd_gather_kernel (mdt_crop_and_resize_3d_backward, csrc/roi_align_bwd_v3.hip): P2 %s, pool %s, %d RoIs on the level, "
-                     "SURVEY 8(d) box distribution, cache-warm" % ("x".join(map(str, shape)), "x".join(map(str, crop)), n),
+                     "SURVEY 8(d) box distribution, training-step cache state (output map = fresh memory: 4 x 151 MB rotated; pooled gradients and "
+                     "boxes just produced); same-buffer (cache-warm) and all-cold figures in `variants`" % ("x".join(map(str, shape)), "x".join(map(str, crop)), n),
            "alg_bytes_per_launch": head["alg_bytes_per_launch"], "avg_us": head["avg_us"], "median_us": head["median_us"], "launches": launches,
            "timing": "HIP events around every launch on the launch stream; adds ~2 us over the kernel's own duration (profiles/r03_* rocprofv3 stats)",
            "variants": variants}
@@ -256,8 +278,101 @@ def _self_launch(n):
     raise SystemExit(subprocess.call(cmd))
 
 
+def _graph_preflight(args, device_index, timeout_s=420):
+    """hipGraph capture of the whole step in a CHILD process first (build the net, capture, two replays, compare with nothing): a crash
+    inside the runtime's capture / instantiate code (seen once in round 4 with the per-element matching launches) then costs the graphed
+    headline, not the bench line -- the parent falls back to the eager step and says so."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph-preflight", "--patch", args.patch, "--batch", str(args.batch), "--gmax", str(args.gmax),
+           "--device-index", str(device_index), "--channels-last", str(args.channels_last)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                          "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        ok = r.returncode == 0 and "GRAPH_PREFLIGHT_OK" in r.stdout
+        note = "ok (%.0f s)" % (time.time() - t0) if ok else "FAILED rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])
+    except subprocess.TimeoutExpired:
+        ok, note = False, "FAILED: timeout after %d s" % timeout_s
+    return ok, note
+
+
+def graph_preflight_main(args):
+    from medicaldetectiontoolkit_amd import training
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from medicaldetectiontoolkit_amd.models import mrcnn
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch, to_device
+    idx = args.device_index or 0
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
+    torch.backends.cudnn.benchmark = True
+    patch = [int(v) for v in args.patch.split(",")]
+    cf = Configs(dim=3, model="mrcnn", patch_size=patch, batch_size=args.batch, channels_last=bool(args.channels_last))
+    torch.manual_seed(0)
+    net = mrcnn.net(cf, device=dev)
+    opt = training.build_optimizer(net, cf, flat=True)
+    step = training.GraphedTrainStep(net, opt, gmax=args.gmax)
+    b = to_device(make_batch(patch, args.batch, seed=7), dev)
+    for _ in range(2):
+        res = step(b)
+    torch.cuda.synchronize()
+    if not np.isfinite(float(res["torch_loss"])):
+        raise SystemExit("graph preflight: non-finite loss")
+    print("GRAPH_PREFLIGHT_OK loss=%.4f" % float(res["torch_loss"]), flush=True)
+
+
+def exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph):
+    """exec.py:67-79 as the reference runs it: `batch = next(batch_gen)` (host numpy), `results = net.train_forward(batch)`, zero_grad,
+    backward, step, then the consumers of results_dict (`logger_string` logged, `boxes` appended for the training metrics,
+    `monitor_values` plotted) -- with the mask head over the detections on (mrcnn.py:1046-1048).  The batch stream goes through
+    training.DevicePrefetcher; the read-out is one packed device->host copy per step (1 sync per step)."""
+    from medicaldetectiontoolkit_amd import training
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch
+    n = max(3, min(args.steps, 8))
+    host_pool = [make_batch(patch, args.batch, seed=50 + i) for i in range(2)]
+    seq = [host_pool[i % 2] for i in range(n + 2)]
+    prev = getattr(cf, "run_detection_mask_head_in_training", False)
+    cf.run_detection_mask_head_in_training = True
+    try:
+        if use_graph:
+            xstep = training.GraphedTrainStep(net, opt, gmax=args.gmax, monitor=True, with_masks=True)
+        else:
+            def xstep(b):
+                return training.train_step(net, opt, b, monitor=True)
+        pf = training.DevicePrefetcher(seq, dev)
+        consumed = 0
+        for _ in range(2):                       # capture / warm-up
+            res = xstep(next(pf))
+        torch.cuda.synchronize()
+        if use_graph:
+            xstep.host_ms = {}
+        t_wait = 0.0
+        t0 = time.time()
+        while True:
+            tw = time.time()
+            b = next(pf, None)
+            t_wait += time.time() - tw
+            if b is None:
+                break
+            res = xstep(b)
+            consumed += len(res["logger_string"]) + len(res["boxes"]) + len(res["monitor_values"])     # what exec.py:76-79 reads every batch
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+    finally:
+        cf.run_detection_mask_head_in_training = prev
+    host_ms = None
+    if use_graph and xstep.host_ms:
+        c = max(1, xstep.host_ms.pop("calls", 1))
+        host_ms = {k: round(v / c, 2) for k, v in xstep.host_ms.items()}
+        host_ms["wait_for_next_batch"] = round(t_wait / c * 1e3, 2)
+    return {"value": round(args.batch * n / dt, 3), "unit": "patches/s", "steps": n, "ms_per_step": round(dt / n * 1e3, 2),
+            "device_to_host_syncs_per_step": 1, "graph": bool(use_graph), "host_ms_per_step": host_ms, "last_logger_string": res["logger_string"],
+            "note": "host numpy batches (training.DevicePrefetcher: upload of batch i+1 behind step i) + monitoring read-out every step (one packed D2H) "
+                    "+ mask head over the detections (mrcnn.py:1046-1048) + box lists built on the host"}
+
+
 def secondary_configs(timeout_s=240):
-    """BASELINE configs 2 and 5 under the same clock as the headline line: each runs in its OWN process with a
+    """BASELINE configs 1, 2 and 5 under the same clock as the headline line: each runs in its OWN process with a
     timeout (a cold MIOpen find for their layer shapes must never hold the headline line back), results parsed from the
     child's JSON line.  config 2: LIDC-shape 3D Retina U-Net, 128^3, batch 8, 3 timed steps; config 5: one 512x512x256
     volume, 75 patches, bf16, single pass, device-resident predictor (tools/bench_inference.py)."""
@@ -268,6 +383,7 @@ def secondary_configs(timeout_s=240):
     jobs = {
         "config2_retina_unet_128_b8": [sys.executable, os.path.abspath(__file__), "--model", "retina_unet", "--steps", "3", "--warmup", "2",
                                        "--no-cpu-baseline", "--no-h2d-leg", "--no-rccl-selftest", "--no-secondary", "--no-roofline"],
+        "config1_toy2d_retina_net_64x64_b20": [sys.executable, os.path.join(ROOT, "tools", "bench_toy2d.py"), "--steps", "30", "--sizes", "64"],
         "config5_inference_512x512x256_bf16": [sys.executable, os.path.join(ROOT, "tools", "bench_inference.py"), "--amp", "bf16",
                                                "--test-aug", "0", "--repeats", "1"],
     }
@@ -281,14 +397,14 @@ def secondary_configs(timeout_s=240):
             rec = {"failed": "timeout after %d s (cold MIOpen find?)" % timeout_s}
         except Exception as e:
             rec = {"failed": repr(e)}
-        keep = ("metric", "value", "unit", "ms_per_step", "steps", "config", "patients_per_min", "patches_per_s", "s_per_patient", "n_patches",
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "config", "images_per_s", "loss_first5_mean", "loss_last5_mean", "finite", "patients_per_min", "patches_per_s", "s_per_patient", "n_patches",
                 "n_passes", "forwards", "raw_boxes", "boxes_after_wbc", "amp", "failed")
         out[key] = {k: rec[k] for k in keep if k in rec}
         out[key]["wall_s"] = round(time.time() - t0, 1)
     return out
 
 
-def rccl_world1_selftest(net, opt, batch, dev, steps=3):
+def rccl_world1_selftest(net, opt, batch, dev, steps=3, use_graph=False, gmax=8):
     """The N > 1 gradient path on its real backend, on a 1-GPU box: a world-size-1 `nccl` (= RCCL) process group, the
     collectives of training.FlatGradAllReduce forced on.  (1) local gradient (hooks off) vs the same buffer after the
     bucket all-reduces: must be bit-identical (sum over one rank, / 1); (2) `steps` train_steps with the async bucket
@@ -319,10 +435,24 @@ def rccl_world1_selftest(net, opt, batch, dev, steps=3):
         torch.cuda.synchronize()
         ms = (time.time() - t0) / steps * 1e3
         launched = sync._next
+        rec_graph = None
+        if use_graph:      # the N > 1 form of the graphed step: gradients accumulate into the flat buffer inside the graph, the bucket
+            try:           # all-reduces and the Adam launch follow the replay
+                gs = training.GraphedTrainStep(net, opt, grad_sync=sync, gmax=gmax)
+                for _ in range(2):
+                    gs(batch)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for _ in range(steps):
+                    gs(batch)
+                torch.cuda.synchronize()
+                rec_graph = {"ms_per_step_with_collectives": round((time.time() - t0) / steps * 1e3, 2), "buckets_all_reduced_per_step": int(sync._next)}
+            except Exception as e:
+                rec_graph = {"failed": repr(e)[:200]}
         flat_params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
         return {"backend": dist.get_backend(), "world": dist.get_world_size(), "buckets_all_reduced_per_step": int(launched),
                 "grad_bit_identical_after_allreduce": identical, "params_finite": bool(torch.isfinite(flat_params).all()),
-                "ms_per_step_with_collectives": round(ms, 2), "init_plus_first_step_s": round(t_init, 2)}
+                "ms_per_step_with_collectives": round(ms, 2), "graphed_step": rec_graph, "init_plus_first_step_s": round(t_init, 2)}
     finally:
         dist.destroy_process_group()
 
@@ -341,6 +471,13 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the RoIAlign-backward roofline section (child runs of --secondary)")
     ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the world-size-1 RCCL self-test after the timed loop")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra host-batch steps after the timed loop (profiling runs)")
+    ap.add_argument("--graph", type=int, default=1, help="1 (default): the device half of the Mask R-CNN step is ONE hipGraph replay (training.GraphedTrainStep); 0: every kernel launched eagerly (A/B; also timed as `eager_step` in every line)")
+    ap.add_argument("--gmax", type=int, default=8, help="GT objects per batch element the fixed-size GT table of the graphed step holds")
+    ap.add_argument("--no-graph-preflight", action="store_true", help="skip the child-process capture check that precedes the graphed run")
+    ap.add_argument("--graph-preflight", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--device-index", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-eager-leg", action="store_true", help="skip the eager A/B steps after the timed loop")
+    ap.add_argument("--no-exec-leg", action="store_true", help="skip the exec.py-equivalent leg (host batches + monitoring read-out + mask head over detections)")
     ap.add_argument("--fused-adam", type=int, default=0)
     ap.add_argument("--flat-adam", type=int, default=1, help="1 (default): training.FlatAdam -- parameters, gradients and Adam moments in flat buffers, the update one launch of csrc/adam.hip; 0: torch.optim.Adam (A/B)")
     ap.add_argument("--fused-epilogue", type=int, default=1, help="1 (default): fused bias/residual/ReLU conv epilogues (csrc/epilogue.hip); 0: torch ops (A/B)")
@@ -360,6 +497,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP hot path has no CPU fallback")
+    if args.graph_preflight:
+        return graph_preflight_main(args)
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     n_dev = torch.cuda.device_count()
@@ -431,17 +570,69 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+    # ---- the step: ONE hipGraph replay for the device half (training.GraphedTrainStep) unless --graph 0 / Retina U-Net / a failed preflight
+    graph_rec = {"requested": bool(args.graph)}
+    use_graph = bool(args.graph) and args.model == "mrcnn"
+    if use_graph and not args.no_graph_preflight:
+        ok, note = _graph_preflight(args, local_dev)      # a capture crash must kill a child, never the bench line
+        graph_rec["preflight"] = note
+        use_graph = ok
+    graph_rec["used"] = use_graph
+    gstep = training.GraphedTrainStep(net, opt, grad_sync=sync, gmax=args.gmax) if use_graph else None
+
+    def run_step(b):
+        if gstep is not None:
+            return gstep(b)
+        return training.train_step(net, opt, b, grad_sync=sync, monitor=False)
+
+    for i in range(max(args.warmup, 1 if use_graph else 0)):
+        run_step(pool[i % len(pool)])
     barrier()
-    _roi_align_impl.PROFILE = []
     t0 = time.time()
     for i in range(args.steps):
-        training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+        run_step(pool[i % len(pool)])
     host_issue = time.time() - t0      # the host has launched everything (it runs ahead of the GPU while the step is GPU-bound)
     barrier()
     elapsed = time.time() - t0
-    prof, _roi_align_impl.PROFILE = _roi_align_impl.PROFILE, None
+
+    # ---- A/B leg: the EAGER step (~1500 launches issued one by one), same net / optimizer / batches; its RoIAlign backward launches are
+    # event-timed for the roofline's in-step variant (events cannot be recorded inside a graph)
+    eager_rec, prof = None, None
+    if not args.no_eager_leg or not use_graph:
+        n_e = max(2, min(args.steps, 6))
+        for i in range(2 if use_graph else 0):
+            training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+        barrier()
+        _roi_align_impl.PROFILE = []
+        te = time.time()
+        for i in range(n_e):
+            training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+        th_e = time.time() - te
+        barrier()
+        te = time.time() - te
+        prof, _roi_align_impl.PROFILE = _roi_align_impl.PROFILE, None
+        eager_rec = {"value": round(args.batch * world * n_e / te, 3), "unit": "patches/s", "steps": n_e, "ms_per_step": round(te / n_e * 1e3, 2),
+                     "host_issue_ms_per_step": round(th_e / n_e * 1e3, 2),
+                     "note": "training.train_step: the same step with every kernel launched eagerly (the round-3 headline path)"}
+
+    # ---- the in-step RoIAlign backward with the RoI heads FULL: GT boxes derived from the net's own proposals (as
+    # tests/golden/make_step_golden.py does), so that the target layer finds positives and all train_rois_per_image slots are valid
+    prof48 = None
+    if world == 1 and args.model == "mrcnn" and not args.no_roofline:
+        try:
+            from medicaldetectiontoolkit_amd.utils.synthetic_data import batch_with_gt_from_proposals
+            b48 = batch_with_gt_from_proposals(net, cf, pool[0] if not args.host_batches else to_device(pool[0], dev), dev)
+            training.train_step(net, opt, b48, monitor=False)
+            torch.cuda.synchronize()
+            _roi_align_impl.PROFILE = []
+            for _ in range(4):
+                training.train_step(net, opt, b48, monitor=False)
+            torch.cuda.synchronize()
+            prof48, _roi_align_impl.PROFILE = _roi_align_impl.PROFILE, None
+        except Exception as e:
+            prof48 = None
+            graph_rec["instep48_failed"] = repr(e)[:200]
+            _roi_align_impl.PROFILE = None
 
     # the same steps fed from host numpy batches (the reference uploads inside train_forward, mrcnn.py:869): reported
     # beside `value`, never as `value`
@@ -449,14 +640,24 @@ def main():
     if world == 1 and not args.host_batches and not args.no_h2d_leg:
         host_pool = [make_batch(patch, args.batch, seed=i) for i in range(2)]
         n_h2d = max(2, min(args.steps, 5))
-        training.train_step(net, opt, host_pool[0], grad_sync=sync, monitor=False)
+        run_step(host_pool[0])
         barrier()
         th = time.time()
         for i in range(n_h2d):
-            training.train_step(net, opt, host_pool[i % 2], grad_sync=sync, monitor=False)
+            run_step(host_pool[i % 2])
         barrier()
         h2d = {"value": round(args.batch * n_h2d / (time.time() - th), 3), "unit": "patches/s", "steps": n_h2d,
-               "note": "same step with the batch handed over as host numpy arrays (image, GT masks, seg uploaded inside train_forward)"}
+               "note": "same step with the batch handed over as host numpy arrays (image, GT masks uploaded inside the step, on the step's own thread and stream)"}
+
+    # ---- the step as exec.py consumes it: host numpy batches through training.DevicePrefetcher (upload of batch i + 1
+    # behind step i), monitor read-out every step (logger_string / boxes / monitor_values: ONE packed device->host copy), the mask head
+    # over the detections run like the reference does (mrcnn.py:1046-1048)
+    exec_eq = None
+    if world == 1 and args.model == "mrcnn" and not args.no_exec_leg:
+        try:
+            exec_eq = exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph)
+        except Exception as e:
+            exec_eq = {"failed": repr(e)[:300]}
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -477,7 +678,7 @@ def main():
                 "grad_buckets": (len(sync.bucket_range) if sync is not None and sync.flat is not None else None)}
 
     if rank == 0:
-        roofline = None if args.no_roofline else roialign_bwd_roofline(cf, args.batch, dev, prof)
+        roofline = None if args.no_roofline else roialign_bwd_roofline(cf, args.batch, dev, prof, prof48)
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.model == "mrcnn":
             try:
@@ -495,11 +696,13 @@ def main():
                            "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),
                        "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over %s)" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "global_batch": args.batch * world},
+            "graph": graph_rec, "eager_step": eager_rec, "exec_equivalent": exec_eq,
             "roofline": roofline, "cpu_baseline": cpu, "h2d_inclusive": h2d, "distributed": dist_rec,
         }
         if world == 1 and not args.no_rccl_selftest:
             try:
-                out["distributed"]["rccl_world1_selftest"] = rccl_world1_selftest(net, opt, pool[0] if not args.host_batches else to_device(pool[0], dev), dev)
+                out["distributed"]["rccl_world1_selftest"] = rccl_world1_selftest(net, opt, pool[0] if not args.host_batches else to_device(pool[0], dev), dev,
+                                                                                   use_graph=use_graph, gmax=args.gmax)
             except Exception as e:   # reported, never fatal for the bench line
                 out["distributed"]["rccl_world1_selftest"] = {"failed": repr(e)}
         if world == 1 and not args.no_secondary and args.model == "mrcnn":

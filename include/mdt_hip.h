@@ -73,6 +73,16 @@ int mdt_crop_and_resize_2d_forward_bf16(
     int num_boxes, int batch, int image_height, int image_width,
     int crop_height, int crop_width, int depth, float *crops, void *stream);
 
+/* uint8-input forms (round 4): the GT masks of a batch (Appendix B: 'roi_masks' uint8) are cropped to the mask targets
+ * (models/mrcnn.py:551-563: CropAndResizeFunction(mask_shape...)(gt_masks, boxes, box_ids)) straight from their uint8 storage; each
+ * byte is widened exactly to fp32, the interpolation is the fp32 one (bit-equal to the fp32 kernel on image.float()). */
+int mdt_crop_and_resize_3d_forward_u8(
+    const uint8_t *image, const float *boxes, const int *box_ind, int num_boxes, int batch, int H, int W, int D,
+    int ch, int cw, int cd, int depth, float *crops, void *stream);
+int mdt_crop_and_resize_2d_forward_u8(
+    const uint8_t *image, const float *boxes, const int *box_ind, int num_boxes, int batch, int H, int W,
+    int ch, int cw, int depth, float *crops, void *stream);
+
 /*
  * Replaces CropAndResizeBackpropImageLaucher (3D)
  *   crop_and_resize_kernel.h:14-18 (kernel: crop_and_resize_kernel.cu:154-304)
@@ -446,9 +456,11 @@ int mdt_conv_stem_forward(const float *x_padded, const float *weight, const floa
  * One step of torch.optim.Adam (exec.py:39: Adam(lr = cf.learning_rate[0], weight_decay = cf.weight_decay); no amsgrad) for n
  * parameters whose values, gradients and moment estimates are four flat arrays: step >= 1 is the number of this update (bias
  * corrections 1 - beta^step), weight_decay is the L2 term added to the gradient; the hyper-parameters are doubles (derived scalars are
- * formed in double and rounded to fp32 once, like torch's python-side arithmetic).  In place on param / exp_avg / exp_avg_sq. */
+ * formed in double and rounded to fp32 once, like torch's python-side arithmetic).  grad_div > 0: every gradient is divided by it first
+ * (IEEE fp32 division) -- the averaging step of the data-parallel gradient all-reduce (sum over ranks / world size) folded into the
+ * update instead of a separate pass over the 19.75 MB buffer; 1.0 = gradients as they are.  In place on param / exp_avg / exp_avg_sq. */
 int mdt_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, double lr, double beta1, double beta2,
-                  double eps, double weight_decay, long long step, void *stream);
+                  double eps, double weight_decay, long long step, double grad_div, void *stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,8 @@ _SIGNATURES = {
     "mdt_crop_and_resize_3d_forward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_float, c_void_p, c_void_p]),
     "mdt_crop_and_resize_3d_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
     "mdt_crop_and_resize_2d_forward_bf16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
+    "mdt_crop_and_resize_3d_forward_u8": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
+    "mdt_crop_and_resize_2d_forward_u8": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
     "mdt_crop_and_resize_backward_workspace_bytes": (c_size_t, [c_int] * 9),
     "mdt_crop_and_resize_3d_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_crop_and_resize_backward_twophase_workspace_bytes": (c_size_t, [c_int] * 9),
@@ -38,7 +40,7 @@ _SIGNATURES = {
     "mdt_conv3x3x3_small_forward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mdt_conv_stem_wgrad_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mdt_conv_stem_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]),
-    "mdt_adam_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong] + [c_double] * 5 + [c_longlong, c_void_p]),
+    "mdt_adam_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong] + [c_double] * 5 + [c_longlong, c_double, c_void_p]),
     "mdt_conv_stem_forward_supported": (c_int, [c_int] * 7),
     "mdt_conv_stem_forward": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
     "mdt_conv3x3x3_small_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),

@@ -12,11 +12,12 @@
 namespace {
 
 struct AdamScalars {
-    float one_minus_b1, b2, one_minus_b2, eps, wd, neg_step_size, bc2_sqrt;
+    float one_minus_b1, b2, one_minus_b2, eps, wd, neg_step_size, bc2_sqrt, grad_div;
 };
 
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, const AdamScalars &a)
 {
+    if (a.grad_div != 1.0f) g = g / a.grad_div;      // the averaging of the gradient all-reduce (sum over ranks / world), same IEEE division as flat.div_(world)
     if (a.wd != 0.0f) g = g + a.wd * p;
     m = m + (g - m) * a.one_minus_b1;
     v = v * a.b2 + a.one_minus_b2 * (g * g);
@@ -47,9 +48,9 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
 }  // namespace
 
 extern "C" int mdt_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, double lr, double beta1, double beta2,
-                             double eps, double weight_decay, long long step, void *stream)
+                             double eps, double weight_decay, long long step, double grad_div, void *stream)
 {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return MDT_ERR_INVALID_ARGUMENT;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1 || !(grad_div > 0.0)) return MDT_ERR_INVALID_ARGUMENT;
     if (n == 0) return MDT_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                          reinterpret_cast<uintptr_t>(exp_avg_sq);
@@ -65,6 +66,7 @@ extern "C" int mdt_adam_flat(float *param, const float *grad, float *exp_avg, fl
     a.wd = (float)weight_decay;
     a.neg_step_size = (float)(-lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
+    a.grad_div = (float)grad_div;
     long long work = n4 > 0 ? n4 : n;
     if (n - 4 * n4 > work) work = n - 4 * n4;
     long long blocks = (work + 255) / 256;

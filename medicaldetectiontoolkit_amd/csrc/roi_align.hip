@@ -43,8 +43,12 @@ constexpr int FWD_SLAB = FWD_THREADS * FWD_PER_THREAD;
 // input element: fp32, or bf16 (raw 16-bit pattern, widened exactly to fp32 on load -- the interpolation itself is
 // always fp32; used by the autocast inference path, where it halves the gathered bytes)
 struct bf16raw { unsigned short v; };
+// uint8 (round 4): the GT masks of a training batch travel and stay as uint8 (2 MB per 128^3 mask); the mask-target crop of
+// detection_target_layer (mrcnn.py:551-563) reads them as they are, each byte widened exactly, instead of a 4x larger fp32 copy
+struct u8raw { unsigned char v; };
 __device__ __forceinline__ float ld(const float *p, long long i) { return p[i]; }
 __device__ __forceinline__ float ld(const bf16raw *p, long long i) { return __uint_as_float(((unsigned int)p[i].v) << 16); }
+__device__ __forceinline__ float ld(const u8raw *p, long long i) { return (float)p[i].v; }
 
 template <int DIM, typename TIN>
 __device__ __forceinline__ void crop_fwd_body(
@@ -1308,6 +1312,22 @@ int mdt_crop_and_resize_3d_forward_bf16(const uint16_t *image, const float *boxe
 {
     return launch_fwd<3, bf16raw>(reinterpret_cast<const bf16raw *>(image), boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth,
                                   crops, (hipStream_t)stream);
+}
+
+int mdt_crop_and_resize_3d_forward_u8(const uint8_t *image, const float *boxes, const int *box_ind,
+                                      int num_boxes, int batch, int H, int W, int D,
+                                      int ch, int cw, int cd, int depth, float *crops, void *stream)
+{
+    return launch_fwd<3, u8raw>(reinterpret_cast<const u8raw *>(image), boxes, box_ind, num_boxes, batch, H, W, D, ch, cw, cd, depth,
+                                crops, (hipStream_t)stream);
+}
+
+int mdt_crop_and_resize_2d_forward_u8(const uint8_t *image, const float *boxes, const int *box_ind,
+                                      int num_boxes, int batch, int H, int W,
+                                      int ch, int cw, int depth, float *crops, void *stream)
+{
+    return launch_fwd<2, u8raw>(reinterpret_cast<const u8raw *>(image), boxes, box_ind, num_boxes, batch, H, W, 1, ch, cw, 1, depth,
+                                crops, (hipStream_t)stream);
 }
 
 int mdt_crop_and_resize_2d_forward_bf16(const uint16_t *image, const float *boxes, const int *box_ind,

@@ -34,7 +34,8 @@ def _prep(image, boxes, box_ind, dim):
     # bf16 feature maps (autocast, BASELINE config 5) ALWAYS go to the bf16-input kernel as they are: it widens each bf16
     # value exactly to fp32 and interpolates in fp32 (bit-equal to the fp32 kernel on the widened map), in training too --
     # the backward produces an fp32 gradient map that is cast back to the map's dtype.  Other dtypes are converted to fp32.
-    if image.dtype not in (torch.float32, torch.bfloat16):
+    # uint8 images (the GT masks of a batch) are read as uint8 by their own kernel instantiation when no gradient is wanted.
+    if image.dtype not in (torch.float32, torch.bfloat16) and not (image.dtype == torch.uint8 and not image.requires_grad):
         image = image.float()
     boxes = boxes.detach().to(device=image.device, dtype=torch.float32).contiguous()
     box_ind = box_ind.detach().to(device=image.device, dtype=torch.int32).contiguous()
@@ -51,7 +52,16 @@ def crop_forward(image, boxes, box_ind, crop, extrapolation_value=0.0):
         return crops
     with torch.cuda.device(image.device):
         s = _lib.current_stream_ptr()
-        if image.dtype == torch.bfloat16:
+        if image.dtype == torch.uint8:
+            if dim == 3:
+                rc = L.mdt_crop_and_resize_3d_forward_u8(
+                    _lib.ptr(image), _lib.ptr(boxes), _lib.ptr(box_ind), n, B, image.size(2), image.size(3), image.size(4),
+                    crop[0], crop[1], crop[2], C, _lib.ptr(crops), s)
+            else:
+                rc = L.mdt_crop_and_resize_2d_forward_u8(
+                    _lib.ptr(image), _lib.ptr(boxes), _lib.ptr(box_ind), n, B, image.size(2), image.size(3),
+                    crop[0], crop[1], C, _lib.ptr(crops), s)
+        elif image.dtype == torch.bfloat16:
             if dim == 3:
                 rc = L.mdt_crop_and_resize_3d_forward_bf16(
                     _lib.ptr(image), _lib.ptr(boxes), _lib.ptr(box_ind), n, B, image.size(2), image.size(3), image.size(4),

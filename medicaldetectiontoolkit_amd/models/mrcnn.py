@@ -207,33 +207,59 @@ class GtOnDevice(object):
       cls    [B, Gmax] i64 class ids of all objects
       valid  [B, Gmax] bool, gidx [B, Gmax] i32 (index into the stacked GT masks): set for elements with at least one
              foreground class id, like the target layer expects (mrcnn.py:487)
-      n_all  python list: objects per element;  counts: 0 for elements without a foreground class id else n_all"""
+      n_gt   [B] i32 DEVICE tensor: objects per element (read by the batched matching kernel -- no host count enters a launch)
+      n_all  python list: objects per element;  counts: 0 for elements without a foreground class id else n_all
+    The whole content is one float64 table [B, Gmax, 2*dim + 4] (box, class id, valid flag, mask index, n_all of the element):
+    `stage()` builds it in pinned host memory, `GtOnDevice(table=...)` derives the views from a table that is already on the device
+    (training.GraphedTrainStep copies the staged table into a STATIC device table and captures the derivation).  `gmax` fixes the
+    padded object count (static shapes for hipGraph capture); default: the batch's own maximum."""
 
-    def __init__(self, batch_gt_boxes, batch_gt_class_ids, dim, dev):
+    @staticmethod
+    def stage(batch_gt_boxes, batch_gt_class_ids, dim, gmax=None, pin=True):
         B = len(batch_gt_boxes)
-        self.n_all = [0 if g is None else len(g) for g in batch_gt_boxes]
-        self.counts = [0 if (self.n_all[b] == 0 or not np.any(np.asarray(batch_gt_class_ids[b]) > 0)) else self.n_all[b]
-                       for b in range(B)]
-        gmax = max(1, max(self.n_all))
-        stage = torch.zeros((B, gmax, 2 * dim + 3), dtype=torch.float64, pin_memory=(torch.device(dev).type == "cuda"))
+        n_all = [0 if g is None else len(g) for g in batch_gt_boxes]
+        counts = [0 if (n_all[b] == 0 or not np.any(np.asarray(batch_gt_class_ids[b]) > 0)) else n_all[b] for b in range(B)]
+        if gmax is None:
+            gmax = max(1, max(n_all))
+        elif max(n_all) > gmax:
+            raise ValueError("a batch element has %d GT objects, the fixed-size GT table holds %d (cf.max_gt_per_element)" % (max(n_all), gmax))
+        stage = torch.zeros((B, gmax, 2 * dim + 4), dtype=torch.float64, pin_memory=bool(pin))
         a = stage.numpy()
         a[:, :, 2 * dim + 2] = -1.0
         run = 0
         for b in range(B):
-            n = self.n_all[b]
+            n = n_all[b]
+            a[b, :, 2 * dim + 3] = n
             if n:
                 a[b, :n, :2 * dim] = np.asarray(batch_gt_boxes[b], dtype=np.float64)
                 a[b, :n, 2 * dim] = np.asarray(batch_gt_class_ids[b])
-            if self.counts[b]:
+            if counts[b]:
                 a[b, :n, 2 * dim + 1] = 1.0
                 a[b, :n, 2 * dim + 2] = run + np.arange(n)
             run += n
-        d = stage.to(dev, non_blocking=True)
+        return stage, n_all, counts
+
+    def __init__(self, batch_gt_boxes, batch_gt_class_ids, dim, dev, gmax=None, table=None):
+        if table is None:
+            stage, self.n_all, self.counts = self.stage(batch_gt_boxes, batch_gt_class_ids, dim, gmax, pin=False)
+            if torch.device(dev).type == "cuda":
+                # through the table's own persistent pinned ring (a fresh pinned block per step = a hipHostMalloc and an implicit device
+                # sync per step as soon as the host runs ahead of the GPU: torch's caching host allocator re-issues a block only
+                # after its copy has executed)
+                table = mutils.stage_pinned(stage, dev, "gt_table").to(dev, non_blocking=True)
+                mutils.stage_release(dev, "gt_table")
+            else:
+                table = stage
+        else:
+            self.n_all = self.counts = None       # host-side counts are not known (and not needed) for a device table
+        d = table
+        self.table = d
         self.px = d[:, :, :2 * dim].contiguous()
         self.cls = d[:, :, 2 * dim].long()
         self.cls_i32 = d[:, :, 2 * dim].int()
         self.valid = d[:, :, 2 * dim + 1] > 0
         self.gidx = d[:, :, 2 * dim + 2].int()
+        self.n_gt = d[:, 0, 2 * dim + 3].int()
 
 
 def _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev, gt_dev=None):
@@ -302,7 +328,9 @@ def detection_target_layer(batch_proposals, batch_mrcnn_class_scores, batch_gt_c
     ra = ra2D(cf.mask_shape[0], cf.mask_shape[1], 0) if dim == 2 else ra3D(cf.mask_shape[0], cf.mask_shape[1], cf.mask_shape[2], 0)
     if batch_gt_masks is not None and batch_gt_masks.shape[0] > 0:
         with torch.no_grad():
-            masks = torch.round(ra(batch_gt_masks.float(), pos_rois.view(-1, 2 * dim).contiguous(), box_ids).squeeze(1))
+            # uint8 masks are read as uint8 (csrc/roi_align.hip u8 instantiation): no fp32 copy of the stacked 128^3 masks
+            gm = batch_gt_masks if batch_gt_masks.dtype in (torch.uint8, torch.float32) else batch_gt_masks.float()
+            masks = torch.round(ra(gm, pos_rois.view(-1, 2 * dim).contiguous(), box_ids).squeeze(1))
     else:
         masks = torch.zeros((B * P,) + tuple(cf.mask_shape), device=dev)
 
@@ -461,14 +489,15 @@ def compute_mrcnn_mask_loss(target_masks, pred_masks, target_class_ids, is_pos):
 ############################################################
 def get_results(cf, img_shape, detections, det_valid, detection_masks, box_results_list=None, return_masks=True):
     """mrcnn.py:717-799: restore the batch dimension, unmold, fill the results dict."""
-    det = detections.detach().cpu().numpy()[det_valid.detach().cpu().numpy()]
+    dv = det_valid if isinstance(det_valid, np.ndarray) else det_valid.detach().cpu().numpy()
+    det = (detections if isinstance(detections, np.ndarray) else detections.detach().cpu().numpy())[dv]
     dim = cf.dim
     if box_results_list is None:
         box_results_list = [[] for _ in range(img_shape[0])]
     masks_np = None
     if return_masks and detection_masks is not None:
         perm = (0, 2, 3, 1) if dim == 2 else (0, 2, 3, 4, 1)
-        masks_np = detection_masks.permute(*perm).detach().cpu().numpy()[det_valid.detach().cpu().numpy()]
+        masks_np = detection_masks.permute(*perm).detach().cpu().numpy()[dv]
     batch_ixs = det[:, dim * 2] if det.shape[0] else np.zeros(0)
     seg_preds = []
     for ix in range(img_shape[0]):
@@ -595,93 +624,131 @@ class net(nn.Module):
         sample_mask = self.mask(self.mrcnn_feature_maps, sample_proposals)
         return [sample_logits, sample_boxes, sample_mask, tcls, tdeltas, tmasks, sample_proposals, valid, is_pos]
 
-    def train_forward(self, batch, is_validation=False, monitor=True):
-        """mrcnn.py:853-967.  batch: the reference's batch dict (numpy): 'data', 'roi_labels', 'bb_target', 'roi_masks'.
-        monitor=False skips building the python box lists (the loss terms are unchanged)."""
-        cf = self.cf
-        dev = self.device_
+    # ------------------------------------------------------------------ the training step: host half / device half / read-out
+    def prepare_batch(self, batch, gmax=None):
+        """Host half of train_forward (mrcnn.py:864-869: the uploads).  Returns {'img': [B, C, *patch] fp32 device tensor, 'gt': GtOnDevice,
+        'masks': stacked GT masks [sum_G, 1, *patch] uint8 device tensor | StagedUpload (resolved after the backbone was launched) | None}.
+        All GT boxes / class ids go up in one pinned async copy BEFORE the backbone is launched: nothing in the step waits for the
+        stream afterwards, so the host keeps running ahead of the GPU through the glue."""
+        cf, dev = self.cf, self.device_
+        ev = batch.get("ready_event")            # training.DevicePrefetcher uploaded on its side stream
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for k in ("data", "roi_masks_device"):
+                if torch.is_tensor(batch.get(k)):
+                    batch[k].record_stream(cur)
         img = mutils.upload(batch["data"], dev).float()
-        gt_class_ids = batch["roi_labels"]
-        gt_boxes = batch["bb_target"]
-        B = img.shape[0]
-        # GT masks of all elements stacked [sum_G, 1, Y, X, (Z)] (uint8 over PCIe, float on the device)
         if "roi_masks_device" in batch:          # already resident in HBM (utils.synthetic_data.to_device)
             gt_masks = batch["roi_masks_device"]
         else:
-            # staged into pinned memory on a background thread while this thread launches the backbone; resolved below
+            # staged into pinned memory on a background thread while this thread launches the backbone
             gt_masks = mutils.StagedUpload([m for m in batch["roi_masks"] if len(m) > 0], dev)
+        gt_dev = GtOnDevice(batch["bb_target"], batch["roi_labels"], cf.dim, dev, gmax=gmax)
+        return {"img": img, "gt": gt_dev, "masks": gt_masks}
 
-        # all GT boxes / class ids go up in one pinned async copy BEFORE the backbone is launched: nothing in the step
-        # waits for the stream afterwards, so the host keeps running ahead of the GPU through the glue
-        gt_dev = GtOnDevice(gt_boxes, gt_class_ids, cf.dim, dev)
-
-        # the mask head over the detections only feeds the validation read-out (return_masks, :949): not run for a training
-        # step (the reference runs it and drops the result)
-        rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(
-            img, with_masks=bool(is_validation and cf.return_masks_in_val))
+    def train_forward_device(self, img, gt_dev, gt_masks, with_masks=False):
+        """Device half of train_forward (mrcnn.py:870-946): forward, target layer, heads, anchor matching, the five loss terms.  Touches no
+        host data and no host-side count (GT counts are read on the device), launches only: the whole function is capturable in a
+        hipGraph (training.GraphedTrainStep).  Returns a dict of DEVICE tensors: 'loss', 'terms', 'sample_counts' and what the
+        monitoring read-out of exec.py needs ('mon')."""
+        cf = self.cf
+        B = img.shape[0]
+        rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(img, with_masks=with_masks)
         if isinstance(gt_masks, mutils.StagedUpload):
             gt_masks = gt_masks.get()
         (mrcnn_class_logits, mrcnn_pred_deltas, mrcnn_pred_mask, target_class_ids, mrcnn_target_deltas, target_mask,
-         sample_proposals, s_valid, s_pos) = self.loss_samples_forward(gt_class_ids, gt_boxes, gt_masks, B, gt_dev=gt_dev)
+         sample_proposals, s_valid, s_pos) = self.loss_samples_forward(None, None, gt_masks, B, gt_dev=gt_dev)
 
-        # anchor matching per element on the device (the reference: numpy on one host core, mrcnn.py:894)
-        matches, argmaxes = [], []
+        # anchor matching of the whole batch on the device, ONE launch pair (the reference: numpy on one host core per element,
+        # mrcnn.py:894); the per-element GT counts are read by the kernel
         neg_thr = 0.1 if cf.dim == 2 else 0.01
-        for b in range(B):
-            gt_t = gt_dev.px[b, :gt_dev.n_all[b]] if gt_dev.n_all[b] > 0 else None
-            m, am, _, _ = mutils.anchor_match_labels(self.anchors_f64, gt_t, None, neg_thr, float(cf.anchor_matching_iou))
-            matches.append(m)
-            argmaxes.append(am)
-        rpn_match = torch.stack(matches)
-        rpn_argmax = torch.stack(argmaxes)
+        rpn_match, rpn_argmax = mutils.anchor_match_labels_batched(self.anchors_f64, gt_dev.px, gt_dev.n_gt, None, neg_thr, float(cf.anchor_matching_iou))
         batch_rpn_class_loss, batch_rpn_bbox_loss, rpn_samples = compute_rpn_losses(
-            rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, self.anchors_f64, gt_boxes, cf, gt_dev=gt_dev)
+            rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, self.anchors_f64, None, cf, gt_dev=gt_dev)
 
         mrcnn_class_loss = compute_mrcnn_class_loss(target_class_ids, mrcnn_class_logits, s_valid)
         mrcnn_bbox_loss = compute_mrcnn_bbox_loss(mrcnn_target_deltas, mrcnn_pred_deltas, target_class_ids, s_pos)
         if not cf.frcnn_mode:
             mrcnn_mask_loss = compute_mrcnn_mask_loss(target_mask, mrcnn_pred_mask, target_class_ids, s_pos)
         else:
-            mrcnn_mask_loss = torch.zeros((), device=dev)
+            mrcnn_mask_loss = torch.zeros((), device=img.device)
         loss = batch_rpn_class_loss + batch_rpn_bbox_loss + mrcnn_class_loss + mrcnn_bbox_loss + mrcnn_mask_loss
+        terms = {"rpn_class": batch_rpn_class_loss.detach(), "rpn_bbox": batch_rpn_bbox_loss.detach(),
+                 "mrcnn_class": mrcnn_class_loss.detach(), "mrcnn_bbox": mrcnn_bbox_loss.detach(), "mrcnn_mask": mrcnn_mask_loss.detach()}
+        mon = {"rpn_samples": rpn_samples, "proposal_boxes": proposal_boxes, "sample_proposals": sample_proposals.detach(),
+               "target_class_ids": target_class_ids, "s_valid": s_valid, "detections": detections, "det_valid": det_valid,
+               "detection_masks": detection_masks}
+        return {"loss": loss, "terms": terms, "sample_counts": (s_valid.sum(), s_pos.sum()), "mon": mon}
 
+    def monitor_pack(self, out):
+        """Device side of the monitoring read-out (mrcnn.py:898-961 reads a dozen tensors back one by one): everything exec.py's
+        consumers need -- the sampled anchors, the best n_plot_rpn_props proposals per element, the sampled RoIs with their target
+        classes, the detections and the six loss values -- packed into ONE int32 buffer (fp32 values by bit pattern), so a step has one
+        device->host copy.  Launches only (capturable).  Returns (buffer, layout)."""
+        cf, mon, terms = self.cf, out["mon"], out["terms"]
+        pidx, pvalid, nidx, nvalid = mon["rpn_samples"]
+        props = mon["proposal_boxes"]
+        n_plot = min(int(cf.n_plot_rpn_props), int(props.shape[1]))
+        _, order = torch.sort(props[:, :, -1], dim=1, descending=True, stable=True)          # :919-921: best proposals first
+        top = torch.gather(props[:, :, :-1], 1, order[:, :n_plot].unsqueeze(-1).expand(-1, -1, props.shape[2] - 1))
+        vals = torch.stack([out["loss"].detach(), terms["rpn_class"], terms["rpn_bbox"], terms["mrcnn_class"], terms["mrcnn_bbox"], terms["mrcnn_mask"]])
+        items = [("pidx", pidx), ("pvalid", pvalid), ("nidx", nidx), ("nvalid", nvalid), ("props", top), ("sample_proposals", mon["sample_proposals"]),
+                 ("target_class_ids", mon["target_class_ids"]), ("s_valid", mon["s_valid"]), ("detections", mon["detections"]),
+                 ("det_valid", mon["det_valid"]), ("vals", vals)]
+        return mutils.pack_for_readout(items)
+
+    def monitor_results(self, packed, batch, img_shape, is_validation=False, detection_masks=None):
+        """Host side of the read-out: the reference's results_dict entries ('boxes', 'seg_preds', 'monitor_values', 'logger_string',
+        mrcnn.py:898-961) from the packed buffer of monitor_pack()."""
+        cf = self.cf
+        r = mutils.unpack_readout(packed)
+        B = img_shape[0]
+        box_results_list = [[] for _ in range(B)]
+        for b in range(B):
+            for ix in range(len(batch["bb_target"][b])):
+                box_results_list[b].append({"box_coords": batch["bb_target"][b][ix], "box_label": batch["roi_labels"][b][ix], "box_type": "gt"})
+        if getattr(self, "_anchors_host", None) is None:
+            self._anchors_host = self.anchors.cpu().numpy()          # constant table: read back once, not every step
+        anchors_np = self._anchors_host
+        pidx, pvalid, nidx, nvalid = r["pidx"], r["pvalid"].astype(bool), r["nidx"], r["nvalid"].astype(bool)
+        for b in range(B):
+            for a in anchors_np[pidx[b][pvalid[b]]]:
+                box_results_list[b].append({"box_coords": a, "box_type": "pos_anchor"})
+            for a in anchors_np[nidx[b][nvalid[b]]]:
+                box_results_list[b].append({"box_coords": a, "box_type": "neg_anchor"})
+            for row in r["props"][b]:
+                box_results_list[b].append({"box_coords": row, "box_type": "prop"})
+        sp, tc = r["sample_proposals"], r["target_class_ids"]
+        for ix, row in enumerate(sp):
+            if row[-1] >= 0:
+                box_results_list[int(row[-1])].append({"box_coords": row[:-1] * cf.scale, "box_type": "pos_class" if tc[ix] > 0 else "neg_class"})
+        return_masks = cf.return_masks_in_val if is_validation else False
+        res = get_results(cf, img_shape, r["detections"], r["det_valid"].astype(bool), detection_masks, box_results_list, return_masks=return_masks)
+        tcv = tc[r["s_valid"].astype(bool)]
+        dcount = [int((tcv == c).sum()) for c in range(1, cf.head_classes)]
+        vals = r["vals"]
+        res["monitor_values"] = {"loss": float(vals[0]), "class_loss": float(vals[3])}
+        res["logger_string"] = (
+            "loss: {0:.2f}, rpn_class: {1:.2f}, rpn_bbox: {2:.2f}, mrcnn_class: {3:.2f}, mrcnn_bbox: {4:.2f}, "
+            "mrcnn_mask: {5:.2f}, dcount {6}".format(vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], dcount))
+        return res
+
+    def train_forward(self, batch, is_validation=False, monitor=True):
+        """mrcnn.py:853-967.  batch: the reference's batch dict (numpy): 'data', 'roi_labels', 'bb_target', 'roi_masks'.
+        monitor=False skips the read-out and the python box lists (the loss terms are unchanged).
+        The mask head over the DETECTIONS (mrcnn.py:1046-1048) only feeds the validation read-out (return_masks, :949); in a training
+        step its result is dropped by the reference and it is not run here, unless cf.run_detection_mask_head_in_training asks for the
+        reference's exact work (bench.py `exec_equivalent`)."""
+        cf = self.cf
+        d = self.prepare_batch(batch)
+        with_masks = bool(is_validation and cf.return_masks_in_val) or bool(getattr(cf, "run_detection_mask_head_in_training", False))
+        out = self.train_forward_device(d["img"], d["gt"], d["masks"], with_masks=with_masks)
         # the five terms of mrcnn.py:946 as device scalars (no read-out here): what the assembled-step parity test compares
-        results_dict = {"torch_loss": loss,
-                        "loss_terms": {"rpn_class": batch_rpn_class_loss.detach(), "rpn_bbox": batch_rpn_bbox_loss.detach(),
-                                       "mrcnn_class": mrcnn_class_loss.detach(), "mrcnn_bbox": mrcnn_bbox_loss.detach(),
-                                       "mrcnn_mask": mrcnn_mask_loss.detach()},
-                        "sample_counts": (s_valid.sum(), s_pos.sum())}
+        results_dict = {"torch_loss": out["loss"], "loss_terms": out["terms"], "sample_counts": out["sample_counts"]}
         if monitor:
-            box_results_list = [[] for _ in range(B)]
-            for b in range(B):
-                for ix in range(len(gt_boxes[b])):
-                    box_results_list[b].append({"box_coords": batch["bb_target"][b][ix], "box_label": batch["roi_labels"][b][ix], "box_type": "gt"})
-            pidx, pvalid, nidx, nvalid = [t.cpu().numpy() for t in rpn_samples]
-            anchors_np = self.anchors.cpu().numpy()
-            props = proposal_boxes.cpu().numpy()
-            for b in range(B):
-                for a in anchors_np[pidx[b][pvalid[b]]]:
-                    box_results_list[b].append({"box_coords": a, "box_type": "pos_anchor"})
-                for a in anchors_np[nidx[b][nvalid[b]]]:
-                    box_results_list[b].append({"box_coords": a, "box_type": "neg_anchor"})
-                rp = props[b][props[b, :, -1].argsort()][::-1]
-                for r in rp[:cf.n_plot_rpn_props, :-1]:
-                    box_results_list[b].append({"box_coords": r, "box_type": "prop"})
-            sp = sample_proposals.detach().cpu().numpy()
-            tc = target_class_ids.cpu().numpy()
-            for ix, r in enumerate(sp):
-                if r[-1] >= 0:
-                    box_results_list[int(r[-1])].append({"box_coords": r[:-1] * cf.scale, "box_type": "pos_class" if tc[ix] > 0 else "neg_class"})
-            return_masks = cf.return_masks_in_val if is_validation else False
-            results_dict.update(get_results(cf, img.shape, detections, det_valid, detection_masks, box_results_list, return_masks=return_masks))
-            tcv = tc[s_valid.cpu().numpy()]
-            dcount = [int((tcv == c).sum()) for c in range(1, cf.head_classes)]
-            vals = torch.stack([loss.detach(), batch_rpn_class_loss.detach(), batch_rpn_bbox_loss.detach(), mrcnn_class_loss.detach(),
-                                mrcnn_bbox_loss.detach(), mrcnn_mask_loss.detach()]).cpu().numpy()      # one read-out instead of six .item()
-            results_dict["monitor_values"] = {"loss": float(vals[0]), "class_loss": float(vals[3])}
-            results_dict["logger_string"] = (
-                "loss: {0:.2f}, rpn_class: {1:.2f}, rpn_bbox: {2:.2f}, mrcnn_class: {3:.2f}, mrcnn_bbox: {4:.2f}, "
-                "mrcnn_mask: {5:.2f}, dcount {6}".format(vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], dcount))
+            results_dict.update(self.monitor_results(self.monitor_pack(out), batch, tuple(d["img"].shape), is_validation,
+                                                     detection_masks=out["mon"]["detection_masks"]))
         return results_dict
 
     def test_forward(self, batch, return_masks=True):

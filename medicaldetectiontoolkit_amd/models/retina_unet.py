@@ -194,19 +194,13 @@ class net(nn.Module):
         B = img.shape[0]
         gt_dev = GtOnDevice(gt_boxes, gt_class_ids, cf.dim, dev)      # one pinned async upload, before the backbone launch
         detections, det_valid, class_logits, pred_deltas, seg_logits = self.forward(img)
-        matches, argmaxes = [], []
+        # anchor matching of the whole batch: ONE launch pair, GT counts read on the device (the reference: one numpy
+        # gt_anchor_matching per element on the host, retina_unet.py:408-420)
         neg_thr = 0.1 if cf.dim == 2 else 0.01
-        for b in range(B):
-            n_b = gt_dev.n_all[b]
-            if n_b > 0:
-                gt_t, cls_t = gt_dev.px[b, :n_b], gt_dev.cls_i32[b, :n_b]
-            else:
-                gt_t, cls_t = None, None
-            m, am, _, _ = mutils.anchor_match_labels(self.anchors_f64, gt_t, cls_t, neg_thr, float(cf.anchor_matching_iou))
-            matches.append(m)
-            argmaxes.append(am)
+        rpn_match, rpn_argmax = mutils.anchor_match_labels_batched(self.anchors_f64, gt_dev.px, gt_dev.n_gt, gt_dev.cls_i32, neg_thr,
+                                                                   float(cf.anchor_matching_iou))
         batch_class_loss, batch_bbox_loss, samples = compute_rpn_losses(
-            torch.stack(matches), torch.stack(argmaxes), class_logits, pred_deltas, self.anchors_f64, gt_boxes, cf,
+            rpn_match, rpn_argmax, class_logits, pred_deltas, self.anchors_f64, gt_boxes, cf,
             shem_poolsize=getattr(cf, "retina_shem_poolsize", 20),      # the reference calls compute_class_loss with its default 20 (retina_unet.py:432)
             gt_dev=gt_dev)
         loss = batch_class_loss + batch_bbox_loss
@@ -227,7 +221,9 @@ class net(nn.Module):
                 for ix in range(len(gt_boxes[b])):
                     box_results_list[b].append({"box_coords": batch["bb_target"][b][ix], "box_label": batch["roi_labels"][b][ix], "box_type": "gt"})
             pidx, pvalid, nidx, nvalid = [t.cpu().numpy() for t in samples]
-            anchors_np = self.anchors.cpu().numpy()
+            if getattr(self, "_anchors_host", None) is None:
+                self._anchors_host = self.anchors.cpu().numpy()      # constant table: read back once, not every step
+            anchors_np = self._anchors_host
             for b in range(B):
                 for a in anchors_np[pidx[b][pvalid[b]]]:
                     box_results_list[b].append({"box_coords": a, "box_type": "pos_anchor"})

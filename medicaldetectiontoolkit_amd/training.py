@@ -35,6 +35,13 @@ class FlatAdam(torch.optim.Adam):
     * a parameter that received no gradient in a step sees a ZERO gradient (torch skips it): identical while it never had one
       (the unused P1 convolutions of the reference FPN, backbone.py:112,118) and for weight_decay = 0 otherwise up to the decay of its
       moments -- the same convention the multi-GPU path has (FlatGradAllReduce).  One step counter for all parameters.
+    * ONE step counter for all parameters (bias corrections 1 - beta^t): torch.optim.Adam counts per parameter from the parameter's
+      first gradient.  In the fixed-size masked step of this repo every trainable parameter receives a gradient in every step (the
+      heads see zero-weighted padding rows instead of being skipped), so the counters coincide; a loaded state whose per-parameter
+      steps DIFFER is refused rather than collapsed to one value.
+    * every step checks that each `p.data` is still the view into the flat parameter buffer (`net.to(memory_format=...)`, `.half()`,
+      `load_state_dict(assign=True)` or a second FlatAdam over the same net re-point it -- the kernel would then update an orphaned
+      buffer and the model would silently stop training): on mismatch the flat buffers are rebuilt from the live parameters.
     * amsgrad / maximize / capturable / differentiable are not supported (the reference never sets them)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_sync=None):
@@ -60,6 +67,7 @@ class FlatAdam(torch.optim.Adam):
             if len(gs.params) != len(params) or any(a is not b for a, b in zip(gs.params, params)):
                 raise ValueError("FlatAdam: grad_sync was built over a different parameter list")
             fgrad = gs.flat
+            gs.defer_div = True         # this optimizer divides by the world size inside its launch
         else:
             fgrad = torch.zeros(n, dtype=torch.float32, device=dev)
         fparam = torch.empty(n, dtype=torch.float32, device=dev)
@@ -67,6 +75,7 @@ class FlatAdam(torch.optim.Adam):
         fv = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         gviews = []
+        loaded_steps = set()
         with torch.no_grad():
             for p in reversed(params):                       # backward order, as FlatGradAllReduce lays the gradients out
                 v = _view_like(fparam, off, p)
@@ -79,11 +88,17 @@ class FlatAdam(torch.optim.Adam):
                     st["exp_avg"].copy_(old_state["exp_avg"])
                     st["exp_avg_sq"].copy_(old_state["exp_avg_sq"])
                     st["step"] = torch.tensor(float(old_state["step"]))
-                    self._steps = max(self._steps, int(float(old_state["step"])))
+                    loaded_steps.add(int(float(old_state["step"])))
                 self.state[p] = st
                 off += p.numel()
+        if len(loaded_steps) > 1:
+            raise ValueError("FlatAdam: the adopted optimizer state has different step counts per parameter (%s); FlatAdam keeps ONE "
+                             "counter -- continue such a run with torch.optim.Adam" % sorted(loaded_steps))
+        if loaded_steps:
+            self._steps = max(self._steps, loaded_steps.pop())
         self._params = params
         self._rparams = list(reversed(params))
+        self._pptr = [p.data_ptr() for p in self._rparams]       # where each parameter must still live at every step
         self._gviews = gviews                       # flat-gradient views, in `_rparams` order
         self._gdirty = [False] * len(gviews)        # view holds a gradient of an earlier step
         self._flat = (fparam, fgrad, fm, fv)
@@ -113,6 +128,8 @@ class FlatAdam(torch.optim.Adam):
         g = self.param_groups[0]
         if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
             raise ValueError("FlatAdam: amsgrad / maximize / capturable / differentiable are not supported")
+        if any(p.data_ptr() != q for p, q in zip(self._rparams, self._pptr)):
+            self._build()                # a parameter was re-pointed: re-home all of them (moments are carried over by `_build`)
         fparam, fgrad, fm, fv = self._flat
         if self._grad_sync is not None:
             for p in self._params:       # a dropped view (someone's zero_grad(set_to_none=True)) would silently freeze p
@@ -133,18 +150,21 @@ class FlatAdam(torch.optim.Adam):
             if dst:
                 torch._foreach_copy_(dst, src)
         self._steps += 1
+        gdiv = 1.0
+        if self._grad_sync is not None:      # the all-reduce left SUMS: the division by the world size rides this launch
+            gdiv, self._grad_sync.pending_div = float(self._grad_sync.pending_div), 1.0
         self._update(fparam, fgrad, fm, fv, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                     float(g["weight_decay"]), self._steps)
+                     float(g["weight_decay"]), self._steps, gdiv)
         for p in self._params:
             self.state[p]["step"].fill_(float(self._steps))   # CPU scalars (torch.optim.Adam's own format)
         return loss
 
-    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, step):
+    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, step, grad_div=1.0):
         """the one launch (csrc/adam.hip); no CPU implementation in the product -- the gloo tests substitute this method"""
         from . import _lib
         with torch.cuda.device(fparam.device):
             rc = _lib.lib().mdt_adam_flat(fparam.data_ptr(), fgrad.data_ptr(), fm.data_ptr(), fv.data_ptr(), fparam.numel(), lr, beta1, beta2,
-                                          eps, weight_decay, step, _lib.raw_stream(fparam))
+                                          eps, weight_decay, step, grad_div, _lib.raw_stream(fparam))
         _lib.check(rc, "mdt_adam_flat")
 
 
@@ -174,6 +194,11 @@ class FlatGradAllReduce(object):
         self.flat = None
         self._hooks = []
         self._handles = []
+        self.suspended = False       # True: the backward hooks launch nothing (GraphedTrainStep: the collectives run after the replay)
+        # defer_div: a FlatAdam built over this buffer folds the averaging (sum / world) into its one launch (mdt_adam_flat's grad_div)
+        # instead of a separate pass over the buffer; until its step() the buffer then holds the SUM over ranks, pending_div the divisor
+        self.defer_div = False
+        self.pending_div = 1.0
 
     # -- setup (lazy: parameters must already live on their device)
     def _build(self):
@@ -210,7 +235,7 @@ class FlatGradAllReduce(object):
             self._next += 1
 
     def _on_grad(self, p):
-        if not self._active():
+        if self.suspended or not self._active():
             return
         b = self.bucket_of[p]
         self._left[b] -= 1
@@ -236,7 +261,25 @@ class FlatGradAllReduce(object):
         self._launch_ready(force=True)
         for h in self._handles:
             h.wait()
-        self.flat.div_(dist.get_world_size())
+        self._average()
+
+    def _average(self):
+        w = dist.get_world_size()
+        if self.defer_div:
+            self.pending_div = float(w)
+        elif w > 1:
+            self.flat.div_(w)
+
+    def finish_all(self):
+        """after a captured backward (GraphedTrainStep: hooks suspended): all buckets in order, wait, average"""
+        if not self._active():
+            return
+        self._next = 0
+        self._handles = []
+        self._launch_ready(force=True)
+        for h in self._handles:
+            h.wait()
+        self._average()
 
     def __call__(self):          # round-1 spelling
         self.finish()
@@ -257,6 +300,10 @@ def _dense(p):
 
 def train_step(net, optimizer, batch, grad_sync=None, monitor=False):
     """exec.py:68-74: results = net.train_forward(batch); zero_grad; loss.backward(); optimizer.step()."""
+    if isinstance(optimizer, FlatAdam) and optimizer._grad_sync is not grad_sync:
+        raise ValueError("train_step: this FlatAdam was built %s, the step was called %s: the optimizer would read a gradient buffer the "
+                         "collective never touches" % ("without a grad_sync" if optimizer._grad_sync is None else "over another grad_sync",
+                                                       "with one" if grad_sync is not None else "without"))
     results = net.train_forward(batch, monitor=monitor)
     if isinstance(optimizer, FlatAdam):
         optimizer.zero_grad()            # one fill (and the bucket bookkeeping of its grad_sync, if any)
@@ -269,3 +316,220 @@ def train_step(net, optimizer, batch, grad_sync=None, monitor=False):
         grad_sync.finish()
     optimizer.step()
     return results
+
+
+class GraphedTrainStep(object):
+    """exec.py:68-74 with the DEVICE half of the step -- forward, target layer, heads, matching, losses, backward: ~1500 kernel launches
+    that cost 38-40 ms of host time against 43 ms of GPU time when issued one by one -- captured once in ONE hipGraph and
+    replayed with a single hipGraphLaunch (0.3 ms of host time for the FPN + RPN segment, tools/graph_segment_whole_probe.py).
+
+    What makes the step capturable: fixed-size masked tensors everywhere in the glue (round 2), GT counts read on the device by the
+    batched matching kernel (no per-element launches, no host integers in launch parameters), a fixed-size GT table (`gmax` objects
+    per element) and a fixed-capacity uint8 mask stack (`max_masks`) as STATIC inputs, the device RNG (torch registers its Philox
+    state with the graph), no host synchronisation inside the step.  Per call: the batch is copied into the static inputs (device
+    batches: device-to-device; host numpy batches: pinned staging + one asynchronous upload each), the graph is replayed, then --
+    eagerly, three launches -- the gradient all-reduce (N > 1; bucketed, after the replay) and the Adam update.
+    The eager step (`train_step`) stays the reference implementation: `tests/test_graph_step_gpu.py` requires bit-identical losses
+    and gradients from both on a deterministic batch.
+
+    monitor=True: the read-out tensors are packed inside the graph (net.monitor_pack) and leave with ONE device->host copy per step."""
+
+    def __init__(self, net, optimizer, grad_sync=None, gmax=8, max_masks=None, monitor=False, with_masks=False, warmup=2):
+        if not hasattr(net, "train_forward_device"):
+            raise TypeError("GraphedTrainStep needs a model with the split step (prepare_batch / train_forward_device): models.mrcnn.net")
+        if isinstance(optimizer, FlatAdam) and optimizer._grad_sync is not grad_sync:
+            raise ValueError("GraphedTrainStep: optimizer and step disagree about the grad_sync")
+        self.net, self.opt, self.sync = net, optimizer, grad_sync
+        self.gmax, self.monitor, self.with_masks, self.warmup = int(gmax), bool(monitor), bool(with_masks), int(warmup)
+        self.max_masks = max_masks
+        self.graph = None
+        self.static = None
+        self.host_ms = None          # set to a dict to collect host-side wall time per phase of __call__ (diagnosis; bench.py exec leg)
+
+    # -- static inputs
+    def _alloc(self, batch):
+        net, cf, dev = self.net, self.net.cf, self.net.device_
+        B = len(batch["bb_target"])
+        shape = tuple(int(v) for v in batch["data"].shape)
+        mm = self.max_masks if self.max_masks is not None else B * min(self.gmax, 4)
+        self.static = {"img": torch.zeros(shape, dtype=torch.float32, device=dev),
+                       "gt": torch.zeros((B, self.gmax, 2 * cf.dim + 4), dtype=torch.float64, device=dev),
+                       "masks": torch.zeros((mm, 1) + shape[2:], dtype=torch.uint8, device=dev)}
+        self.static["gt"][:, :, 2 * cf.dim + 2] = -1.0
+
+    def _load(self, batch):
+        """copy one batch into the static inputs (asynchronous; nothing here waits for the GPU)"""
+        from .models.mrcnn import GtOnDevice
+        from .utils import model_utils as mutils
+        st, cf, dev = self.static, self.net.cf, self.net.device_
+        ev = batch.get("ready_event")            # DevicePrefetcher: the uploads ran on its side stream
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for k in ("data", "roi_masks_device"):
+                if torch.is_tensor(batch.get(k)):
+                    batch[k].record_stream(cur)     # allocated on the side stream, read here: do not recycle before this read ran
+        # the small GT table goes through its own persistent pinned ring: a fresh pinned allocation per step (torch's caching host
+        # allocator hands a block out again only after its copy has EXECUTED) is a hipHostMalloc -- and an implicit device sync --
+        # every step once the host runs ahead of the GPU, which it does by a whole step here (measured: 41 ms of "host issue" per step)
+        stage, _, _ = GtOnDevice.stage(batch["bb_target"], batch["roi_labels"], cf.dim, gmax=self.gmax, pin=False)
+        st["gt"].copy_(mutils.stage_pinned(stage, dev, "gt_table"), non_blocking=True)
+        mutils.stage_release(dev, "gt_table")
+        data = batch["data"]
+        if torch.is_tensor(data) and data.is_cuda:
+            st["img"].copy_(data, non_blocking=True)
+        else:
+            st["img"].copy_(mutils.stage_pinned(data, dev, "data"), non_blocking=True)
+            mutils.stage_release(dev, "data")
+        if "roi_masks_device" in batch:
+            m = batch["roi_masks_device"]
+            n = 0 if m is None else int(m.shape[0])
+            if n > st["masks"].shape[0]:
+                raise ValueError("the batch holds %d GT masks, the static mask stack %d (GraphedTrainStep(max_masks=...))" % (n, st["masks"].shape[0]))
+            if n:
+                st["masks"][:n].copy_(m, non_blocking=True)
+        else:
+            parts = [p for p in batch["roi_masks"] if len(p) > 0]
+            n = sum(int(p.shape[0]) for p in parts)
+            if n > st["masks"].shape[0]:
+                raise ValueError("the batch holds %d GT masks, the static mask stack %d (GraphedTrainStep(max_masks=...))" % (n, st["masks"].shape[0]))
+            if n:
+                st["masks"][:n].copy_(mutils.stage_pinned(parts, dev, "masks"), non_blocking=True)
+                mutils.stage_release(dev, "masks")
+
+    # -- the captured body
+    def _body(self):
+        from .models.mrcnn import GtOnDevice
+        net, st = self.net, self.static
+        gt_dev = GtOnDevice(None, None, net.cf.dim, net.device_, table=st["gt"])
+        out = net.train_forward_device(st["img"], gt_dev, st["masks"], with_masks=self.with_masks)
+        if self.sync is not None:
+            self.sync.zero()
+        else:
+            for p in self._params:
+                p.grad = None
+        out["loss"].backward()
+        packed = net.monitor_pack(out) if self.monitor else None
+        return out, packed
+
+    def capture(self, batch):
+        """warm up and capture on `batch` (its shapes fix the static inputs); __call__ does this on its first call"""
+        from .cuda_functions import _roi_align_impl
+        if _roi_align_impl.PROFILE is not None:
+            raise RuntimeError("GraphedTrainStep: switch the RoIAlign event profile off before the capture (events cannot be recorded inside a graph)")
+        self._params = [p for p in self.net.parameters() if p.requires_grad]
+        if isinstance(self.opt, FlatAdam) and self.opt._flat is None:
+            self.opt._build()            # re-homes the parameters: must happen before their addresses are baked into the graph
+        if self.sync is not None:
+            if self.sync.flat is None:
+                self.sync._build()
+            self.sync.suspended = True   # the bucket all-reduces are launched after the replay, not from hooks inside the capture
+        self._alloc(batch)
+        self._load(batch)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):    # warm-up on a side stream (MIOpen find, workspaces, cached constants), as torch's capture protocol asks
+            for _ in range(max(1, self.warmup)):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._out, self._packed = self._body()
+        self._grads = [p.grad for p in self._params]
+        torch.cuda.synchronize()
+
+    def __call__(self, batch):
+        import time
+        if self.graph is None:
+            self.capture(batch)
+        hm = self.host_ms
+        t0 = time.perf_counter()
+        self._load(batch)
+        t1 = time.perf_counter()
+        self.graph.replay()
+        t2 = time.perf_counter()
+        if self.sync is None:
+            for p, g in zip(self._params, self._grads):      # (an eager zero_grad() in between may have dropped them)
+                p.grad = g
+        else:
+            self.sync.finish_all()
+        self.opt.step()
+        t3 = time.perf_counter()
+        out = self._out
+        res = {"torch_loss": out["loss"].detach(), "loss_terms": out["terms"], "sample_counts": out["sample_counts"]}
+        if self.monitor:
+            host = self._packed[0].detach().cpu()                 # the ONE device->host copy (and the one sync) of the step
+            t4 = time.perf_counter()
+            res.update(self.net.monitor_results((host.numpy(), self._packed[1]), batch, tuple(self.static["img"].shape), False,
+                                                detection_masks=None))
+            if hm is not None:
+                hm["readout_wait"] = hm.get("readout_wait", 0.0) + (t4 - t3) * 1e3
+                hm["readout_host"] = hm.get("readout_host", 0.0) + (time.perf_counter() - t4) * 1e3
+        if hm is not None:
+            hm["load"] = hm.get("load", 0.0) + (t1 - t0) * 1e3
+            hm["replay"] = hm.get("replay", 0.0) + (t2 - t1) * 1e3
+            hm["collective_adam"] = hm.get("collective_adam", 0.0) + (t3 - t2) * 1e3
+            hm["calls"] = hm.get("calls", 0) + 1
+        return res
+
+
+class DevicePrefetcher(object):
+    """Iterator over the reference's batch dicts (host numpy arrays, what batchgenerators' MultiThreadedAugmenter delivers to
+    exec.py:67) that hands them out with the bulky entries already in HBM: a background thread copies batch i + 1 into pinned ring
+    buffers (GIL-free memcpy) and enqueues its uploads on a SIDE stream while the GPU runs step i, so the PCIe time of
+    `torch.FloatTensor(img).cuda()` (mrcnn.py:869) disappears behind the step.  Each batch comes out as a dict with 'data' (device
+    fp32), 'roi_masks_device' (stacked uint8 masks), every other entry untouched, and 'ready_event' (recorded on the side stream after
+    the uploads; training.GraphedTrainStep and train_step wait for it on the compute stream)."""
+
+    def __init__(self, batches, device, depth=2):
+        import queue
+        import threading
+        self.device = torch.device(device)
+        self.q = queue.Queue(maxsize=max(1, int(depth)))
+        self.src = iter(batches)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._stop = False
+        self.thread = threading.Thread(target=self._run, name="mdt-prefetch", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        from .utils import model_utils as mutils
+        try:
+            with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+                for batch in self.src:
+                    if self._stop:
+                        break
+                    out = dict(batch)
+                    if not (torch.is_tensor(batch["data"]) and batch["data"].is_cuda):
+                        out["data"] = mutils.stage_pinned(batch["data"], self.device, "prefetch_data").to(self.device, non_blocking=True)
+                        mutils.stage_release(self.device, "prefetch_data")
+                    if "roi_masks_device" not in batch:
+                        parts = [m for m in batch["roi_masks"] if len(m) > 0]
+                        if parts:
+                            out["roi_masks_device"] = mutils.stage_pinned(parts, self.device, "prefetch_masks").to(self.device, non_blocking=True)
+                            mutils.stage_release(self.device, "prefetch_masks")
+                        else:
+                            out["roi_masks_device"] = None
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                    out["ready_event"] = ev
+                    self.q.put(out)
+            self.q.put(None)
+        except BaseException as e:      # hand the failure to the consumer instead of dying silently
+            self.q.put(e)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self.q.get()
+        if item is None:
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def close(self):
+        self._stop = True

@@ -171,6 +171,27 @@ def upload(array_or_tensor, device, channel="data"):
     return d
 
 
+_PENDING_SLOT = {}
+
+
+def stage_pinned(array_or_parts, device, channel):
+    """host numpy array / CPU tensor (or a list of them, stacked along dim 0) -> a view of the channel's persistent pinned ring slot
+    holding a copy of it.  The caller enqueues ITS OWN asynchronous copy out of the slot (e.g. straight into a static graph input,
+    training.GraphedTrainStep) and then calls stage_release(device, channel), which guards the slot with an event."""
+    parts = array_or_parts if isinstance(array_or_parts, (list, tuple)) else [array_or_parts]
+    parts = [_as_cpu_tensor(p).contiguous() for p in parts]
+    st = _stager(device, channel)
+    nbytes = sum(t.numel() * t.element_size() for t in parts)
+    k, raw = st.acquire(nbytes)
+    _PENDING_SLOT[(str(torch.device(device)), channel)] = k
+    return _stack_into(raw, parts, pool=_stage_pool())
+
+
+def stage_release(device, channel):
+    """call after the asynchronous copy out of the slot stage_pinned() returned has been enqueued on the current stream"""
+    _stager(device, channel).release(_PENDING_SLOT.pop((str(torch.device(device)), channel)))
+
+
 class StagedUpload(object):
     """Upload whose host half (stacking `parts` along dim 0 into pinned memory) runs on a background thread while the caller
     keeps launching kernels; `.get()` -- called on the caller's thread, i.e. on ITS current stream -- waits for the staging
@@ -200,6 +221,37 @@ class StagedUpload(object):
         d = pinned.to(self.device, non_blocking=True)
         self.stager.release(k)
         return d
+
+
+# --------------------------------------------------------------------------- one device->host copy for a set of small tensors
+def pack_for_readout(items):
+    """[(name, device tensor)] -> (one int32 device buffer, layout): fp32 tensors travel as their bit pattern, bool / integer ones as
+    int32.  Device side of a read-out that costs ONE device->host copy (and one sync) instead of one per tensor; launches only."""
+    flat, layout, at = [], [], 0
+    for name, t in items:
+        t = t.detach()
+        if t.dtype == torch.float64:
+            t = t.float()
+        if t.dtype == torch.float32:
+            f, kind = t.contiguous().view(-1).view(torch.int32), "f32"
+        else:
+            f, kind = t.to(torch.int32).reshape(-1), "i32"
+        flat.append(f)
+        layout.append((name, kind, tuple(t.shape), at, int(f.numel())))
+        at += int(f.numel())
+    return torch.cat(flat), layout
+
+
+def unpack_readout(packed):
+    """host side of pack_for_readout: {name: numpy array}; `packed[0]` may be the device buffer (copied here: the one sync of the
+    read-out) or a host tensor / numpy array that was already copied"""
+    buf, layout = packed
+    host = buf.detach().cpu().numpy() if torch.is_tensor(buf) else np.asarray(buf)
+    out = {}
+    for name, kind, shape, at, n in layout:
+        a = host[at:at + n]
+        out[name] = (a.view(np.float32) if kind == "f32" else a).reshape(shape)
+    return out
 
 
 # --------------------------------------------------------------------------- anchor <-> GT matching

@@ -88,7 +88,8 @@ class _TorchMathFlatAdam(training.FlatAdam):
     adoption of the collective's gradient buffer, state dict) is what these CPU tests exercise; the kernel itself is pinned
     against torch.optim.Adam on the GPU (tests/test_flat_adam_gpu.py)."""
 
-    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, step):
+    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, step, grad_div=1.0):
+        fgrad = fgrad / grad_div if grad_div != 1.0 else fgrad       # the averaging folded into the update (mdt_adam_flat's grad_div)
         g = fgrad + weight_decay * fparam if weight_decay != 0 else fgrad
         fm.lerp_(g, 1 - beta1)
         fv.mul_(beta2).addcmul_(g, g, value=1 - beta2)

@@ -1,0 +1,143 @@
+"""training.GraphedTrainStep (the device half of the Mask R-CNN training step captured in ONE hipGraph) against the eager step
+(training.train_step) -- the eager step is pinned against the reference's own train_forward (tests/test_step_parity_gpu.py), so the
+graph inherits that parity if it reproduces the eager step:
+  * on the deterministic golden batch (no random draw changes a sampled set: tests/golden/step_inputs.py) the replayed loss terms are
+    BIT-IDENTICAL to the eager ones (the forward is deterministic) and every parameter gradient agrees to 1e-5 of its max-abs
+    (MIOpen's backward-weights solvers accumulate with atomics: run-to-run differences of one ulp exist in eager mode too); after k
+    optimizer steps the parameters agree likewise;
+  * the static inputs really are inputs: replaying with a second batch gives that batch's eager losses;
+  * a batch with more GT objects than the fixed-size table holds is refused, loudly."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import step_inputs as si
+from tests.test_step_parity_gpu import GOLDS, _batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _seeded(fn, *a, **k):
+    """same Philox seed / offset for the eager step and for the replay (torch's graph-safe RNG reads both at replay time): the random
+    keys that ORDER the sampled rows are then the same, and so is every fp32 summation order"""
+    torch.manual_seed(1234)
+    return fn(*a, **k)
+
+
+def _net(cuda, case="small"):
+    from medicaldetectiontoolkit_amd import miopen_env
+    miopen_env.setup()
+    from medicaldetectiontoolkit_amd.models import mrcnn
+    cf = si.make_cf("mrcnn", case)
+    cf.channels_last = True
+    net = mrcnn.net(cf, device=cuda)
+    si.fill_by_name(net)
+    return net, cf
+
+
+def test_graphed_step_reproduces_eager_step_bit_for_bit(cuda):
+    from medicaldetectiontoolkit_amd import training
+    batch = _batch("small")
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        net_e, cf = _net(cuda)
+        net_g, _ = _net(cuda)
+        opt_e = training.build_optimizer(net_e, cf, flat=True)
+        opt_g = training.build_optimizer(net_g, cf, flat=True)
+        step = training.GraphedTrainStep(net_g, opt_g, gmax=4, max_masks=8)
+        step.capture(batch)
+        for k in range(3):
+            res_e = _seeded(training.train_step, net_e, opt_e, batch, monitor=False)
+            terms_e = {n: float(v) for n, v in res_e["loss_terms"].items()}
+            grads_e = {n: p.grad.detach().clone() for n, p in net_e.named_parameters() if p.grad is not None}
+            res_g = _seeded(step, batch)
+            terms_g = {n: float(v) for n, v in res_g["loss_terms"].items()}
+            if k == 0:
+                assert terms_g == terms_e, (k, terms_g, terms_e)
+                assert float(res_g["torch_loss"]) == float(res_e["torch_loss"])
+            else:
+                for n in terms_e:
+                    assert abs(terms_g[n] - terms_e[n]) <= 1e-4 * abs(terms_e[n]) + 1e-6, (k, n, terms_g[n], terms_e[n])
+            grads_g = {n: p.grad.detach().clone() for n, p in net_g.named_parameters() if p.grad is not None}
+            assert set(grads_g) == set(grads_e)
+            for n in grads_e:
+                err = float((grads_g[n] - grads_e[n]).abs().max())
+                assert err <= 1e-5 * float(grads_e[n].abs().max()) + 1e-12, (k, n, err)
+        for (n, a), (_, b) in zip(net_e.named_parameters(), net_g.named_parameters()):
+            # Adam normalises the gradient: an entry whose gradient is ~0 can move by a full lr = 1e-4 per step in either direction on
+            # a one-ulp difference; everything else agrees to ~1e-7.  Bound: the total movement of 3 steps.
+            assert float((a - b).abs().max()) <= 3e-4 + 1e-7, n
+            assert float((a - b).abs().mean()) <= 1e-6, (n, float((a - b).abs().mean()))
+        # the golden itself (reference train_forward on the CPU) for the first step's terms is checked in test_step_parity_gpu
+    finally:
+        torch.backends.cudnn.benchmark = prev
+
+
+def test_graphed_step_static_inputs_follow_the_batch(cuda):
+    """second batch (other image, GT boxes shifted, one element WITHOUT objects) through the same captured graph == its eager step;
+    then the first batch again"""
+    from medicaldetectiontoolkit_amd import training
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        net_e, cf = _net(cuda)
+        net_g, _ = _net(cuda)
+        b1 = _batch("small")
+        gold = GOLDS["small"]
+        img2 = si.make_image(seed=77)
+        gtb = [gold["gt_boxes_0"][:1].copy(), np.zeros((0, 6), dtype=np.float32)]
+        gtl = [gold["gt_labels_0"][:1].copy(), np.zeros((0,), dtype=np.int64)]
+        b2 = si.make_batch(img2, gtb, gtl)
+        # lr = 0: the weights stay put, so eager results of both batches can be compared with replays in any order
+        opt_e = training.FlatAdam(net_e.parameters(), lr=0.0)
+        opt_g = training.FlatAdam(net_g.parameters(), lr=0.0)
+        step = training.GraphedTrainStep(net_g, opt_g, gmax=4, max_masks=8)
+        step.capture(b1)
+        want = {}
+        for tag, b in (("b1", b1), ("b2", b2)):
+            r = _seeded(training.train_step, net_e, opt_e, b, monitor=False)
+            want[tag] = {n: float(v) for n, v in r["loss_terms"].items()}
+        for tag, b in (("b1", b1), ("b2", b2), ("b1", b1)):
+            r = _seeded(step, b)
+            got = {n: float(v) for n, v in r["loss_terms"].items()}
+            assert got == want[tag], (tag, got, want[tag])
+        assert want["b1"] != want["b2"]
+    finally:
+        torch.backends.cudnn.benchmark = prev
+
+
+def test_graphed_step_monitor_readout_equals_eager_readout(cuda):
+    """monitor=True: the packed one-copy read-out of the replay carries the same box lists / logger string as eager train_forward"""
+    from medicaldetectiontoolkit_amd import training
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        net_e, cf = _net(cuda)
+        net_g, _ = _net(cuda)
+        batch = _batch("small")
+        opt_g = training.FlatAdam(net_g.parameters(), lr=0.0)
+        step = training.GraphedTrainStep(net_g, opt_g, gmax=4, max_masks=8, monitor=True)
+        step.capture(batch)
+        r_e = _seeded(net_e.train_forward, batch, monitor=True)
+        r_g = _seeded(step, batch)
+        assert r_g["logger_string"] == r_e["logger_string"]
+        assert r_g["monitor_values"] == r_e["monitor_values"]
+        for be, bg in zip(r_e["boxes"], r_g["boxes"]):
+            assert [d["box_type"] for d in be] == [d["box_type"] for d in bg]
+            for de, dg in zip(be, bg):
+                assert np.array_equal(np.asarray(de["box_coords"]), np.asarray(dg["box_coords"]))
+        assert np.array_equal(r_e["seg_preds"], r_g["seg_preds"])
+    finally:
+        torch.backends.cudnn.benchmark = prev
+
+
+def test_graphed_step_refuses_a_batch_beyond_the_static_tables(cuda):
+    from medicaldetectiontoolkit_amd import training
+    net_g, cf = _net(cuda)
+    opt_g = training.FlatAdam(net_g.parameters(), lr=0.0)
+    step = training.GraphedTrainStep(net_g, opt_g, gmax=1, max_masks=8)
+    with pytest.raises(ValueError, match="GT objects"):
+        step(_batch("small"))          # two objects per element

@@ -416,3 +416,27 @@ def test_roialign3d_forward_staged_variant_bitexact(cuda, monkeypatch):
     monkeypatch.setenv("MDT_FWD_KERNEL", "staged")
     got = _roi_align_impl.crop_forward(_t(image, cuda), _t(boxes, cuda), _t(box_ind, cuda), (7, 7, 3))
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------ uint8-input forward (round 4: GT masks are cropped from their uint8 storage)
+@pytest.mark.parametrize("dim", [2, 3])
+def test_roialign_forward_uint8_input_bit_equal_to_fp32_and_oracle(dim, cuda):
+    """mdt_crop_and_resize_{2,3}d_forward_u8 == the fp32 kernel on image.float() == the oracle, bit for bit: the mask-target crop of
+    detection_target_layer (mrcnn.py:551-563) on the batch's uint8 masks; incl. an out-of-range box_ind (zero row) and a spilling box"""
+    rng = np.random.default_rng(11 + dim)
+    if dim == 3:
+        img = (rng.uniform(size=(5, 1, 32, 24, 16)) > 0.6).astype(np.uint8) * rng.integers(1, 4, size=(5, 1, 1, 1, 1)).astype(np.uint8)
+        boxes, crop, ra = random_boxes_3d(rng, 11, spill=True), (28, 28, 10), ra3D
+    else:
+        img = (rng.uniform(size=(5, 1, 40, 36)) > 0.6).astype(np.uint8)
+        boxes, crop, ra = random_boxes_2d(rng, 11, spill=True), (28, 28), ra2D
+    ind = rng.integers(0, 5, size=11).astype(np.int32)
+    ind[3] = -1
+    got = ra(*crop, 0)(_t(img, cuda), _t(boxes, cuda), _t(ind, cuda))
+    assert got.dtype == torch.float32
+    via_float = ra(*crop, 0)(_t(img, cuda).float(), _t(boxes, cuda), _t(ind, cuda))
+    assert torch.equal(got, via_float)
+    ok = ind >= 0
+    want = oracle.crop_and_resize_forward(img.astype(np.float32), boxes[ok], ind[ok], crop)
+    assert np.array_equal(got.cpu().numpy()[ok], want)
+    assert not got[3].any()

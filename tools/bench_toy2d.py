@@ -47,10 +47,11 @@ def toy_batch(size, batch, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--sizes", type=str, default="64,320", help="image sizes to run (BASELINE config 1 names 64x64)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.backends.cudnn.benchmark = True
-    for size, batch in ((64, 20), (320, 20)):
+    for size, batch in [(int(v), 20) for v in args.sizes.split(",")]:
         cf = Configs(dim=2, model="retina_net", patch_size=[size, size], batch_size=batch, rpn_train_anchors_per_image=2,
                      train_rois_per_image=2, class_dict={1: "circle", 2: "donut"})
         torch.manual_seed(0)
@@ -71,6 +72,7 @@ def main():
         res = net.test_forward(batches[0])
         n_det = sum(1 for b in res["boxes"] for d in b if d["box_type"] == "det")
         print(json.dumps({"config": "toy_exp 2D Retina Net, %dx%d, batch %d (BASELINE config 1 shapes, run on MI355X)" % (size, size, batch),
+                          "metric": "2D images/sec (train), toy_exp Retina Net", "value": round(batch * args.steps / dt, 1), "unit": "images/s",
                           "images_per_s": round(batch * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "steps": args.steps,
                           "loss_first5_mean": round(float(np.mean(losses[:5])), 4), "loss_last5_mean": round(float(np.mean(losses[-5:])), 4),
                           "test_forward_detections": n_det, "finite": bool(np.isfinite(losses).all())}), flush=True)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from medicaldetectiontoolkit_amd import _lib
 from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
-from tests.helpers import random_boxes_3d, trainlike_rois_3d
+from medicaldetectiontoolkit_amd.utils.synthetic_data import random_boxes_3d, trainlike_rois_3d
 
 dev = torch.device("cuda:0")
 L = _lib.lib()

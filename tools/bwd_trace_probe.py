@@ -4,7 +4,7 @@ sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from medicaldetectiontoolkit_amd import _lib
 from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
-from tests.helpers import random_boxes_3d
+from medicaldetectiontoolkit_amd.utils.synthetic_data import random_boxes_3d
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 B, C = 8, 36

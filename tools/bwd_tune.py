@@ -15,7 +15,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl  # noqa: E402
-from tests.helpers import random_boxes_3d  # noqa: E402
+from medicaldetectiontoolkit_amd.utils.synthetic_data import random_boxes_3d  # noqa: E402
 
 
 def timeit(fn, iters, warmup=10):

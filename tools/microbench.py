@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from medicaldetectiontoolkit_amd import _lib  # noqa: E402
 from medicaldetectiontoolkit_amd.cuda_functions import _nms_impl, _roi_align_impl  # noqa: E402
-from tests.helpers import nms_boxes, random_boxes_3d, trainlike_rois_3d  # noqa: E402
+from medicaldetectiontoolkit_amd.utils.synthetic_data import nms_boxes, random_boxes_3d, trainlike_rois_3d  # noqa: E402
 
 HBM_PEAK = 8.0e12
 

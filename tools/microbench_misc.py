@@ -7,7 +7,7 @@ from medicaldetectiontoolkit_amd import predictor
 from medicaldetectiontoolkit_amd.configs import Configs
 from medicaldetectiontoolkit_amd.cuda_functions import _nms_impl, _roi_align_impl
 from medicaldetectiontoolkit_amd.utils import model_utils as mutils
-from tests.helpers import nms_boxes, random_boxes_2d
+from medicaldetectiontoolkit_amd.utils.synthetic_data import nms_boxes, random_boxes_2d
 
 dev = torch.device("cuda:0"); rng = np.random.default_rng(0)
 

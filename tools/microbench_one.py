@@ -3,7 +3,7 @@ import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
-from tests.helpers import random_boxes_3d
+from medicaldetectiontoolkit_amd.utils.synthetic_data import random_boxes_3d
 N = int(os.environ.get("MDT_N", 48)); dev = torch.device("cuda:0"); rng = np.random.default_rng(0)
 shape = (8, 36, 32, 32, 128)
 boxes = torch.from_numpy(random_boxes_3d(rng, N)).to(dev)

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from medicaldetectiontoolkit_amd.cuda_functions import _nms_impl, _roi_align_impl  # noqa: E402
-from tests.helpers import nms_boxes, random_boxes_3d, trainlike_rois_3d  # noqa: E402
+from medicaldetectiontoolkit_amd.utils.synthetic_data import nms_boxes, random_boxes_3d, trainlike_rois_3d  # noqa: E402
 
 case = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -23,7 +23,7 @@ LEVELS = {"P2": (32, 32, 128), "P3": (16, 16, 64), "P4": (8, 8, 32), "P5": (4, 4
 shape = (8, 36) + LEVELS[os.environ.get("MDT_LEVEL", "P2")]
 boxes = torch.from_numpy(random_boxes_3d(rng, N)).to(dev)
 box_ind = torch.from_numpy(rng.integers(0, 8, size=N).astype(np.int32)).to(dev)
-if os.environ.get("MDT_ROIS", "random") == "trainlike":   # 6 RoIs per element, P2-sized (tests/helpers.trainlike_rois_3d)
+if os.environ.get("MDT_ROIS", "random") == "trainlike":   # 6 RoIs per element, P2-sized (utils/synthetic_data.trainlike_rois_3d)
     tb, ti = trainlike_rois_3d(rng, 8, N // 8, 8.0)
     boxes, box_ind = torch.from_numpy(tb).to(dev), torch.from_numpy(ti).to(dev)
 if os.environ.get("MDT_INVALID"):        # all rows routed to other pyramid levels (what the random-init bench sees on P2)
