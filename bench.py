@@ -27,6 +27,9 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# hipGraph replays of the step need the runtime's graph packet capture OFF (medicaldetectiontoolkit_amd/__init__.py explains); set before
+# anything can initialise the HIP runtime (the package import below does the same)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -247,13 +250,28 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, in_step_prof48=None, lau
                 "achieved": round(float(np.mean(byts)) / dur / 1e9, 1), "frac": round(float(np.mean(byts)) / dur / HBM_PEAK_BPS, 4),
                 "avg_us": round(dur * 1e6, 2), "launches": len(recs), "alg_bytes_per_launch": int(np.mean(byts)),
                 "rois": round(float(np.mean([int(m["n_valid"].item()) for _, m in recs])), 2)}
-    out = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": head["frac"], "traffic": head["traffic"],
+    kernel_desc = ("crop_bwd_gather_kernel (mdt_crop_and_resize_3d_backward, csrc/roi_align_bwd_v3.hip): P2 %s, pool %s, %d RoIs on the level, "
+                   "SURVEY 8(d) box distribution, training-step cache state (output map = fresh memory: 4 x 151 MB rotated; pooled gradients and "
+                   "boxes just produced)" % ("x".join(map(str, shape)), "x".join(map(str, crop)), n))
+    variants["P2_survey_8d_random_boxes_step_cache_state"] = dict(head)
+    full = variants.get("in_training_step_all_levels_one_launch_rois_heads_full")
+    if full is not None and full.get("rois", 0) >= 0.5 * n:
+        # HEADLINE: the op AS IT RUNS in the training step -- the mask head's pyramid backward (mdt_pyramid_roi_align_backward: all four
+        # gradient maps of the batch in ONE launch, 173.7 MB + the pooled gradients), event-timed inside eager training steps on a batch
+        # whose GT boxes come from the net's own proposals, so the RoI heads are (nearly) full instead of ~8 valid RoIs of 48: the real
+        # allocator / cache state, the real box distribution of the level rule.  The synthetic single-level cases are variants.
+        head = dict(full)
+        head["traffic"] = None
+        head["median_us"] = None
+        kernel_desc = ("crop_bwd_gather_kernel (mdt_pyramid_roi_align_backward, csrc/roi_align_bwd_v3.hip) AS IT RAN INSIDE TRAINING STEPS: the mask head's "
+                       "backward, all four pyramid gradient maps (8 x 36 x {32x32x128, 16x16x64, 8x8x32, 4x4x16}) in one launch, pool %s, %.1f valid RoIs of %d "
+                       "(GT boxes derived from the net's own proposals so that the RoI heads are full), HIP events around the launch in eager steps"
+                       % ("x".join(map(str, crop)), full["rois"], n))
+    out = {"bound": "hbm", "achieved": head["achieved"], "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": head["frac"], "traffic": head.get("traffic"),
            "traffic_source": ("OFFLINE measurement, not part of this run: profiles/r03_pmc/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes "
-                              "of this op, tools/gpu_pmc.sh)") if head["traffic"] else None,
-           "kernel": "crop_bwd_gather_kernel (mdt_crop_and_resize_3d_backward, csrc/roi_align_bwd_v3.hip): P2 %s, pool %s, %d RoIs on the level, "
-                     "SURVEY 8(d) box distribution, training-step cache state (output map = fresh memory: 4 x 151 MB rotated; pooled gradients and "
-                     "boxes just produced); same-buffer (cache-warm) and all-cold figures in `variants`" % ("x".join(map(str, shape)), "x".join(map(str, crop)), n),
-           "alg_bytes_per_launch": head["alg_bytes_per_launch"], "avg_us": head["avg_us"], "median_us": head["median_us"], "launches": launches,
+                              "of this op, tools/gpu_pmc.sh)") if head.get("traffic") else None,
+           "kernel": kernel_desc,
+           "alg_bytes_per_launch": head["alg_bytes_per_launch"], "avg_us": head["avg_us"], "median_us": head.get("median_us"), "launches": head.get("launches", launches),
            "timing": "HIP events around every launch on the launch stream; adds ~2 us over the kernel's own duration (profiles/r03_* rocprofv3 stats)",
            "variants": variants}
     return out
@@ -488,6 +506,7 @@ def main():
     ap.add_argument("--stem-fwd", type=int, default=1, help="1 (default): forward of the one-channel 7x7x7 stem on the fp32-MFMA kernel (csrc/conv_stem_fwd.hip); 0: MIOpen, space-to-depth form (A/B)")
     ap.add_argument("--conv3-small", type=int, default=1, help="1 (default): the few-channel 3x3x3 convolutions (18 -> 18 on the large maps) on the fp32-MFMA kernel (csrc/conv3x3x3_small.hip), forward and input gradient; 0: MIOpen (A/B)")
     ap.add_argument("--head-as-linear", type=int, default=1, help="1 (default): the classifier head's full-extent / 1x1x1 convolutions as GEMMs (models/mrcnn.py Classifier); 0: MIOpen convolutions (A/B)")
+    ap.add_argument("--merge-rpn-heads", type=int, default=1, help="1 (default): conv_class and conv_bbox of the RPN as one 1x1 convolution over the shared 128-channel map (models/mrcnn.py RPN); 0: two layers (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
     ap.add_argument("--pool-cl", type=int, default=1, help="1 (default): channels-last max pooling kernel of the stem (csrc/pool.hip); 0: torch (A/B)")
     ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
@@ -547,6 +566,7 @@ def main():
     from medicaldetectiontoolkit_amd.models import mrcnn, retina_unet
     from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch, to_device
     mrcnn.HEAD_AS_LINEAR = bool(args.head_as_linear)
+    mrcnn.MERGE_RPN_HEADS = bool(args.merge_rpn_heads)
 
     # MIOpen's immediate-mode heuristics pick naive 3D solvers for the 18/36/72-channel convolutions of this
     # backbone (3.2 s per step); the exhaustive find selects im2col+GEMM / CK kernels (42x faster, profiles/).
@@ -588,12 +608,23 @@ def main():
     for i in range(max(args.warmup, 1 if use_graph else 0)):
         run_step(pool[i % len(pool)])
     barrier()
+    if gstep is not None:
+        gstep.host_ms = {}
     t0 = time.time()
     for i in range(args.steps):
         run_step(pool[i % len(pool)])
     host_issue = time.time() - t0      # the host has launched everything (it runs ahead of the GPU while the step is GPU-bound)
     barrier()
     elapsed = time.time() - t0
+    host_work = None
+    if gstep is not None:
+        # host_issue includes BACK-PRESSURE (the pinned GT ring lets the host run at most 3 steps ahead of the GPU, then every step waits
+        # one GPU step): the host's own work per step is load + replay (hipGraphLaunch) + collective / Adam launch
+        hm, gstep.host_ms = gstep.host_ms, None
+        c = max(1, hm.pop("calls", 1))
+        host_work = {k: round(v / c, 3) for k, v in hm.items()}
+        host_work["work_total"] = round(sum(v for k, v in host_work.items() if k != "ring_wait_backpressure"), 3)
+        graph_rec["host_ms_per_step"] = host_work
 
     # ---- A/B leg: the EAGER step (~1500 launches issued one by one), same net / optimizer / batches; its RoIAlign backward launches are
     # event-timed for the roofline's in-step variant (events cannot be recorded inside a graph)

@@ -101,6 +101,11 @@ def lib():
     return _lib
 
 
+# > 0 while training.GraphedTrainStep captures a hipGraph: helpers that keep grown-on-demand device workspaces in module-level caches
+# must then hand out a fresh tensor from the graph's private pool instead (a cached workspace that is re-allocated LATER -- a bigger
+# shape in an eager call -- would leave the captured kernels pointing at freed memory)
+CAPTURING = 0
+
 _COUNTED = None     # {symbol: original ctypes function} while count_calls() is on
 CALLS = {}          # symbol -> number of calls since count_calls(True)
 

@@ -147,6 +147,160 @@ __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_kernel(
     crop_fwd_body<DIM, TIN>(image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, crops);
 }
 
+// ---------------------------------------------------------------------------
+// forward, wave-staged form (round 4): one WAVE per (RoI, channel)
+// ---------------------------------------------------------------------------
+// The direct kernel above issues 8 scattered 4-byte loads per output: a wave's load touches up to 64 different cache lines and the
+// texture-address unit serialises them (N = 240 RoIs x 36 channels x (14,14,5): 58 us for 34 MB of output = 7 % of HBM -- bound by
+// line look-ups, not by bytes).  Here a wave owns one (RoI, channel) pair: it reads every voxel row the RoI touches ONCE, as 16-byte
+// (4-element) loads along the contiguous z axis -- ~10-60 line look-ups per pair instead of ~1000 -- into its private LDS region, then
+// interpolates all ch x cw x cd outputs of the pair from LDS (scattered 4-byte LDS reads are what LDS is good at) and writes them as
+// one contiguous run.  The sample tables are built once per workgroup (4 waves = 4 channels of one RoI).  The arithmetic per output is
+// the direct kernel's, term for term (bit-exact against the oracle).  A pair whose source box does not fit the wave's LDS region (or a
+// map whose z extent is not a multiple of 4) takes the direct path inside the same kernel.
+constexpr int FW_WAVES = 4;
+constexpr int FW_THREADS = 64 * FW_WAVES;
+constexpr int FW_REGION_FLOATS = 3072;          // 12 KB per wave
+
+struct u8x4 { unsigned char v[4]; };
+struct bf16x4 { unsigned short v[4]; };
+__device__ __forceinline__ void ld4(const float *p, long long i, float o[4]) { const v4f q = *reinterpret_cast<const v4f *>(p + i); o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; }
+__device__ __forceinline__ void ld4(const bf16raw *p, long long i, float o[4])
+{
+    const uint2 q = *reinterpret_cast<const uint2 *>(p + i);
+    o[0] = __uint_as_float(q.x << 16); o[1] = __uint_as_float(q.x & 0xffff0000u); o[2] = __uint_as_float(q.y << 16); o[3] = __uint_as_float(q.y & 0xffff0000u);
+}
+__device__ __forceinline__ void ld4(const u8raw *p, long long i, float o[4])
+{
+    const unsigned int q = *reinterpret_cast<const unsigned int *>(p + i);
+    o[0] = (float)(q & 255u); o[1] = (float)((q >> 8) & 255u); o[2] = (float)((q >> 16) & 255u); o[3] = (float)(q >> 24);
+}
+
+template <int DIM, typename TIN>
+__device__ __forceinline__ void crop_fwd_wave_body(
+    const TIN *__restrict__ image, const float *__restrict__ boxes, const int *__restrict__ box_ind, int B, int H, int W, int D,
+    int ch, int cw, int cd, int C, float *__restrict__ crops)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *region_all = reinterpret_cast<float *>(smem_raw);                                   // [FW_WAVES][FW_REGION_FLOATS]
+    AxisEntry *tab = reinterpret_cast<AxisEntry *>(region_all + FW_WAVES * FW_REGION_FLOATS);   // [ch + cw + cd]
+    int *ext = reinterpret_cast<int *>(tab + (ch + cw + cd));                                   // ymin, ny, xmin, nx, zmin4, nz4
+
+    const int n = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.y * FW_WAVES + wave;
+    const int P = ch * cw * cd;
+    const int b_in = box_ind[n];
+    float *out = crops + ((long long)n * C + c) * P;
+    if (b_in < 0 || b_in >= B) {  // skipped RoI: reference leaves the zero-fill
+        if (c < C) for (int e = lane; e < P; e += 64) out[e] = 0.0f;
+        return;
+    }
+    const float *bx = boxes + (long long)n * (2 * DIM);
+    for (int t = threadIdx.x; t < ch + cw + cd; t += FW_THREADS) {
+        AxisEntry e;
+        if (t < ch) e = axis_entry(bx[0], bx[2], H, ch, t);
+        else if (t < ch + cw) e = axis_entry(bx[1], bx[3], W, cw, t - ch);
+        else if (DIM == 3) e = axis_entry(bx[4], bx[5], D, cd, t - ch - cw);
+        else { e.lo = 0; e.lerp = 0.0f; }
+        tab[t] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {        // extent of the touched voxel box per axis (a box may be inverted: min / max over the whole table)
+        const int a = threadIdx.x;
+        const int t0 = a == 0 ? 0 : (a == 1 ? ch : ch + cw), cnt = a == 0 ? ch : (a == 1 ? cw : cd);
+        int lo = 0x7fffffff, hi = -1;
+        for (int t = 0; t < cnt; ++t) { const AxisEntry e = tab[t0 + t]; lo = min(lo, e.lo); hi = max(hi, entry_hi(e)); }
+        if (a == 2) { const int lo4 = lo & ~3; ext[4] = lo4; ext[5] = (hi - lo4) / 4 + 1; }
+        else { ext[2 * a] = lo; ext[2 * a + 1] = hi - lo + 1; }
+    }
+    __syncthreads();
+    if (c >= C) return;
+    const int ymin = ext[0], ny = ext[1], xmin = ext[2], nx = ext[3], zmin4 = ext[4], nz4 = ext[5];
+    const int rowf = nz4 * 4;                     // floats per staged row
+    const long long vol = (long long)H * W * D;
+    const TIN *pimage = image + ((long long)b_in * C + c) * vol;
+    const bool staged = (D % 4 == 0) && ((long long)ny * nx * rowf <= FW_REGION_FLOATS);
+    float *reg = region_all + wave * FW_REGION_FLOATS;
+    if (staged) {
+        const int quads = ny * nx * nz4;
+        for (int q = lane; q < quads; q += 64) {
+            const int row = q / nz4, zq = q - row * nz4;
+            const int ry = row / nx, rx = row - ry * nx;
+            float v[4];
+            ld4(pimage, (long long)D * ((xmin + rx) + (long long)W * (ymin + ry)) + zmin4 + 4 * zq, v);
+            *reinterpret_cast<v4f *>(reg + q * 4) = v4f{v[0], v[1], v[2], v[3]};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // outputs of the pair, z fastest: lane-strided walk with a mixed-radix counter (no division per output)
+    const int s_z = 64 % cd, s_xq = 64 / cd;
+    const int s_x = s_xq % cw, s_y = s_xq / cw;
+    int z = lane % cd, t = lane / cd;
+    int x = t % cw, y = t / cw;
+    for (int e = lane; e < P; e += 64) {
+        const AxisEntry ey = tab[y];
+        const AxisEntry ex = tab[ch + x];
+        const int top = ey.lo, bottom = entry_hi(ey);
+        const int left = ex.lo, right = entry_hi(ex);
+        float res;
+        if (DIM == 3) {
+            const AxisEntry ez = tab[ch + cw + z];
+            const int front = ez.lo, back = entry_hi(ez);
+            float tlf, trf, blf, brf, tlb, trb, blb, brb;
+            if (staged) {
+                const int rt = (top - ymin) * nx, rb = (bottom - ymin) * nx, cl = left - xmin, cr = right - xmin;
+                const int f = front - zmin4, k = back - zmin4;
+                const float *a = reg + (rt + cl) * rowf, *bq = reg + (rt + cr) * rowf, *cq = reg + (rb + cl) * rowf, *d = reg + (rb + cr) * rowf;
+                tlf = a[f]; trf = bq[f]; blf = cq[f]; brf = d[f];
+                tlb = a[k]; trb = bq[k]; blb = cq[k]; brb = d[k];
+            } else {
+                const long long rt_l = (long long)D * (left + (long long)W * top), rt_r = (long long)D * (right + (long long)W * top);
+                const long long rb_l = (long long)D * (left + (long long)W * bottom), rb_r = (long long)D * (right + (long long)W * bottom);
+                tlf = ld(pimage, front + rt_l); trf = ld(pimage, front + rt_r); blf = ld(pimage, front + rb_l); brf = ld(pimage, front + rb_r);
+                tlb = ld(pimage, back + rt_l); trb = ld(pimage, back + rt_r); blb = ld(pimage, back + rb_l); brb = ld(pimage, back + rb_r);
+            }
+            const float top_front = tlf + (trf - tlf) * ex.lerp;
+            const float bottom_front = blf + (brf - blf) * ex.lerp;
+            const float top_back = tlb + (trb - tlb) * ex.lerp;
+            const float bottom_back = blb + (brb - blb) * ex.lerp;
+            const float frontv = top_front + (bottom_front - top_front) * ey.lerp;
+            const float backv = top_back + (bottom_back - top_back) * ey.lerp;
+            res = frontv + (backv - frontv) * ez.lerp;
+        } else {
+            const float tl = ld(pimage, (long long)top * W + left), tr = ld(pimage, (long long)top * W + right);
+            const float bl = ld(pimage, (long long)bottom * W + left), br = ld(pimage, (long long)bottom * W + right);
+            const float topv = tl + (tr - tl) * ex.lerp;
+            const float bottomv = bl + (br - bl) * ex.lerp;
+            res = topv + (bottomv - topv) * ey.lerp;
+        }
+        out[e] = res;
+        z += s_z; x += s_x; y += s_y;
+        if (z >= cd) { z -= cd; x += 1; }
+        if (x >= cw) { x -= cw; y += 1; }
+    }
+}
+
+template <int DIM, typename TIN>
+__global__ __launch_bounds__(FW_THREADS) void crop_fwd_wave_kernel(
+    const TIN *__restrict__ image, const float *__restrict__ boxes, const int *__restrict__ box_ind, int B, int H, int W, int D,
+    int ch, int cw, int cd, int C, float *__restrict__ crops)
+{
+    crop_fwd_wave_body<DIM, TIN>(image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, crops);
+}
+
+inline size_t fwd_wave_lds(int ch, int cw, int cd) { return (size_t)FW_WAVES * FW_REGION_FLOATS * sizeof(float) + (size_t)(ch + cw + cd) * sizeof(AxisEntry) + 8 * sizeof(int); }
+
+// MDT_FWD_KERNEL=direct selects the round-1 direct kernel (A/B)
+inline bool fwd_use_wave_kernel(int dim)
+{
+    static int mode = -1;
+    if (mode < 0) { const char *f = getenv("MDT_FWD_KERNEL"); mode = (f && f[0] == 'd') ? 0 : 1; }
+    return mode == 1 && dim == 3;
+}
+
 // All pyramid levels in one launch (mrcnn.py:373-457 pools every RoI on exactly one level and restores the order:
 // here the RoI's workgroups read their level's map directly and write the RoI's row, so the order never changes).
 constexpr int PYR_MAX_LEVELS = 5;
@@ -166,6 +320,18 @@ __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_pyramid_kernel(
     if (l < 0 || l >= maps.n_levels) { l = 0; b_limit = 0; }      // no level: the row is zero-filled like a skipped RoI
     crop_fwd_body<DIM, TIN>(reinterpret_cast<const TIN *>(maps.image[l]), boxes, box_ind, b_limit,
                             maps.H[l], maps.W[l], maps.D[l], ch, cw, cd, C, crops);
+}
+
+template <int DIM, typename TIN>
+__global__ __launch_bounds__(FW_THREADS) void crop_fwd_wave_pyramid_kernel(
+    PyramidMaps maps, const float *__restrict__ boxes, const int *__restrict__ box_ind, const int *__restrict__ level,
+    int B, int ch, int cw, int cd, int C, float *__restrict__ crops)
+{
+    int l = level[blockIdx.x];
+    int b_limit = B;
+    if (l < 0 || l >= maps.n_levels) { l = 0; b_limit = 0; }      // no level: the row is zero-filled like a skipped RoI
+    crop_fwd_wave_body<DIM, TIN>(reinterpret_cast<const TIN *>(maps.image[l]), boxes, box_ind, b_limit,
+                                 maps.H[l], maps.W[l], maps.D[l], ch, cw, cd, C, crops);
 }
 
 // ---------------------------------------------------------------------------
@@ -1094,6 +1260,13 @@ int launch_fwd(const TIN *image, const float *boxes, const int *box_ind, int N, 
             return check_launch();
         }
     }
+    if (fwd_use_wave_kernel(DIM) && (C + FW_WAVES - 1) / FW_WAVES <= 65535 && (long long)ch * cw * cd <= 0x3fffffff &&
+        (reinterpret_cast<uintptr_t>(image) & 15) == 0) {       // (its 4-element loads need the map 16-byte aligned)
+        (void)hipGetLastError();
+        hipLaunchKernelGGL((crop_fwd_wave_kernel<DIM, TIN>), dim3((unsigned)N, (unsigned)((C + FW_WAVES - 1) / FW_WAVES)), dim3(FW_THREADS),
+                           fwd_wave_lds(ch, cw, cd), s, image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, crops);
+        return check_launch();
+    }
     const long long slabs = (per_roi + FWD_SLAB - 1) / FWD_SLAB;
     if (slabs > 65535) return MDT_ERR_UNSUPPORTED;
     dim3 grid((unsigned)N, (unsigned)slabs);
@@ -1124,6 +1297,13 @@ int launch_fwd_pyramid(int n_levels, const void *const *images, const int *H, co
     const long long slabs = (per_roi + FWD_SLAB - 1) / FWD_SLAB;
     if (tab_bytes > 24 * 1024 || slabs > 65535) return MDT_ERR_UNSUPPORTED;
     (void)hipGetLastError();
+    bool aligned = true;
+    for (int l = 0; l < n_levels; ++l) aligned = aligned && (reinterpret_cast<uintptr_t>(images[l]) & 15) == 0;
+    if (fwd_use_wave_kernel(DIM) && aligned && (C + FW_WAVES - 1) / FW_WAVES <= 65535 && (long long)ch * cw * cd <= 0x3fffffff) {
+        hipLaunchKernelGGL((crop_fwd_wave_pyramid_kernel<DIM, TIN>), dim3((unsigned)N, (unsigned)((C + FW_WAVES - 1) / FW_WAVES)), dim3(FW_THREADS),
+                           fwd_wave_lds(ch, cw, cd), s, maps, boxes, box_ind, level, B, ch, cw, cd, C, crops);
+        return check_launch();
+    }
     hipLaunchKernelGGL((crop_fwd_pyramid_kernel<DIM, TIN>), dim3((unsigned)N, (unsigned)slabs), dim3(FWD_THREADS), tab_bytes, s,
                        maps, boxes, box_ind, level, B, ch, cw, cd, C, crops);
     return check_launch();

@@ -59,6 +59,8 @@ constexpr int V3_LDS_CAP = 80 * 1024;  // gfx950: 160 KB per CU -> two workgroup
 constexpr long long V3_MERGE_BYTES = 32 * 1024;   // volumes up to this size are zero-filled by their scatter workgroup
 constexpr int V3_LEV_BYTES = 512;      // head of the LDS carve: the level table (kernel arguments indexed dynamically would go through scratch)
 
+constexpr int V3_ZERO_CHUNK_ROWS = 0;     // default geometry of the zero role (see V3Level::chunk_rows); MDT_BWD3_ZERO_CHUNK_ROWS under MDT_BWD_TUNE
+
 struct V3Level {
     float *out;
     int H, W, D;                       // 2D: (H, 1, W)
@@ -68,6 +70,7 @@ struct V3Level {
     int bw;                            // u64 words of one batch element's territory bitmap
     int merged;                        // 1: no zero role, scatter workgroups zero-fill
     int zero_parts, rows_per_part;     // zero role geometry
+    int chunk_rows;                    // 0: a zero workgroup streams ONE contiguous run of rows_per_part rows; > 0: chunks of chunk_rows rows, dealt round-robin
     unsigned zero_base;                // first zero block of this level (relative to the first zero block of the launch)
 };
 
@@ -150,13 +153,25 @@ __device__ __forceinline__ void zero_role(const V3Params &p, const int li, const
 #pragma unroll
     for (int l = 1; l < V3_MAX_LEVELS; ++l) if (l == li) lv = p.lev[l];     // static indices: the table stays in scalar registers
     const long long total_rows = (long long)p.B * p.C * lv.R;
-    const long long g0 = (long long)zi * lv.rows_per_part;
-    long long g1 = g0 + lv.rows_per_part;
-    if (g1 > total_rows) g1 = total_rows;
-    if (g0 >= g1) return;
     const long long rows_per_elem = (long long)p.C * lv.R;
-    const int b_first = (int)(g0 / rows_per_elem);
-    const int b_last = (int)((g1 - 1) / rows_per_elem);
+    long long g0, g1, gstep, glen;
+    int b_first, b_last;
+    if (lv.chunk_rows > 0) {       // interleaved chunks: this workgroup's rows are spread over the whole map (all batch elements)
+        glen = lv.chunk_rows;
+        g0 = (long long)zi * glen;
+        gstep = (long long)lv.zero_parts * glen;
+        g1 = total_rows;
+        b_first = 0; b_last = p.B - 1;
+        if (g0 >= total_rows) return;
+    } else {
+        g0 = (long long)zi * lv.rows_per_part;
+        g1 = g0 + lv.rows_per_part;
+        if (g1 > total_rows) g1 = total_rows;
+        if (g0 >= g1) return;
+        glen = g1 - g0; gstep = total_rows;       // one run
+        b_first = (int)(g0 / rows_per_elem);
+        b_last = (int)((g1 - 1) / rows_per_elem);
+    }
     const int nb = b_last - b_first + 1;
     short *cand = reinterpret_cast<short *>(smem_raw + V3_LEV_BYTES);                               // [V3_MAXR][8]
     int *ncand = reinterpret_cast<int *>(smem_raw + V3_LEV_BYTES + V3_MAXR * 8 * sizeof(short));     // [1] (+ padding)
@@ -197,10 +212,11 @@ __device__ __forceinline__ void zero_role(const V3Params &p, const int li, const
     }
     __syncthreads();
     const v4f z4 = {0.f, 0.f, 0.f, 0.f};
-    for (long long g = g0; g < g1;) {
+    for (long long run0 = g0; run0 < g1; run0 += gstep)
+    for (long long g = run0, ge = min(g1, run0 + glen); g < ge;) {
         const int vol = (int)(g / lv.R);
         const int r0 = (int)(g - (long long)vol * lv.R);
-        const int r1 = (int)min((long long)lv.R, r0 + (g1 - g));
+        const int r1 = (int)min((long long)lv.R, r0 + (ge - g));
         const u64 *bmb = bm + (vol / p.C - b_first) * lv.bw;
         v4f *base = reinterpret_cast<v4f *>(lv.out + ((long long)vol * lv.R + r0) * lv.L);
         const int nu = (r1 - r0) * lv.upr;
@@ -789,7 +805,7 @@ int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *bo
         const long long nbits = (long long)lv.R * lv.nseg;
         lv.bw = (int)((nbits + 63) / 64);
         lv.merged = (vol_floats * 4 <= V3_MERGE_BYTES) ? 1 : 0;
-        lv.zero_parts = 0; lv.rows_per_part = lv.R; lv.zero_base = 0;
+        lv.zero_parts = 0; lv.rows_per_part = lv.R; lv.zero_base = 0; lv.chunk_rows = 0;
         if (!lv.merged) {
             if (nbits > 65536) return MDT_ERR_UNSUPPORTED;
             const size_t need = (size_t)V3_LEV_BYTES + (size_t)V3_MAXR * 8 * sizeof(short) + 16 + (size_t)B * lv.bw * sizeof(u64);
@@ -849,6 +865,8 @@ int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *bo
             if (z > total_rows) z = total_rows;
             lv.rows_per_part = (int)((total_rows + z - 1) / z);
             lv.zero_parts = (int)((total_rows + lv.rows_per_part - 1) / lv.rows_per_part);
+            const int cr = env_int("MDT_BWD3_ZERO_CHUNK_ROWS", V3_ZERO_CHUNK_ROWS);
+            if (cr > 0 && cr < lv.rows_per_part) lv.chunk_rows = cr;
             lv.zero_base = zrun;
             zrun += (unsigned)lv.zero_parts;
         }

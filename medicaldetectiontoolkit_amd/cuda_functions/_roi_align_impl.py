@@ -87,7 +87,7 @@ _SMALL_WS = {}
 
 def _workspace(nbytes, device):
     """the default kernel needs no workspace (the query answers 256 bytes): reuse one tiny buffer per device"""
-    if nbytes <= 256:
+    if nbytes <= 256 and not _lib.CAPTURING:
         ws = _SMALL_WS.get(device)
         if ws is None:
             ws = _SMALL_WS[device] = torch.empty(256, dtype=torch.uint8, device=device)

@@ -33,6 +33,7 @@ from . import backbone as backbone_module
 # Networks on top of backbone (state_dict-compatible with the reference)
 ############################################################
 HEAD_AS_LINEAR = True    # module switch (A/B: bench.py --head-as-linear 0): classifier-head convolutions as matrix products
+MERGE_RPN_HEADS = True   # module switch (A/B: bench.py --merge-rpn-heads 0): conv_class and conv_bbox of the RPN as ONE 1x1 convolution
 
 
 class RPN(nn.Module):
@@ -48,9 +49,23 @@ class RPN(nn.Module):
     def forward(self, x):
         x = self.conv_shared(x)
         axes = (0, 2, 3, 1) if self.dim == 2 else (0, 2, 3, 4, 1)
-        rpn_class_logits = self.conv_class(x).permute(*axes).contiguous().view(x.size(0), -1, 2)
+        if MERGE_RPN_HEADS and isinstance(self.conv_class, fused_epilogue.ConvBias) and isinstance(self.conv_bbox, fused_epilogue.ConvBias) \
+                and x.is_cuda and x.dtype == torch.float32:
+            # both heads are 1x1 convolutions of the SAME 128-channel map (mrcnn.py:70-77; 537 MB on P2 at 8 x 128^3): as two layers
+            # the map is read twice forward, twice for the weight gradients, and its gradient is produced twice (two 537 MB
+            # tensors + an add).  One convolution with the concatenated filters [2A + 2*dim*A, C] reads / writes it once each way;
+            # the parameters stay separate (state-dict keys unchanged), autograd splits the gradient of the concatenation.
+            nc = self.conv_class.out_channels
+            w = torch.cat([self.conv_class.weight, self.conv_bbox.weight], 0)
+            b = torch.cat([self.conv_class.bias, self.conv_bbox.bias], 0)
+            y = fused_epilogue.bias_act(fused_epilogue.conv_unit_stride(x, w, self.conv_class.padding), b)
+            y = y.permute(*axes)
+            rpn_class_logits = y[..., :nc].contiguous().view(x.size(0), -1, 2)
+            rpn_bbox = y[..., nc:].contiguous().view(x.size(0), -1, self.dim * 2)
+        else:
+            rpn_class_logits = self.conv_class(x).permute(*axes).contiguous().view(x.size(0), -1, 2)
+            rpn_bbox = self.conv_bbox(x).permute(*axes).contiguous().view(x.size(0), -1, self.dim * 2)
         rpn_probs = F.softmax(rpn_class_logits, dim=2)
-        rpn_bbox = self.conv_bbox(x).permute(*axes).contiguous().view(x.size(0), -1, self.dim * 2)
         return [rpn_class_logits, rpn_probs, rpn_bbox]
 
 
@@ -503,8 +518,8 @@ def get_results(cf, img_shape, detections, det_valid, detection_masks, box_resul
     for ix in range(img_shape[0]):
         sel = batch_ixs == ix
         d = det[sel]
-        final_masks = np.zeros(img_shape[2:])
-        if d.shape[0] > 0:
+        final_masks = None           # stays None unless masks are pasted: the all-zero volume is then made once, as uint8 (the reference
+        if d.shape[0] > 0:           # builds an fp64 volume per element and rounds / casts the stack: 35 ms per 8 x 128^3 step)
             boxes = d[:, :2 * dim].astype(np.int32)
             class_ids = d[:, 2 * dim + 1].astype(np.int32)
             scores = d[:, 2 * dim + 2]
@@ -531,7 +546,11 @@ def get_results(cf, img_shape, detections, det_valid, detection_masks, box_resul
                 box_results_list[ix].append({"box_coords": boxes[i2], "box_score": score, "box_type": "det",
                                              "box_pred_class_id": class_ids[i2]})
         seg_preds.append(final_masks)
-    return {"boxes": box_results_list, "seg_preds": np.round(np.array(seg_preds))[:, np.newaxis].astype("uint8")}
+    seg = np.zeros((img_shape[0], 1) + tuple(img_shape[2:]), dtype=np.uint8)
+    for ix, fm in enumerate(seg_preds):
+        if fm is not None:
+            seg[ix, 0] = np.round(fm).astype("uint8")
+    return {"boxes": box_results_list, "seg_preds": seg}
 
 
 ############################################################

@@ -1,6 +1,8 @@
 """Training step driver: the reference's exec.py:67-79 hot loop (forward, zero_grad, backward, Adam step),
 plus patch-level data parallelism -- one process per GPU, gradients averaged with a single flat-bucket
 all-reduce over RCCL (the whole model is 4.94 M fp32 parameters = 19.75 MB)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -414,7 +416,12 @@ class GraphedTrainStep(object):
 
     def capture(self, batch):
         """warm up and capture on `batch` (its shapes fix the static inputs); __call__ does this on its first call"""
+        import medicaldetectiontoolkit_amd as pkg
         from .cuda_functions import _roi_align_impl
+        if not pkg.GRAPH_RUNTIME_SAFE and not os.environ.get("MDT_ALLOW_UNSAFE_GRAPH"):
+            raise RuntimeError("GraphedTrainStep: the HIP runtime was initialised before DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 could be set (import "
+                               "medicaldetectiontoolkit_amd before the first CUDA call, or export the variable): with the runtime's graph packet "
+                               "capture on, replays of this step fault (see medicaldetectiontoolkit_amd/__init__.py); use training.train_step")
         if _roi_align_impl.PROFILE is not None:
             raise RuntimeError("GraphedTrainStep: switch the RoIAlign event profile off before the capture (events cannot be recorded inside a graph)")
         self._params = [p for p in self.net.parameters() if p.requires_grad]
@@ -434,9 +441,14 @@ class GraphedTrainStep(object):
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        from . import _lib
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._out, self._packed = self._body()
+        _lib.CAPTURING += 1              # cached device workspaces are bypassed: everything the graph touches lives in its own pool
+        try:
+            with torch.cuda.graph(self.graph):
+                self._out, self._packed = self._body()
+        finally:
+            _lib.CAPTURING -= 1
         self._grads = [p.grad for p in self._params]
         torch.cuda.synchronize()
 
@@ -445,9 +457,12 @@ class GraphedTrainStep(object):
         if self.graph is None:
             self.capture(batch)
         hm = self.host_ms
+        from .utils import model_utils as _mu
+        w0 = _mu.RING_WAIT_S[0]
         t0 = time.perf_counter()
         self._load(batch)
         t1 = time.perf_counter()
+        ring_wait = _mu.RING_WAIT_S[0] - w0
         self.graph.replay()
         t2 = time.perf_counter()
         if self.sync is None:
@@ -468,7 +483,8 @@ class GraphedTrainStep(object):
                 hm["readout_wait"] = hm.get("readout_wait", 0.0) + (t4 - t3) * 1e3
                 hm["readout_host"] = hm.get("readout_host", 0.0) + (time.perf_counter() - t4) * 1e3
         if hm is not None:
-            hm["load"] = hm.get("load", 0.0) + (t1 - t0) * 1e3
+            hm["load"] = hm.get("load", 0.0) + (t1 - t0 - ring_wait) * 1e3
+            hm["ring_wait_backpressure"] = hm.get("ring_wait_backpressure", 0.0) + ring_wait * 1e3
             hm["replay"] = hm.get("replay", 0.0) + (t2 - t1) * 1e3
             hm["collective_adam"] = hm.get("collective_adam", 0.0) + (t3 - t2) * 1e3
             hm["calls"] = hm.get("calls", 0) + 1

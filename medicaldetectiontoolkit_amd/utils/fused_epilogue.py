@@ -39,6 +39,8 @@ _WS = {}       # per-device workspace of the backward's partial sums, grown on d
 
 
 def _workspace(nbytes, device):
+    if _lib.CAPTURING:          # inside a hipGraph capture: a tensor of the graph's own pool (see _lib.CAPTURING)
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
     ws = _WS.get(device)
     if ws is None or ws.numel() < nbytes:
         ws = _WS[device] = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
@@ -425,6 +427,18 @@ def _conv(conv, x):
         return _ConvStem221.apply(x, conv.weight)
     fn = F.conv3d if isinstance(conv, nn.Conv3d) else F.conv2d
     return fn(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def conv_unit_stride(x, w, padding):
+    """unit-stride, size-preserving convolution of x with an explicit filter tensor (e.g. the concatenation of two layers' filters):
+    the same dispatch as `_conv` -- `_ConvStride1` (input gradient as a forward convolution, own weight-gradient kernels) when
+    gradients are wanted, a plain MIOpen forward otherwise"""
+    nd = w.dim() - 2
+    padding = tuple(int(p) for p in (padding if isinstance(padding, (tuple, list)) else (padding,) * nd))
+    if BWD_DATA_AS_FWD and x.is_cuda and x.dtype == torch.float32 and all(2 * p + 1 == int(k) for p, k in zip(padding, w.shape[2:])) \
+            and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return _ConvStride1.apply(x, w, padding)
+    return (F.conv3d if nd == 3 else F.conv2d)(x, w, None, 1, padding)
 
 
 class ConvBias(object):

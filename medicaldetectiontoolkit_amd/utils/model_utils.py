@@ -78,6 +78,9 @@ def _stage_pool():
     return _STAGE_POOL
 
 
+RING_WAIT_S = [0.0]      # wall time spent waiting for a ring slot's previous copy (back-pressure: the host is a ring-depth ahead of the GPU)
+
+
 class PinnedStager(object):
     """A ring of persistent pinned host buffers for ONE upload channel (the image of a batch, its GT masks, its seg map).
     torch's caching host allocator hands a block out again only once the copy that used it has EXECUTED; a host that runs a step
@@ -95,7 +98,11 @@ class PinnedStager(object):
         k = self.at
         self.at = (k + 1) % len(self.slots)
         if self.events[k] is not None:
-            self.events[k].synchronize()
+            if not self.events[k].query():
+                import time
+                t0 = time.perf_counter()
+                self.events[k].synchronize()
+                RING_WAIT_S[0] += time.perf_counter() - t0
             self.events[k] = None
         buf = self.slots[k]
         if buf is None or buf.numel() < nbytes:

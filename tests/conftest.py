@@ -1,6 +1,12 @@
 import os
 import sys
 
+# before anything initialises the HIP runtime (the `cuda` fixture's torch.cuda.is_available() does): the runtime flag hipGraph replays of
+# the training step need (see medicaldetectiontoolkit_amd/__init__.py); importing the package sets it, too -- this covers test modules
+# that touch torch.cuda first
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+os.environ.setdefault("MDT_PACKET_CAPTURE_SET_EARLY", "1")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -140,3 +140,31 @@ def test_bench_refuses_more_gpus_than_present(cuda):
     assert r.returncode != 0
     assert "requested but this node exposes" in r.stderr
     assert "n_gpus" not in r.stdout
+
+
+def test_bench_rank_code_path_world4_gloo(cuda):
+    """bench.py's OWN multi-rank path, end to end, without a multi-GPU node: `python bench.py --gpus 4 --backend gloo`
+    re-launches itself as 4 ranks under torch.distributed.run (they share the one GPU of the test box; gloo instead of RCCL), each rank
+    builds the net from the same seed, captures its graphed step over the flat gradient buffer, runs warm-up + 1 timed step on its own
+    patch stream with the bucket all-reduces + the Adam launch (averaging folded in) after the replay; rank 0 prints the ONE JSON line.
+    Required: n_gpus == world == 4, the graphed step was used, parameters bit-identical on all four ranks after the steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["MDT_MIOPEN_SKIP_NAIVE"] = "1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--patch", "64,64,32",
+           "--batch", "2", "--no-secondary", "--no-cpu-baseline", "--no-roofline", "--no-h2d-leg", "--no-exec-leg", "--no-eager-leg",
+           "--no-graph-preflight", "--no-rccl-selftest"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stderr[-1500:])
+    rec = json.loads(lines[-1])
+    assert rec["n_gpus"] == 4 and rec["distributed"]["world"] == 4 and rec["distributed"]["backend"] == "gloo"
+    assert rec["graph"]["used"] is True
+    assert rec["distributed"]["params_identical_across_ranks"] is True
+    assert rec["distributed"]["grad_buckets"] == 4 and len(rec["distributed"]["devices"]) == 4
+    assert rec["config"]["global_batch"] == 8 and rec["value"] > 0

@@ -43,8 +43,13 @@ def test_flat_adam_equals_torch_adam(wd, cuda):
     assert sa["param_groups"][0]["params"] == sb["param_groups"][0]["params"]
     for k in sa["state"]:
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 12.0
-        assert torch.allclose(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"], rtol=5e-5, atol=1e-9)
-        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=5e-5, atol=1e-12)
+        # the two nets' GRADIENTS agree only to the run-to-run noise of MIOpen's atomics-based weight-gradient solvers (one ulp of the
+        # largest terms): an entry of the running mean that nearly cancels sees that noise amplified, so the absolute bar scales with
+        # the tensor (1e-6 of its max), on top of the 5e-5 relative one
+        ea, eb = sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"]
+        assert torch.allclose(ea, eb, rtol=5e-5, atol=1e-6 * float(ea.abs().max()) + 1e-12), float((ea - eb).abs().max())
+        va, vb = sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]
+        assert torch.allclose(va, vb, rtol=5e-5, atol=1e-6 * float(va.abs().max()) + 1e-15), float((va - vb).abs().max())
 
 
 def test_flat_adam_state_dict_round_trip_and_adoption(cuda):

@@ -70,6 +70,9 @@ class _FakeEvent(object):
     def synchronize(self):
         _FakeEvent.waits += 1
 
+    def query(self):              # "not finished yet": the stager must wait (and account the wait as back-pressure)
+        return False
+
 
 def _patch_pinned(monkeypatch):
     import torch

@@ -1,0 +1,45 @@
+"""RoIAlign-3D forward at the reference's inference / training call sizes, event-timed through the Python boundary: the wave-staged
+kernel (round 4, default) against the direct kernel (MDT_FWD_KERNEL=direct, read once per process), fp32 and bf16 maps, bit-compared with
+each other.  One JSON line per case.  usage: [MDT_FWD_KERNEL=direct] python tools/fwd_bench.py"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
+from medicaldetectiontoolkit_amd.utils.synthetic_data import random_boxes_3d, trainlike_rois_3d
+
+dev = torch.device("cuda:0")
+kern = os.environ.get("MDT_FWD_KERNEL", "wave")
+rng = np.random.default_rng(0)
+B, C = 8, 36
+P2 = torch.randn((B, C, 32, 32, 128), device=dev)
+P3 = torch.randn((B, C, 16, 16, 64), device=dev)
+
+
+def time_op(fn, n=50):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    return float(np.mean(t)), float(t[len(t) // 2])
+
+
+cases = [("N240_14x14x5_P2_survey_boxes", P2, random_boxes_3d(rng, 240), rng.integers(0, B, 240), (14, 14, 5)),
+         ("N600_7x7x3_P2_survey_boxes", P2, random_boxes_3d(rng, 600), rng.integers(0, B, 600), (7, 7, 3)),
+         ("N4096_7x7x3_P2_survey_boxes", P2, random_boxes_3d(rng, 4096), rng.integers(0, B, 4096), (7, 7, 3)),
+         ("N48_14x14x5_P2_trainlike", P2, *trainlike_rois_3d(rng, B, 6, 8.0, 128.0), (14, 14, 5)),
+         ("N600_7x7x3_P3_survey_boxes", P3, random_boxes_3d(rng, 600), rng.integers(0, B, 600), (7, 7, 3))]
+for tag, img, boxes, ind, crop in cases:
+    bx, bi = torch.from_numpy(np.ascontiguousarray(boxes)).to(dev), torch.from_numpy(np.asarray(ind, dtype=np.int32)).to(dev)
+    for dt in ("f32", "bf16"):
+        im = img if dt == "f32" else img.bfloat16()
+        out = _roi_align_impl.crop_forward(im, bx, bi, crop)
+        mean, med = time_op(lambda: _roi_align_impl.crop_forward(im, bx, bi, crop))
+        byts = 4.0 * out.numel() + 28 * len(boxes)
+        print(json.dumps({"case": tag, "map": dt, "kernel": kern, "avg_us": round(mean, 2), "median_us": round(med, 2), "out_MB": round(4e-6 * out.numel(), 2),
+                          "GBps": round(byts / mean / 1e3, 1), "frac_of_8TBps": round(byts / (mean * 1e-6) / 8e12, 4),
+                          "checksum": float(out.double().sum())}), flush=True)
