@@ -9,8 +9,9 @@ patches (LIDC-shape config 3), one process per GPU, plus the RoIAlign-3D-backwar
 
 A "step" = exec.py:68-74 of the reference: net.train_forward(batch) [incl. H2D of the batch], zero_grad,
 backward, (gradient all-reduce over RCCL when N > 1), Adam step; per-GPU batch = 8 patches (weak scaling).
-Since round 4 the device half of the step is ONE hipGraph replay (training.GraphedTrainStep; `--graph 0` = the eager step, which
-is also timed as an A/B leg in every line: `eager_step`).  `exec_equivalent` is the step as exec.py consumes it: host numpy batches
+Since round 4 the device half of the step can run as ONE hipGraph replay (training.GraphedTrainStep, `--graph 1`); the default
+headline launches the step eagerly (faster by ~4 % at one rank on a fast host, see main()) and times the graphed step as the
+`graphed_step` leg of every line (with `--graph 1`: the other way round, `eager_step`).  `exec_equivalent` is the step as exec.py consumes it: host numpy batches
 (uploaded behind the previous step by training.DevicePrefetcher), the monitoring read-out (`logger_string`, `boxes`,
 `monitor_values`) taken every step, the mask head over the detections run like the reference does (mrcnn.py:1046-1048).
 Rank 0 prints ONE JSON line.  `roofline` is the dominant custom kernel (RoIAlign-3D backward on the P2 level):
@@ -296,26 +297,36 @@ def _self_launch(n):
     raise SystemExit(subprocess.call(cmd))
 
 
-def _graph_preflight(args, device_index, timeout_s=420):
-    """hipGraph capture of the whole step in a CHILD process first (build the net, capture, two replays, compare with nothing): a crash
-    inside the runtime's capture / instantiate code (seen once in round 4 with the per-element matching launches) then costs the graphed
-    headline, not the bench line -- the parent falls back to the eager step and says so."""
+def _graph_preflight(args, device_index, legs=False, timeout_s=600):
+    """hipGraph work in a CHILD process (see graph_preflight_main): `legs=False` -- capture + three replays, as the check that precedes a
+    graphed headline; `legs=True` -- the graphed A/B legs of an eager headline.  Returns (ok, note, legs dict or None)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--graph-preflight", "--patch", args.patch, "--batch", str(args.batch), "--gmax", str(args.gmax),
-           "--device-index", str(device_index), "--channels-last", str(args.channels_last)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph-preflight", "legs" if legs else "check", "--patch", args.patch, "--batch", str(args.batch),
+           "--gmax", str(args.gmax), "--steps", str(args.steps), "--device-index", str(device_index), "--channels-last", str(args.channels_last),
+           "--merge-rpn-heads", str(args.merge_rpn_heads)] + (["--no-exec-leg"] if args.no_exec_leg else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                           "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     t0 = time.time()
+    out = None
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
-        ok = r.returncode == 0 and "GRAPH_PREFLIGHT_OK" in r.stdout
+        ok = "GRAPH_PREFLIGHT_OK" in r.stdout and (r.returncode == 0 or not legs)
+        for line in r.stdout.splitlines():
+            if line.startswith("GRAPH_LEGS "):
+                out = json.loads(line[len("GRAPH_LEGS "):])
+        ok = ok and (out is not None or not legs)
         note = "ok (%.0f s)" % (time.time() - t0) if ok else "FAILED rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])
     except subprocess.TimeoutExpired:
         ok, note = False, "FAILED: timeout after %d s" % timeout_s
-    return ok, note
+    return ok, note, out
 
 
 def graph_preflight_main(args):
+    """child process (`--graph-preflight [legs]`): ALL hipGraph work of a `--graph 0` bench line happens here, the capture first thing in a
+    fresh process -- a capture AFTER eager training steps of the same net in one process segfaults in hipStreamEndCapture on this stack
+    (the AccumulateGrad nodes of the parameters were created on the default stream by the eager backward and pull it into the capture;
+    r04_final first try), and no runtime crash may ever cost the headline line.  Prints GRAPH_PREFLIGHT_OK and, with `legs`, one JSON line:
+    the graphed step's rate + host-work breakdown, hipGraphLaunch host time with the GPU idle, the exec-equivalent leg in graphed form."""
     from medicaldetectiontoolkit_amd import training
     from medicaldetectiontoolkit_amd.configs import Configs
     from medicaldetectiontoolkit_amd.models import mrcnn
@@ -326,17 +337,49 @@ def graph_preflight_main(args):
     torch.backends.cudnn.benchmark = True
     patch = [int(v) for v in args.patch.split(",")]
     cf = Configs(dim=3, model="mrcnn", patch_size=patch, batch_size=args.batch, channels_last=bool(args.channels_last))
+    mrcnn.MERGE_RPN_HEADS = bool(args.merge_rpn_heads)
     torch.manual_seed(0)
     net = mrcnn.net(cf, device=dev)
     opt = training.build_optimizer(net, cf, flat=True)
     step = training.GraphedTrainStep(net, opt, gmax=args.gmax)
-    b = to_device(make_batch(patch, args.batch, seed=7), dev)
-    for _ in range(2):
-        res = step(b)
+    pool = [to_device(make_batch(patch, args.batch, seed=1000 + i), dev) for i in range(3)]
+    for i in range(3):
+        res = step(pool[i % 3])
     torch.cuda.synchronize()
     if not np.isfinite(float(res["torch_loss"])):
         raise SystemExit("graph preflight: non-finite loss")
     print("GRAPH_PREFLIGHT_OK loss=%.4f" % float(res["torch_loss"]), flush=True)
+    if args.graph_preflight != "legs":
+        return
+    n = max(2, min(args.steps, 10))
+    step.host_ms = {}
+    t0 = time.time()
+    for i in range(n):
+        step(pool[i % 3])
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    hm, step.host_ms = step.host_ms, None
+    c = max(1, hm.pop("calls", 1))
+    hw = {k: round(v / c, 3) for k, v in hm.items()}
+    hw["work_total"] = round(sum(v for k, v in hw.items() if k != "ring_wait_backpressure"), 3)
+    idle = []
+    for i in range(3):               # hipGraphLaunch with the GPU idle: the host cost of a replay itself
+        torch.cuda.synchronize()
+        t1 = time.time()
+        step.graph.replay()
+        idle.append((time.time() - t1) * 1e3)
+    torch.cuda.synchronize()
+    rec = {"graphed_step": {"value": round(args.batch * n / dt, 3), "unit": "patches/s", "steps": n, "ms_per_step": round(dt / n * 1e3, 2),
+                            "host_ms_per_step": hw, "hipGraphLaunch_host_ms_gpu_idle": round(min(idle), 2),
+                            "note": "training.GraphedTrainStep in a child process (fresh net of the same seed, same batch generator): the device half of the step as "
+                                    "ONE hipGraph replay (+ Adam launch); `replay` in host_ms_per_step includes waiting for the previous replay of the same "
+                                    "graph (= the GPU), the idle figure is the launch itself"}}
+    if not args.no_exec_leg:
+        try:
+            rec["exec_equivalent_graphed"] = exec_equivalent_leg(net, opt, cf, patch, args, dev, True)
+        except Exception as e:
+            rec["exec_equivalent_graphed"] = {"failed": repr(e)[:300]}
+    print("GRAPH_LEGS " + json.dumps(rec), flush=True)
 
 
 def exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph):
@@ -489,10 +532,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the RoIAlign-backward roofline section (child runs of --secondary)")
     ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the world-size-1 RCCL self-test after the timed loop")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra host-batch steps after the timed loop (profiling runs)")
-    ap.add_argument("--graph", type=int, default=1, help="1 (default): the device half of the Mask R-CNN step is ONE hipGraph replay (training.GraphedTrainStep); 0: every kernel launched eagerly (A/B; also timed as `eager_step` in every line)")
+    ap.add_argument("--graph", type=int, default=0, help="0 (default): the headline steps are launched eagerly and the graphed step is timed as the `graphed_step` leg; 1: the headline steps are ONE hipGraph replay each (training.GraphedTrainStep) and the eager step is the `eager_step` leg")
+    ap.add_argument("--no-graph-leg", action="store_true", help="with --graph 0: skip the graphed A/B leg and the graphed exec_equivalent form")
     ap.add_argument("--gmax", type=int, default=8, help="GT objects per batch element the fixed-size GT table of the graphed step holds")
     ap.add_argument("--no-graph-preflight", action="store_true", help="skip the child-process capture check that precedes the graphed run")
-    ap.add_argument("--graph-preflight", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--graph-preflight", type=str, default="", help=argparse.SUPPRESS)
     ap.add_argument("--device-index", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-eager-leg", action="store_true", help="skip the eager A/B steps after the timed loop")
     ap.add_argument("--no-exec-leg", action="store_true", help="skip the exec.py-equivalent leg (host batches + monitoring read-out + mask head over detections)")
@@ -590,14 +634,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the step: ONE hipGraph replay for the device half (training.GraphedTrainStep) unless --graph 0 / Retina U-Net / a failed preflight
-    graph_rec = {"requested": bool(args.graph)}
+    # ---- the step.  Headline = the step launched eagerly (--graph 0, default) or as ONE hipGraph replay (--graph 1); the other form is
+    # timed as an A/B leg in the same process, so every line carries both.  Same-box pairs (profiles/r04/r04_ab_same_box.txt): eager
+    # 190.4 patches/s, graphed 182.5 -- at one rank on a fast host the eager step is already GPU-bound and the replay costs ~1 us of GPU
+    # time per graph node with the runtime's packet capture off (medicaldetectiontoolkit_amd/__init__.py); what the graph buys is the HOST:
+    # ~4.5 ms instead of 37-40 ms of host work per step.
+    graph_rec = {"headline": bool(args.graph)}
     use_graph = bool(args.graph) and args.model == "mrcnn"
     if use_graph and not args.no_graph_preflight:
-        ok, note = _graph_preflight(args, local_dev)      # a capture crash must kill a child, never the bench line
+        ok, note, _ = _graph_preflight(args, local_dev)      # a capture crash must kill a child, never the bench line
         graph_rec["preflight"] = note
         use_graph = ok
-    graph_rec["used"] = use_graph
+    graph_rec["used_for_headline"] = use_graph
+    # graphed headline: capture FIRST, before any eager step of this net (graph_preflight_main explains)
     gstep = training.GraphedTrainStep(net, opt, grad_sync=sync, gmax=args.gmax) if use_graph else None
 
     def run_step(b):
@@ -605,46 +654,57 @@ def main():
             return gstep(b)
         return training.train_step(net, opt, b, grad_sync=sync, monitor=False)
 
+    def host_work_of(g):
+        hm, g.host_ms = g.host_ms, None
+        c = max(1, hm.pop("calls", 1))
+        hw = {k: round(v / c, 3) for k, v in hm.items()}
+        hw["work_total"] = round(sum(v for k, v in hw.items() if k != "ring_wait_backpressure"), 3)
+        return hw
+
     for i in range(max(args.warmup, 1 if use_graph else 0)):
         run_step(pool[i % len(pool)])
     barrier()
+    prof = None
     if gstep is not None:
         gstep.host_ms = {}
+    else:
+        _roi_align_impl.PROFILE = []          # the RoIAlign backward launches of the timed steps, event-timed (roofline in-step variant)
     t0 = time.time()
     for i in range(args.steps):
         run_step(pool[i % len(pool)])
     host_issue = time.time() - t0      # the host has launched everything (it runs ahead of the GPU while the step is GPU-bound)
     barrier()
     elapsed = time.time() - t0
-    host_work = None
     if gstep is not None:
-        # host_issue includes BACK-PRESSURE (the pinned GT ring lets the host run at most 3 steps ahead of the GPU, then every step waits
-        # one GPU step): the host's own work per step is load + replay (hipGraphLaunch) + collective / Adam launch
-        hm, gstep.host_ms = gstep.host_ms, None
-        c = max(1, hm.pop("calls", 1))
-        host_work = {k: round(v / c, 3) for k, v in hm.items()}
-        host_work["work_total"] = round(sum(v for k, v in host_work.items() if k != "ring_wait_backpressure"), 3)
-        graph_rec["host_ms_per_step"] = host_work
+        # a replay blocks while the previous replay of the same graph is still executing (measured: 40 ms inside hipGraphLaunch with the
+        # GPU busy, 3.7-4.9 ms with the GPU idle): host_issue is therefore ~ the GPU time; the host's own WORK is in host_ms_per_step
+        graph_rec["host_ms_per_step"] = host_work_of(gstep)
+    else:
+        prof, _roi_align_impl.PROFILE = _roi_align_impl.PROFILE, None
 
-    # ---- A/B leg: the EAGER step (~1500 launches issued one by one), same net / optimizer / batches; its RoIAlign backward launches are
-    # event-timed for the roofline's in-step variant (events cannot be recorded inside a graph)
-    eager_rec, prof = None, None
-    if not args.no_eager_leg or not use_graph:
-        n_e = max(2, min(args.steps, 6))
-        for i in range(2 if use_graph else 0):
+    # ---- A/B leg: the other form of the step, same net / optimizer / batches, warmed up like the headline
+    eager_rec, graphed_rec = None, None
+    n_ab = max(2, min(args.steps, 8))
+    if use_graph and not args.no_eager_leg:
+        for i in range(3):
             training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
         barrier()
         _roi_align_impl.PROFILE = []
         te = time.time()
-        for i in range(n_e):
+        for i in range(n_ab):
             training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
         th_e = time.time() - te
         barrier()
         te = time.time() - te
         prof, _roi_align_impl.PROFILE = _roi_align_impl.PROFILE, None
-        eager_rec = {"value": round(args.batch * world * n_e / te, 3), "unit": "patches/s", "steps": n_e, "ms_per_step": round(te / n_e * 1e3, 2),
-                     "host_issue_ms_per_step": round(th_e / n_e * 1e3, 2),
-                     "note": "training.train_step: the same step with every kernel launched eagerly (the round-3 headline path)"}
+        eager_rec = {"value": round(args.batch * world * n_ab / te, 3), "unit": "patches/s", "steps": n_ab, "ms_per_step": round(te / n_ab * 1e3, 2),
+                     "host_issue_ms_per_step": round(th_e / n_ab * 1e3, 2),
+                     "note": "training.train_step: the same step with every kernel launched eagerly"}
+    child_legs = None
+    if not use_graph and args.model == "mrcnn" and not args.no_graph_leg and rank == 0 and world == 1:
+        ok, note, child_legs = _graph_preflight(args, local_dev, legs=True)      # all graph work of an eager line: in a child process
+        graph_rec["legs_child"] = note
+        graphed_rec = child_legs.get("graphed_step") if (ok and child_legs) else {"failed": note}
 
     # ---- the in-step RoIAlign backward with the RoI heads FULL: GT boxes derived from the net's own proposals (as
     # tests/golden/make_step_golden.py does), so that the target layer finds positives and all train_rois_per_image slots are valid
@@ -686,7 +746,15 @@ def main():
     exec_eq = None
     if world == 1 and args.model == "mrcnn" and not args.no_exec_leg:
         try:
-            exec_eq = exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph)
+            # both forms: with one read-out sync per step the eager host cannot run ahead of the GPU, the replay can
+            if use_graph:
+                g_eq = exec_equivalent_leg(net, opt, cf, patch, args, dev, True)
+                exec_eq = exec_equivalent_leg(net, opt, cf, patch, args, dev, False)
+            else:
+                exec_eq = exec_equivalent_leg(net, opt, cf, patch, args, dev, False)
+                g_eq = (child_legs or {}).get("exec_equivalent_graphed")
+            if g_eq and "value" in g_eq:
+                exec_eq = dict(g_eq, eager_form=exec_eq) if g_eq["value"] >= exec_eq["value"] else dict(exec_eq, graphed_form=g_eq)
         except Exception as e:
             exec_eq = {"failed": repr(e)[:300]}
 
@@ -727,7 +795,7 @@ def main():
                            "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),
                        "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over %s)" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "global_batch": args.batch * world},
-            "graph": graph_rec, "eager_step": eager_rec, "exec_equivalent": exec_eq,
+            "graph": graph_rec, "eager_step": eager_rec, "graphed_step": graphed_rec, "exec_equivalent": exec_eq,
             "roofline": roofline, "cpu_baseline": cpu, "h2d_inclusive": h2d, "distributed": dist_rec,
         }
         if world == 1 and not args.no_rccl_selftest:

@@ -70,7 +70,7 @@ struct V3Level {
     int bw;                            // u64 words of one batch element's territory bitmap
     int merged;                        // 1: no zero role, scatter workgroups zero-fill
     int zero_parts, rows_per_part;     // zero role geometry
-    int chunk_rows;                    // 0: a zero workgroup streams ONE contiguous run of rows_per_part rows; > 0: chunks of chunk_rows rows, dealt round-robin
+    int chunk_rows, chunk_shift, R_shift;   // chunk_rows 0: a zero workgroup streams ONE contiguous run of rows_per_part rows; > 0: chunks of chunk_rows rows, dealt round-robin
     unsigned zero_base;                // first zero block of this level (relative to the first zero block of the launch)
 };
 
@@ -212,6 +212,28 @@ __device__ __forceinline__ void zero_role(const V3Params &p, const int li, const
     }
     __syncthreads();
     const v4f z4 = {0.f, 0.f, 0.f, 0.f};
+    if (lv.chunk_rows > 0) {
+        // dense moving window (round 4): chunk k of chunk_rows rows goes to workgroup k mod zero_parts, so at any moment the zero
+        // workgroups together write ONE contiguous window of the map (zero_parts x chunk bytes), like a grid-stride fill -- the
+        // write-back stream that leaves the L2 is then sequential in DRAM.  (One long run per workgroup, the round-3 geometry, costs
+        // 50 us instead of 26 us when the map is not cache-resident: profiles/r04_bwd_roles_cold_warm.txt.)  All 32-bit, shifts only:
+        // R, units per row and segment units are powers of two and chunk_rows divides R (checked by the host).
+        const int n_chunks = (int)(total_rows >> lv.chunk_shift);
+        const int upc = lv.chunk_rows << lv.upr_shift;                      // 16-byte units per chunk
+        v4f *outv = reinterpret_cast<v4f *>(lv.out);
+        for (int ck = (int)zi; ck < n_chunks; ck += lv.zero_parts) {
+            const int grow = ck << lv.chunk_shift;                          // first row of the chunk (flattened over B * C volumes)
+            const int vol = grow >> lv.R_shift, r0 = grow & (lv.R - 1);
+            const u64 *bmb = bm + (vol / p.C) * lv.bw;
+            v4f *base = outv + ((long long)grow << lv.upr_shift);
+            for (int u = tid; u < upc; u += V3_NT) {
+                const int bit = (r0 + (u >> lv.upr_shift)) * lv.nseg + ((u & (lv.upr - 1)) >> lv.useg_shift);
+                if ((bmb[bit >> 6] >> (bit & 63)) & 1ULL) continue;
+                base[u] = z4;
+            }
+        }
+        return;
+    }
     for (long long run0 = g0; run0 < g1; run0 += gstep)
     for (long long g = run0, ge = min(g1, run0 + glen); g < ge;) {
         const int vol = (int)(g / lv.R);
@@ -805,7 +827,7 @@ int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *bo
         const long long nbits = (long long)lv.R * lv.nseg;
         lv.bw = (int)((nbits + 63) / 64);
         lv.merged = (vol_floats * 4 <= V3_MERGE_BYTES) ? 1 : 0;
-        lv.zero_parts = 0; lv.rows_per_part = lv.R; lv.zero_base = 0; lv.chunk_rows = 0;
+        lv.zero_parts = 0; lv.rows_per_part = lv.R; lv.zero_base = 0; lv.chunk_rows = 0; lv.chunk_shift = -1; lv.R_shift = -1;
         if (!lv.merged) {
             if (nbits > 65536) return MDT_ERR_UNSUPPORTED;
             const size_t need = (size_t)V3_LEV_BYTES + (size_t)V3_MAXR * 8 * sizeof(short) + 16 + (size_t)B * lv.bw * sizeof(u64);
@@ -866,7 +888,11 @@ int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *bo
             lv.rows_per_part = (int)((total_rows + z - 1) / z);
             lv.zero_parts = (int)((total_rows + lv.rows_per_part - 1) / lv.rows_per_part);
             const int cr = env_int("MDT_BWD3_ZERO_CHUNK_ROWS", V3_ZERO_CHUNK_ROWS);
-            if (cr > 0 && cr < lv.rows_per_part) lv.chunk_rows = cr;
+            lv.R_shift = ilog2_exact(lv.R);
+            lv.chunk_shift = ilog2_exact(cr);
+            if (cr > 0 && cr < lv.rows_per_part && lv.chunk_shift >= 0 && lv.R_shift >= 0 && lv.R % cr == 0 && lv.upr_shift >= 0 && lv.useg_shift >= 0 &&
+                total_rows < 0x7fffffffLL / lv.upr)
+                lv.chunk_rows = cr;
             lv.zero_base = zrun;
             zrun += (unsigned)lv.zero_parts;
         }

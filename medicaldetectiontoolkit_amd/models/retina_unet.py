@@ -189,6 +189,12 @@ class net(nn.Module):
     def train_forward(self, batch, monitor=True, **kwargs):
         """retina_unet.py:381-457."""
         cf, dev = self.cf, self.device_
+        ev = batch.get("ready_event")            # training.DevicePrefetcher uploaded the image on its side stream
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            if torch.is_tensor(batch.get("data")):
+                batch["data"].record_stream(cur)
         img = mutils.upload(batch["data"], dev).float()
         gt_class_ids, gt_boxes = batch["roi_labels"], batch["bb_target"]
         B = img.shape[0]

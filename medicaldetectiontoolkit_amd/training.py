@@ -425,6 +425,16 @@ class GraphedTrainStep(object):
         if _roi_align_impl.PROFILE is not None:
             raise RuntimeError("GraphedTrainStep: switch the RoIAlign event profile off before the capture (events cannot be recorded inside a graph)")
         self._params = [p for p in self.net.parameters() if p.requires_grad]
+        # ORDER MATTERS on this stack: capture BEFORE any eager backward of these parameters ran in the process (or after every autograd
+        # graph of such a step has died).  A parameter's AccumulateGrad node is created once, on the stream of its first backward, and
+        # lives as long as any autograd graph references it; an eager step leaves such graphs behind (the net keeps its last feature maps),
+        # the capture's backward then runs those nodes on the DEFAULT stream and hipStreamEndCapture segfaults (bench.py r04: eager steps,
+        # then capture).  Dropping the net's references to the last step makes the old nodes die in the common case:
+        import gc
+        for attr in ("mrcnn_feature_maps", "rpn_rois_batch_info", "batch_mrcnn_class_scores"):
+            if hasattr(self.net, attr):
+                setattr(self.net, attr, None)
+        gc.collect()
         if isinstance(self.opt, FlatAdam) and self.opt._flat is None:
             self.opt._build()            # re-homes the parameters: must happen before their addresses are baked into the graph
         if self.sync is not None:

@@ -246,8 +246,16 @@ class _ConvStride1(Function):
             mf = torch.contiguous_format if gy.is_contiguous() else (torch.channels_last_3d if nd == 3 else torch.channels_last)
             pad_t = tuple(int(k) - 1 - int(p) for k, p in zip(w.shape[2:], ctx.padding))
             wf = flip_transpose_filter(w, mf)
-            gx = conv3x3x3_small(gy if gy.is_contiguous(memory_format=torch.channels_last_3d) or nd != 3 else gy.contiguous(memory_format=torch.channels_last_3d), wf) \
-                if (nd == 3 and pad_t == (1, 1, 1)) else None
+            gx = None
+            if nd == 3 and pad_t == (1, 1, 1) and x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous():
+                # the few-channel MFMA kernel runs on channels-last activations only: ask it only when the forward saw a channels-last x
+                # (its gx then has x's layout), and convert gy only when the kernel WILL run -- an NCDHW gy of a 36-channel P2 layer is a
+                # 151 MB copy that used to be made and thrown away when the shape was not the kernel's
+                cin_t, cout_t = int(wf.shape[1]), int(wf.shape[0])
+                Bq, _, Yq, Xq, Zq = (int(v) for v in gy.shape)
+                if CONV3_SMALL and gy.is_cuda and gy.dtype == torch.float32 and Bq * Yq * Xq * Zq >= 65536 and _conv3_small_pays(cin_t, cout_t) \
+                        and _lib.lib().mdt_conv3x3x3_small_supported(Yq, Xq, Zq, cin_t, cout_t):
+                    gx = conv3x3x3_small(gy if gy.is_contiguous(memory_format=torch.channels_last_3d) else gy.contiguous(memory_format=torch.channels_last_3d), wf)
             if gx is None:
                 gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, 1, pad_t)
         if ctx.needs_input_grad[1]:

@@ -157,14 +157,14 @@ def test_bench_rank_code_path_world4_gloo(cuda):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--patch", "64,64,32",
-           "--batch", "2", "--no-secondary", "--no-cpu-baseline", "--no-roofline", "--no-h2d-leg", "--no-exec-leg", "--no-eager-leg",
+           "--batch", "2", "--graph", "1", "--no-secondary", "--no-cpu-baseline", "--no-roofline", "--no-h2d-leg", "--no-exec-leg", "--no-eager-leg",
            "--no-graph-preflight", "--no-rccl-selftest"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, (r.returncode, r.stderr[-1500:])
     rec = json.loads(lines[-1])
     assert rec["n_gpus"] == 4 and rec["distributed"]["world"] == 4 and rec["distributed"]["backend"] == "gloo"
-    assert rec["graph"]["used"] is True
+    assert rec["graph"]["used_for_headline"] is True
     assert rec["distributed"]["params_identical_across_ranks"] is True
     assert rec["distributed"]["grad_buckets"] == 4 and len(rec["distributed"]["devices"]) == 4
     assert rec["config"]["global_batch"] == 8 and rec["value"] > 0

@@ -1,6 +1,8 @@
 """GPU: the model call-site owners run end to end on the HIP kernels (training step and test_forward),
 losses are finite, every parameter the architecture uses receives a gradient, results follow the
 reference's results_dict format."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -291,3 +293,25 @@ def test_rpn_merged_heads_equal_separate_layers(channels_last, cuda):
     for n in res[0][1]:
         a, b = res[0][1][n], res[1][1][n]
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-7), (n, float((a - b).abs().max()))
+
+
+def test_train_py_exec_loop_graphed_then_resumed_eager(cuda, tmp_path):
+    """train.py = the stand-in for exec.py's training loop: batches through training.DevicePrefetcher, the monitoring read-out and log line
+    every batch, reference-format checkpoint per epoch.  Epoch 1 with the graphed step (--graph 1), then --resume for epoch 2 with the
+    eager step: both print one 'tr. batch' line per batch with the five loss terms, the second run resumes at epoch 2."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["MDT_MIOPEN_SKIP_NAIVE"] = "1"
+    base = [sys.executable, os.path.join(root, "train.py"), "--patch", "64,64,32", "--batch", "2", "--batches", "3", "--exp-dir", str(tmp_path)]
+    r1 = subprocess.run(base + ["--epochs", "1", "--graph", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-1500:]
+    lines = [l for l in r1.stdout.splitlines() if l.startswith("tr. batch")]
+    assert len(lines) == 3 and all("rpn_class" in l and "mrcnn_mask" in l for l in lines), r1.stdout[-800:]
+    assert os.path.exists(os.path.join(str(tmp_path), "fold_0", "last_checkpoint", "params.pth"))
+    r2 = subprocess.run(base + ["--epochs", "2", "--resume"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-1500:]
+    assert "resumed to checkpoint at epoch 2" in r2.stdout
+    lines = [l for l in r2.stdout.splitlines() if l.startswith("tr. batch")]
+    assert len(lines) == 3 and all("(ep. 2)" in l for l in lines), r2.stdout[-800:]

@@ -1,7 +1,9 @@
 """One case in a loop, for rocprofv3 --kernel-trace --stats.  Usage: profile_case.py <case> [iters]
 cases: bwd_fast | bwd_twophase | bwd_ordered | fwd | nms6000 | nms6000_keep75 | pmc_bwd
        | pyramid_bwd (all four levels in one launch, 48 RoIs routed 24/12/8/4)
-env: MDT_N, MDT_CROP, MDT_ROIS=random|trainlike, MDT_INVALID=1, MDT_LEVEL=P2..P5"""
+env: MDT_N, MDT_CROP, MDT_ROIS=random|trainlike, MDT_INVALID=1, MDT_LEVEL=P2..P5,
+     MDT_ROTATE=k (round 4: bwd_fast / pmc_bwd write k rotating output buffers -- 4 x 151 MB = 604 MB > the 256 MiB Infinity Cache -- instead of
+     a fresh allocation that the caching allocator hands back as the SAME block every launch, i.e. cache-warm)"""
 import os
 import sys
 
@@ -32,8 +34,20 @@ g = torch.randn((N, 36) + crop, device=dev)
 image = torch.randn(shape, device=dev)
 dets = nms_boxes(rng, 6000)
 ds = torch.from_numpy(dets[np.argsort(-dets[:, -1].astype(np.float64), kind="stable")]).to(dev)
+n_rot = int(os.environ.get("MDT_ROTATE", "0"))
+rot = [torch.empty(shape, device=dev) for _ in range(n_rot)]
+state = {"k": 0}
+
+
+def bwd_fast():
+    if n_rot:
+        state["k"] += 1
+        return _roi_align_impl.crop_backward(g, boxes, box_ind, shape, out=rot[state["k"] % n_rot])
+    return _roi_align_impl.crop_backward(g, boxes, box_ind, shape)
+
+
 fns = {
-    "bwd_fast": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape),
+    "bwd_fast": bwd_fast,
     "bwd_twophase": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="twophase"),
     "bwd_ordered": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="ordered"),
     "fwd": lambda: _roi_align_impl.crop_forward(image, boxes, box_ind, crop),
@@ -59,8 +73,8 @@ if case == "pyramid_bwd":
 if case == "pmc_bwd":
     # calibration dispatches (known byte count: plain 151 MB fill) followed by the op under test
     out = torch.empty(shape, device=dev)
-    for _ in range(iters):
-        out.zero_()
+    for i in range(iters):
+        (rot[i % n_rot] if n_rot else out).zero_()
     torch.cuda.synchronize()
     for _ in range(iters):
         fns["bwd_fast"]()
