@@ -89,7 +89,7 @@ struct V3Params {
     float inv_psum, inv_pd;            // 1 / psum, 1 / pd (division-free index math)
     int off_hdr, off_rbox, off_bb, off_misc;
     long long *ts;                     // tuning only (mdt_debug_bwd3): wall-clock stamps of scatter workgroup `dbg_wg`, or null
-    int dbg, dbg_wg;                   // tuning only: bit0 scatter role returns at once, bit1 zero role returns at once, bit3 zero role skips its box loads
+    int dbg, dbg_wg;                   // tuning only: bit0 scatter role returns at once, bit1 zero role returns at once, bit3 zero role skips its box loads, bit4 zero role stores non-temporally
     V3Level lev[V3_MAX_LEVELS];
 };
 
@@ -249,7 +249,8 @@ __device__ __forceinline__ void zero_role(const V3Params &p, const int li, const
             const int sg = (lv.useg_shift >= 0) ? (ui >> lv.useg_shift) : (ui / lv.useg);
             const int bit = (r0 + rl) * lv.nseg + sg;
             if ((bmb[bit >> 6] >> (bit & 63)) & 1ULL) continue;
-            base[u] = z4;
+            if (p.dbg & 16) __builtin_nontemporal_store(z4, &base[u]);     // (dbg bit 4, tuning only: streaming-store policy for the zero role)
+            else base[u] = z4;
         }
         g += r1 - r0;
     }
