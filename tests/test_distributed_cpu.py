@@ -3,6 +3,8 @@ no gradient on some rank, and the padded all_gather used by patch-sharded infere
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -255,3 +257,38 @@ def test_collect_raw_boxes_two_ranks_equals_reference(tmp_path):
     ok = ~np.isnan(want[:, 11])
     assert np.allclose(t[ok, 10:], want[ok, 10:], rtol=1e-12, atol=0)
     assert got["calls"] < 4 * 80 // 8 + 8          # rank 0 forwarded only its share of the 320 patches
+
+
+def test_flat_adam_rehomes_a_repointed_parameter_and_refuses_mixed_steps():
+    """(1) a parameter whose `.data` was re-pointed after the flat buffers were built (net.to(memory_format=...), .float(), a second
+    FlatAdam over the same net) must keep training -- step() notices the stale address and rebuilds, carrying the moments over;
+    (2) a loaded optimizer state whose per-parameter step counts differ is refused (FlatAdam keeps ONE counter)."""
+    torch.manual_seed(0)
+    net = Tiny()
+    ref = Tiny()
+    ref.load_state_dict(net.state_dict())
+    opt = _TorchMathFlatAdam(net.parameters(), lr=1e-2)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    x = torch.randn(5, 4)
+    for it in range(4):
+        for m, o in ((net, opt), (ref, ropt)):
+            loss = m(x, use_second=True)
+            o.zero_grad()
+            loss.backward()
+            o.step()
+        if it == 1:      # re-point every parameter: fresh storage, same values
+            for p in net.parameters():
+                p.data = p.data.clone()
+    for (n, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
+        if b.grad is not None:
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n          # kept training on the same trajectory
+    fparam = opt._flat[0]
+    assert all(p.data.untyped_storage().data_ptr() == fparam.untyped_storage().data_ptr() for p in net.parameters())
+    # (2) heterogeneous steps
+    sd = ropt.state_dict()
+    keys = sorted(sd["state"])
+    sd["state"][keys[0]]["step"] = torch.tensor(7.0)
+    opt2 = _TorchMathFlatAdam(ref.parameters(), lr=1e-2)
+    opt2.load_state_dict(sd)
+    with pytest.raises(ValueError, match="different step counts"):      # raised when the flat buffers adopt the loaded state
+        opt2.zero_grad()
