@@ -426,6 +426,10 @@ int mdt_upsample2x_yx_cl_backward(const float *grad_out, float *grad_in, long lo
 int mdt_conv3x3x3_small_supported(int Y, int X, int Z, int c_in, int c_out);
 int mdt_conv3x3x3_small_forward(const float *in, const float *w_tap_ci_co, float *out, int batch, int Y, int X, int Z,
                                 int c_in, int c_out, void *stream);
+/* the same with the layer's bias add and ReLU (model_utils.py:732-781: conv -> [norm] -> relu; norm = None in the LIDC configs) in the
+ * kernel's epilogue: out = act(conv(in) + bias), bias [c_out] or NULL, relu 0 / 1 -- no separate pass over the output */
+int mdt_conv3x3x3_small_forward_bias_act(const float *in, const float *w_tap_ci_co, const float *bias, int relu, float *out, int batch, int Y, int X, int Z,
+                                         int c_in, int c_out, void *stream);
 /* weight gradient of the same layer, dW[tap][ci][co] = sum_v in[v + tap - 1][ci] * grad_out[v][co] (what
  * aten.convolution_backward(..., output_mask = [0, 1, 0]) returns, in [27][c_in][c_out] order); workspace = one partial per
  * workgroup tile; deterministic */

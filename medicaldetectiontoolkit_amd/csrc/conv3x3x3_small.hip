@@ -32,6 +32,8 @@ struct C3Params {
     const float *in;                  // [B, Y, X, Z, Cin]
     const float *wt;                  // [27][Cin][Cout]
     float *out;                       // [B, Y, X, Z, Cout]
+    const float *bias;                // [Cout] or null: added in the epilogue (round 4)
+    int relu;                         // 1: max(., 0) in the epilogue
     int B, Y, X, Z, Cin, Cout;
     int xg;                           // x groups per row: ceil(X / 4)
     int row_floats;                   // (ZT + 2) * Cin
@@ -137,10 +139,21 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3x3_small_kernel(C3Params p)
             // C/D map of the 32x32 MFMA: column = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (voxel)
             if (i < p.Cout) {
                 float *o = p.out + ((((long long)b * p.Y + y) * p.X + x) * p.Z + z0) * p.Cout + i;
+                if (p.bias != nullptr || p.relu) {       // bias add + ReLU here instead of a separate pass over the output (epilogue.hip)
+                    const float bv = p.bias ? p.bias[i] : 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int vz = (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    o[(long long)vz * p.Cout] = acc[r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int vz = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                        float v = acc[r] + bv;
+                        if (p.relu) v = v > 0.0f ? v : 0.0f;
+                        o[(long long)vz * p.Cout] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int vz = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                        o[(long long)vz * p.Cout] = acc[r];
+                    }
                 }
             }
         }
@@ -313,10 +326,16 @@ int mdt_conv3x3x3_small_supported(int Y, int X, int Z, int c_in, int c_out)
 int mdt_conv3x3x3_small_forward(const float *in, const float *w_tap_ci_co, float *out, int batch, int Y, int X, int Z,
                                 int c_in, int c_out, void *stream)
 {
+    return mdt_conv3x3x3_small_forward_bias_act(in, w_tap_ci_co, nullptr, 0, out, batch, Y, X, Z, c_in, c_out, stream);
+}
+
+int mdt_conv3x3x3_small_forward_bias_act(const float *in, const float *w_tap_ci_co, const float *bias, int relu, float *out, int batch, int Y, int X, int Z,
+                                         int c_in, int c_out, void *stream)
+{
     if (!in || !w_tap_ci_co || !out || batch <= 0) return MDT_ERR_INVALID_ARGUMENT;
     if (!mdt_conv3x3x3_small_supported(Y, X, Z, c_in, c_out)) return MDT_ERR_UNSUPPORTED;
     C3Params p;
-    p.in = in; p.wt = w_tap_ci_co; p.out = out;
+    p.in = in; p.wt = w_tap_ci_co; p.out = out; p.bias = bias; p.relu = relu ? 1 : 0;
     p.B = batch; p.Y = Y; p.X = X; p.Z = Z; p.Cin = c_in; p.Cout = c_out;
     p.xg = (X + C3_XT - 1) / C3_XT;
     p.row_floats = (C3_ZT + 2) * c_in;

@@ -173,9 +173,10 @@ def _conv3_small_pays(cin, cout):
     return cin % 8 != 0 or cout % 8 != 0
 
 
-def conv3x3x3_small(x, w):
+def conv3x3x3_small(x, w, bias=None, relu=False):
     """3x3x3 / stride 1 / pad 1 convolution of a channels_last_3d fp32 activation with a few-channel filter (C_in even <= 32,
-    C_out <= 32, Z % 32 == 0) on the fp32-MFMA kernel of csrc/conv3x3x3_small.hip (MIOpen: 862 us for 18 -> 18 on 8 x 32x32x128).
+    C_out <= 32, Z % 32 == 0) on the fp32-MFMA kernel of csrc/conv3x3x3_small.hip (MIOpen: 862 us for 18 -> 18 on 8 x 32x32x128),
+    optionally with the bias add and the ReLU in the kernel's epilogue.
     w: [C_out, C_in, 3, 3, 3] in any memory format.  None when the shape is not of that form (the caller then asks MIOpen)."""
     if not (CONV3_SMALL and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 5
             and tuple(w.shape[2:]) == (3, 3, 3) and _on_current_device(x)):
@@ -189,7 +190,11 @@ def conv3x3x3_small(x, w):
         return None
     wt = w.permute(2, 3, 4, 1, 0).contiguous()                  # [27][C_in][C_out]
     y = torch.empty((B, cout, Y, X, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
-    rc = L.mdt_conv3x3x3_small_forward(x.data_ptr(), wt.data_ptr(), y.data_ptr(), B, Y, X, Z, cin, cout, _lib.raw_stream())
+    if bias is None and not relu:
+        rc = L.mdt_conv3x3x3_small_forward(x.data_ptr(), wt.data_ptr(), y.data_ptr(), B, Y, X, Z, cin, cout, _lib.raw_stream())
+    else:
+        rc = L.mdt_conv3x3x3_small_forward_bias_act(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, 1 if relu else 0,
+                                                    y.data_ptr(), B, Y, X, Z, cin, cout, _lib.raw_stream())
     if rc != 0:
         _lib.check(rc, "mdt_conv3x3x3_small_forward")
     return y
@@ -240,32 +245,95 @@ class _ConvStride1(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        nd = w.dim() - 2
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            mf = torch.contiguous_format if gy.is_contiguous() else (torch.channels_last_3d if nd == 3 else torch.channels_last)
-            pad_t = tuple(int(k) - 1 - int(p) for k, p in zip(w.shape[2:], ctx.padding))
-            wf = flip_transpose_filter(w, mf)
-            gx = None
-            if nd == 3 and pad_t == (1, 1, 1) and x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous():
-                # the few-channel MFMA kernel runs on channels-last activations only: ask it only when the forward saw a channels-last x
-                # (its gx then has x's layout), and convert gy only when the kernel WILL run -- an NCDHW gy of a 36-channel P2 layer is a
-                # 151 MB copy that used to be made and thrown away when the shape was not the kernel's
-                cin_t, cout_t = int(wf.shape[1]), int(wf.shape[0])
-                Bq, _, Yq, Xq, Zq = (int(v) for v in gy.shape)
-                if CONV3_SMALL and gy.is_cuda and gy.dtype == torch.float32 and Bq * Yq * Xq * Zq >= 65536 and _conv3_small_pays(cin_t, cout_t) \
-                        and _lib.lib().mdt_conv3x3x3_small_supported(Yq, Xq, Zq, cin_t, cout_t):
-                    gx = conv3x3x3_small(gy if gy.is_contiguous(memory_format=torch.channels_last_3d) else gy.contiguous(memory_format=torch.channels_last_3d), wf)
-            if gx is None:
-                gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, 1, pad_t)
-        if ctx.needs_input_grad[1]:
-            gw = conv1x1_weight_grad(gy, x, w) if WGRAD_1X1 else None
-            if gw is None and nd == 3 and tuple(ctx.padding) == (1, 1, 1):
-                gw = conv3x3x3_small_weight_grad(gy, x, w)
-            if gw is None:
-                gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1] * nd, list(ctx.padding), [1] * nd, False, [0] * nd, 1,
-                                                         [False, True, False])[1]
+        gx, gw = _stride1_grads(x, w, ctx.padding, gy, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gx, gw, None
+
+
+def _stride1_grads(x, w, padding, gy, need_x, need_w):
+    """input and weight gradient of a unit-stride, size-preserving convolution (shared by _ConvStride1 and _Conv3SmallBiasReLU): the input
+    gradient as a FORWARD convolution with the flipped / transposed filter, the weight gradient on this repo's kernels where they pay"""
+    nd = w.dim() - 2
+    gx = gw = None
+    if need_x:
+        mf = torch.contiguous_format if gy.is_contiguous() else (torch.channels_last_3d if nd == 3 else torch.channels_last)
+        pad_t = tuple(int(k) - 1 - int(p) for k, p in zip(w.shape[2:], padding))
+        wf = flip_transpose_filter(w, mf)
+        gx = None
+        if nd == 3 and pad_t == (1, 1, 1) and x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous():
+            # the few-channel MFMA kernel runs on channels-last activations only: ask it only when the forward saw a channels-last x
+            # (its gx then has x's layout), and convert gy only when the kernel WILL run -- an NCDHW gy of a 36-channel P2 layer is a
+            # 151 MB copy that used to be made and thrown away when the shape was not the kernel's (ADVICE r3)
+            cin_t, cout_t = int(wf.shape[1]), int(wf.shape[0])
+            Bq, _, Yq, Xq, Zq = (int(v) for v in gy.shape)
+            if CONV3_SMALL and gy.is_cuda and gy.dtype == torch.float32 and Bq * Yq * Xq * Zq >= 65536 and _conv3_small_pays(cin_t, cout_t) \
+                    and _lib.lib().mdt_conv3x3x3_small_supported(Yq, Xq, Zq, cin_t, cout_t):
+                gx = conv3x3x3_small(gy if gy.is_contiguous(memory_format=torch.channels_last_3d) else gy.contiguous(memory_format=torch.channels_last_3d), wf)
+        if gx is None:
+            gx = (F.conv3d if nd == 3 else F.conv2d)(gy, wf, None, 1, pad_t)
+    if need_w:
+        gw = conv1x1_weight_grad(gy, x, w) if WGRAD_1X1 else None
+        if gw is None and nd == 3 and tuple(padding) == (1, 1, 1):
+            gw = conv3x3x3_small_weight_grad(gy, x, w)
+        if gw is None:
+            gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1] * nd, list(padding), [1] * nd, False, [0] * nd, 1,
+                                                     [False, True, False])[1]
+    return gx, gw
+
+
+def _bias_act_bwd(gy, y, relu, mf):
+    """g = gy * (y > 0) (when relu) and the bias gradient (per-channel sum of g) in one pass (csrc/epilogue.hip), channels-last or contiguous"""
+    if not gy.is_contiguous(memory_format=mf):
+        gy = gy.contiguous(memory_format=mf)
+    L = _lib.lib()
+    n, C = gy.numel(), int(gy.shape[1])
+    inner = 1 if mf != torch.contiguous_format else int(gy.shape[2:].numel())
+    g = torch.empty_like(gy)
+    gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
+    wsb = (4096 * C * 4 + 256) if inner == 1 else L.mdt_bias_act_backward_workspace_bytes(n, C, inner)
+    ws = _workspace(wsb, gy.device)
+    rc = L.mdt_bias_act_backward(g.data_ptr(), gy.data_ptr(), y.data_ptr() if relu else None, gbias.data_ptr(), n, C, inner, 1 if relu else 0,
+                                 ws.data_ptr(), ws.numel(), _lib.raw_stream())
+    if rc != 0:
+        _lib.check(rc, "mdt_bias_act_backward")
+    return g, gbias
+
+
+CONV3_SMALL_EPILOGUE = True   # module switch: bias + ReLU of the few-channel 3x3x3 layers inside the convolution kernel
+
+
+def _conv3_small_fused_applies(conv, x):
+    """ConvBiasReLU layer that csrc/conv3x3x3_small.hip runs with its bias + ReLU epilogue: 3x3x3, unit stride, pad 1, few odd-sized channel
+    counts, channels-last fp32 activation of >= 65 536 voxels, in training (the fused Function owns the backward)"""
+    if not (ENABLED and BWD_DATA_AS_FWD and CONV3_SMALL and CONV3_SMALL_EPILOGUE and isinstance(conv, nn.Conv3d) and conv.bias is not None
+            and conv.groups == 1 and tuple(conv.kernel_size) == (3, 3, 3) and _unit(conv.stride) and _unit(conv.dilation)
+            and not isinstance(conv.padding, str) and tuple(int(p) for p in conv.padding) == (1, 1, 1)):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and _on_current_device(x) and torch.is_grad_enabled()
+            and (x.requires_grad or conv.weight.requires_grad) and not torch.is_autocast_enabled()
+            and x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous()):
+        return False
+    B, cin, Y, X, Z = (int(v) for v in x.shape)
+    cout = int(conv.out_channels)
+    return cin == int(conv.in_channels) and B * Y * X * Z >= 65536 and _conv3_small_pays(cin, cout) \
+        and bool(_lib.lib().mdt_conv3x3x3_small_supported(Y, X, Z, cin, cout))
+
+
+class _Conv3SmallBiasReLU(Function):
+    """relu(conv3x3x3(x) + bias) of a few-channel layer with the bias add and the ReLU in the convolution kernel's epilogue (no separate
+    pass over the output); backward = the fused ReLU-mask / bias-gradient pass + the gradients of `_ConvStride1`"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        y = conv3x3x3_small(x, w, bias.detach(), True)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        g, gbias = _bias_act_bwd(gy, y, True, torch.channels_last_3d)
+        gx, gw = _stride1_grads(x, w, (1, 1, 1), g, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw, gbias
 
 
 STEM_WGRAD = True   # module switch (A/B: bench.py --stem-wgrad 0)
@@ -472,6 +540,8 @@ class ConvBiasReLU(nn.Sequential):
         if residual is None and ENABLED and STEM_SPACE_TO_DEPTH and conv.bias is not None and isinstance(conv, nn.Conv3d) and conv.groups == 1 \
                 and _unit(conv.dilation) and not isinstance(conv.padding, str) and _is_stem221(conv, x) and stem_forward_supported(x, conv.weight):
             return _ConvStemBiasReLU.apply(x, conv.weight, conv.bias)
+        if residual is None and _conv3_small_fused_applies(conv, x):
+            return _Conv3SmallBiasReLU.apply(x, conv.weight, conv.bias)
         return bias_act(_conv(conv, x), conv.bias, residual, True)
 
 

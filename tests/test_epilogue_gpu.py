@@ -282,25 +282,60 @@ def test_conv3x3x3_small_vs_torch(case, cuda):
     assert torch.all(err <= 1e-5 * mag + 1e-12), float((err / mag).max())      # a NaN left anywhere (unwritten output) fails
 
 
+@pytest.mark.parametrize("epilogue", ["bias", "bias_relu", "relu"])
+def test_conv3x3x3_small_epilogue_vs_torch(epilogue, cuda):
+    """mdt_conv3x3x3_small_forward_bias_act == act(F.conv3d + bias) in fp64 to 1e-5 of the summed magnitudes; the sums are the plain
+    kernel's (bit-equal after undoing the epilogue is not asserted: the bias add rounds once more)"""
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    g = torch.Generator(device=cuda).manual_seed(77)
+    x = torch.randn((2, 18, 8, 9, 64), device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    w = torch.randn((18, 18, 3, 3, 3), device=cuda, generator=g) * 0.1
+    bias = torch.randn(18, device=cuda, generator=g) if epilogue != "relu" else None
+    relu = epilogue != "bias"
+    prev = fe.CONV3_SMALL
+    fe.CONV3_SMALL = True
+    try:
+        y = fe.conv3x3x3_small(x, w, bias, relu) if True else None
+        # (the Python helper's use-rule asks for >= 65 536 voxels: call below it through the C ABI directly)
+        if y is None:
+            from medicaldetectiontoolkit_amd import _lib
+            wt = w.permute(2, 3, 4, 1, 0).contiguous()
+            y = torch.full((2, 18, 8, 9, 64), float("nan"), device=cuda).contiguous(memory_format=torch.channels_last_3d)
+            rc = _lib.lib().mdt_conv3x3x3_small_forward_bias_act(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, 1 if relu else 0,
+                                                                 y.data_ptr(), 2, 8, 9, 64, 18, 18, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+    finally:
+        fe.CONV3_SMALL = prev
+    want = F.conv3d(x.double(), w.double(), bias.double() if bias is not None else None, 1, 1)
+    mag = F.conv3d(x.double().abs(), w.double().abs(), bias.double().abs() if bias is not None else None, 1, 1)
+    if relu:
+        want = torch.relu(want)
+    err = (y.double() - want).abs()
+    assert torch.all(err <= 1e-5 * mag + 1e-12), float((err / mag).max())
+
+
 def test_conv3x3x3_small_inside_autograd_matches_miopen(cuda):
-    """an 18 -> 18 ConvBiasReLU layer: forward, input gradient (the kernel with the flipped / transposed filter) and weight
-    gradient with the kernel on / off"""
+    """an 18 -> 18 ConvBiasReLU layer: forward, input gradient (the kernel with the flipped / transposed filter), weight and bias
+    gradient with the kernel on (bias + ReLU in its epilogue, round 4, or as a separate pass) / off"""
     from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
     from medicaldetectiontoolkit_amd.utils.model_utils import NDConvGenerator
     torch.manual_seed(5)
     layer = NDConvGenerator(3)(18, 18, ks=3, pad=1, relu="relu").to(cuda).to(memory_format=torch.channels_last_3d)
     x = torch.randn((2, 18, 16, 16, 128), device=cuda).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
     res = []
-    for flag in (True, False):
-        fe.CONV3_SMALL = flag
+    for flag, epi in ((True, True), (True, False), (False, False)):     # fused bias + ReLU epilogue / kernel + separate epilogue pass / MIOpen
+        fe.CONV3_SMALL, fe.CONV3_SMALL_EPILOGUE = flag, epi
         layer.zero_grad()
         x.grad = None
         y = layer(x)
+        assert (y.grad_fn.name() == "_Conv3SmallBiasReLUBackward") == (flag and epi), y.grad_fn.name()
         y.square().sum().backward()
-        res.append((y.detach().clone(), x.grad.clone(), layer[0].weight.grad.clone()))
-    fe.CONV3_SMALL = True
-    for a, b in zip(res[0], res[1]):
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), float((a - b).abs().max())
+        res.append((y.detach().clone(), x.grad.clone(), layer[0].weight.grad.clone(), layer[0].bias.grad.clone()))
+    fe.CONV3_SMALL = fe.CONV3_SMALL_EPILOGUE = True
+    assert torch.equal(res[0][0], res[1][0])            # same kernel, same sums: the epilogue only moves the bias add + ReLU
+    for other in (res[0], res[1]):
+        for a, b in zip(other, res[2]):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), float((a - b).abs().max())
 
 
 # ------------------------------------------------------------------ stem weight gradient (csrc/conv_stem_wgrad.hip)
