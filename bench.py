@@ -550,6 +550,7 @@ def main():
     ap.add_argument("--stem-fwd", type=int, default=1, help="1 (default): forward of the one-channel 7x7x7 stem on the fp32-MFMA kernel (csrc/conv_stem_fwd.hip); 0: MIOpen, space-to-depth form (A/B)")
     ap.add_argument("--conv3-small", type=int, default=1, help="1 (default): the few-channel 3x3x3 convolutions (18 -> 18 on the large maps) on the fp32-MFMA kernel (csrc/conv3x3x3_small.hip), forward and input gradient; 0: MIOpen (A/B)")
     ap.add_argument("--conv3-small-epilogue", type=int, default=int(os.environ.get("MDT_C3_EPILOGUE", "1")), help="1 (default): bias + ReLU of the few-channel 3x3x3 layers inside the convolution kernel's epilogue (utils/fused_epilogue._Conv3SmallBiasReLU); 0: separate epilogue pass (A/B)")
+    ap.add_argument("--res-tap", type=int, default=1, help="1 (default): identity ResBlocks produce their input gradient already added to the residual gradient (utils/fused_epilogue._Conv1x1ResTap, csrc/epilogue.hip); 0: conv backward + autograd's accumulation pass (A/B)")
     ap.add_argument("--head-as-linear", type=int, default=1, help="1 (default): the classifier head's full-extent / 1x1x1 convolutions as GEMMs (models/mrcnn.py Classifier); 0: MIOpen convolutions (A/B)")
     ap.add_argument("--merge-rpn-heads", type=int, default=1, help="1 (default): conv_class and conv_bbox of the RPN as one 1x1 convolution over the shared 128-channel map (models/mrcnn.py RPN); 0: two layers (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
@@ -604,6 +605,7 @@ def main():
     fused_epilogue.WGRAD_1X1 = bool(args.wgrad_1x1)
     fused_epilogue.UPSAMPLE_CL = bool(args.upsample_cl)
     fused_epilogue.CONV3_SMALL = bool(args.conv3_small)
+    fused_epilogue.RES_TAP = bool(args.res_tap)
     fused_epilogue.CONV3_SMALL_EPILOGUE = bool(args.conv3_small_epilogue)
     fused_epilogue.STEM_WGRAD = bool(args.stem_wgrad)
     fused_epilogue.STEM_FWD = bool(args.stem_fwd)

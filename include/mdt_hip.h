@@ -456,6 +456,14 @@ int mdt_conv_stem_forward_supported(int OY, int OX, int OZ, int c_out, int k, in
 int mdt_conv_stem_forward(const float *x_padded, const float *weight, const float *bias, float *out, int batch, int OY, int OX, int OZ,
                           int c_out, int k, int sy, int sx, int YP, int XP, int ZP, int relu, void *stream);
 
+/* ---- input gradient of a 1x1(x1) convolution added to another gradient of the same tensor (csrc/epilogue.hip, round 4) ------------------
+ * out[v][ci] = res[v][ci] + sum_co gy[v][co] * w[co][ci] over n_voxels channels-last rows (res may be NULL: plain input gradient).
+ * What autograd does in two steps for a ResBlock input (models/backbone.py:197-205: x feeds conv1 and the residual add): the
+ * convolution's backward-data (cuDNN in the reference) and the accumulation of the two gradients.  w = the layer's weight [c_out, c_in]
+ * (1x1x1 kernel squeezed); c_out even, c_in % 4 == 0, c_out * c_in <= 12288 (`..._supported`).  fp32, fixed summation order. */
+int mdt_conv1x1_dgrad_add_supported(int c_out, int c_in);
+int mdt_conv1x1_dgrad_add(const float *gy, const float *w, const float *res, float *out, long long n_voxels, int c_out, int c_in, void *stream);
+
 /* ---- Adam over flat fp32 buffers (csrc/adam.hip) ------------------------------------------------------------------------------
  * One step of torch.optim.Adam (exec.py:39: Adam(lr = cf.learning_rate[0], weight_decay = cf.weight_decay); no amsgrad) for n
  * parameters whose values, gradients and moment estimates are four flat arrays: step >= 1 is the number of this update (bias

@@ -209,6 +209,104 @@ __global__ __launch_bounds__(EP_THREADS) void bias_grad_finish_kernel(float *__r
     if (threadIdx.x == 0) gbias[c] = s_acc[0];
 }
 
+// ---- input gradient of a 1x1(x1) convolution, ADDED to another gradient of the same tensor (round 4) -----------------------------
+//   out[v][ci] = res[v][ci] + sum_co gy[v][co] * w[co][ci]          channels-last rows, co ascending (deterministic)
+// A ResBlock input x feeds conv1 (1x1x1) AND the residual add (models/backbone.py:197-205): autograd computes conv1's input gradient
+// (a 302 MB tensor on the C2 maps) and then adds it to the residual path's gradient in a separate pass (read 2 x 302 MB, write 302 MB:
+// 150 us, four times per step).  Here the input gradient is produced already added to the other gradient: one pass that reads gy
+// (75 MB), the residual gradient (302 MB) and writes the sum (302 MB).  HBM-bound (K = 18 / 36 MACs per output on the VALU), no MFMA.
+// Thread = (voxel of the block's group, 4 consecutive input channels); w lives in LDS, a voxel's gy row is read by its threads as float2.
+__global__ __launch_bounds__(EP_THREADS) void conv1x1_dgrad_add_kernel(float *__restrict__ out, const float *__restrict__ gy, const float *__restrict__ w,
+                                                                       const float *__restrict__ res, long long V, int cout, int cin, int vb, long long groups_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_w[];      // [cout][cin]
+    for (int t = threadIdx.x; t < cout * cin; t += EP_THREADS) s_w[t] = w[t];
+    __syncthreads();
+    const int Q = cin >> 2;
+    const int t = threadIdx.x;
+    if (t >= vb * Q) return;
+    const int vl = t / Q, q = t - vl * Q;
+    const long long g0 = (long long)blockIdx.x * groups_per_block;
+    for (long long gi = g0; gi < g0 + groups_per_block; ++gi) {
+        const long long v = gi * vb + vl;
+        if (v >= V) return;
+        v4f acc = res ? *reinterpret_cast<const v4f *>(res + v * cin + 4 * q) : v4f{0.f, 0.f, 0.f, 0.f};
+        const float2 *grow = reinterpret_cast<const float2 *>(gy + v * cout);
+        for (int c2 = 0; c2 < (cout >> 1); ++c2) {
+            const float2 gv = grow[c2];
+            const v4f w0 = *reinterpret_cast<const v4f *>(s_w + (2 * c2) * cin + 4 * q);
+            const v4f w1 = *reinterpret_cast<const v4f *>(s_w + (2 * c2 + 1) * cin + 4 * q);
+            acc.x = acc.x + gv.x * w0.x; acc.y = acc.y + gv.x * w0.y; acc.z = acc.z + gv.x * w0.z; acc.w = acc.w + gv.x * w0.w;
+            acc.x = acc.x + gv.y * w1.x; acc.y = acc.y + gv.y * w1.y; acc.z = acc.z + gv.y * w1.z; acc.w = acc.w + gv.y * w1.w;
+        }
+        *reinterpret_cast<v4f *>(out + v * cin + 4 * q) = acc;
+    }
+}
+
+// The same product on the matrix cores (the VALU form above is issue-bound: 249 us for the 18 -> 72 layer on the C2 maps, 2.7 TB/s):
+// a wave owns tiles of 32 voxels; A = the tile's gy rows (32 x c_out, one contiguous 32 * c_out * 4 byte run, staged through the wave's
+// LDS slot with 16-byte loads), B = the weight, kept in registers for the wave's lifetime (KS K-steps x NT column tiles), C = the residual
+// gradient, loaded straight into the accumulator layout of v_mfma_f32_32x32x2_f32 (column = lane & 31 = channel, 16 rows per lane: every
+// wave-level load / store is two 128-byte row segments), D = the sum, stored the same way.  fp32 MFMA: exact products, fixed order.
+template <int KS, int NT>
+__global__ __launch_bounds__(256) void conv1x1_dgrad_add_mfma_kernel(float *__restrict__ out, const float *__restrict__ gy, const float *__restrict__ w,
+                                                                     const float *__restrict__ res, long long V, int cin)
+{
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    constexpr int COUT = 2 * KS;
+    constexpr int ASTR = COUT + 1;                         // odd row stride: the 32 rows of a fragment read hit 32 different banks
+    __shared__ float s_a[4][32 * ASTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    float bfrag[KS][NT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ci = nt * 32 + col;
+            bfrag[ks][nt] = ci < cin ? w[(long long)(2 * ks + half) * cin + ci] : 0.0f;
+        }
+    const long long tiles = (V + 31) / 32;
+    float *sa = s_a[wave];
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < tiles; tile += (long long)gridDim.x * 4) {
+        const long long v0 = tile * 32;
+        const int nv = (int)min((long long)32, V - v0);
+        // A: the tile's gy rows, contiguous in memory -> LDS (row stride ASTR)
+        for (int e = lane; e < nv * COUT; e += 64) {
+            const int m = e / COUT, k = e - m * COUT;
+            sa[m * ASTR + k] = gy[v0 * COUT + e];
+        }
+        for (int e = nv * COUT + lane; e < 32 * COUT; e += 64) { const int m = e / COUT, k = e - m * COUT; sa[m * ASTR + k] = 0.0f; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float afrag[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) afrag[ks] = sa[col * ASTR + 2 * ks + half];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ci = nt * 32 + col;
+            v16f acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                acc[r] = (res != nullptr && ci < cin && row < nv) ? res[(v0 + row) * cin + ci] : 0.0f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[ks], bfrag[ks][nt], acc, 0, 0, 0);
+            if (ci < cin) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < nv) out[(v0 + row) * cin + ci] = acc[r];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();       // the slot is rewritten by the next tile
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -297,6 +395,41 @@ int mdt_bias_act_backward(float *gx, const float *gy, const float *y, float *gbi
     // partial[(n * C + c) * chunks + k]: channel stride chunks, chunk stride 1, batch groups stride C * chunks
     hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(fin_blocks), dim3(EP_THREADS), 0, s, gbias, partial, channels, chunks, chunks, 1LL,
                        rows / channels, (long long)channels * chunks);
+    return ep_check();
+}
+
+int mdt_conv1x1_dgrad_add_supported(int c_out, int c_in)
+{
+    return (c_out >= 2 && (c_out & 1) == 0 && c_in >= 4 && (c_in & 3) == 0 && c_in / 4 <= EP_THREADS && (long long)c_out * c_in <= 12288) ? 1 : 0;
+}
+
+int mdt_conv1x1_dgrad_add(const float *gy, const float *w, const float *res, float *out, long long n_voxels, int c_out, int c_in, void *stream)
+{
+    if (!gy || !w || !out || n_voxels < 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (!mdt_conv1x1_dgrad_add_supported(c_out, c_in)) return MDT_ERR_UNSUPPORTED;
+    if (n_voxels == 0) return MDT_OK;
+    if (((((uintptr_t)gy) & 7) | (((uintptr_t)out) & 15) | (((uintptr_t)res) & 15)) != 0) return MDT_ERR_UNSUPPORTED;
+    // the two layer shapes of the LIDC backbone whose maps are large (C2: 18 -> 72 wide, C3: 36 -> 144): matrix cores; MDT_DGRAD_ADD=valu: A/B
+    static int use_mfma = -1;
+    if (use_mfma < 0) { const char *f = getenv("MDT_DGRAD_ADD"); use_mfma = (f && f[0] == 'v') ? 0 : 1; }
+    if (use_mfma && ((c_out == 18 && c_in == 72) || (c_out == 36 && c_in == 144))) {
+        const long long tiles = (n_voxels + 31) / 32;
+        long long blocks = (tiles + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        (void)hipGetLastError();
+        if (c_out == 18) hipLaunchKernelGGL((conv1x1_dgrad_add_mfma_kernel<9, 3>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, gy, w, res, n_voxels, c_in);
+        else hipLaunchKernelGGL((conv1x1_dgrad_add_mfma_kernel<18, 5>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, gy, w, res, n_voxels, c_in);
+        return ep_check();
+    }
+    const int Q = c_in / 4;
+    const int vb = EP_THREADS / Q;                                   // voxels per block and pass
+    const long long groups = (n_voxels + vb - 1) / vb;
+    long long blocks = groups < 8192 ? groups : 8192;
+    const long long gpb = (groups + blocks - 1) / blocks;
+    blocks = (groups + gpb - 1) / gpb;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(conv1x1_dgrad_add_kernel, dim3((unsigned)blocks), dim3(EP_THREADS), (size_t)c_out * c_in * sizeof(float), static_cast<hipStream_t>(stream),
+                       out, gy, w, res, n_voxels, c_out, c_in, vb, gpb);
     return ep_check();
 }
 

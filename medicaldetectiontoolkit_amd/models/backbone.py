@@ -31,8 +31,14 @@ class ResBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        residual = x if self.downsample is None else self.downsample(x)
-        out = self.conv2(self.conv1(x))
+        if self.downsample is None and fused_epilogue.res_tap_applies(self.conv1, x):
+            # identity block: x feeds conv1 AND the residual add -- one autograd node owns both paths, so that its backward produces
+            # the input gradient already added to the residual gradient (utils/fused_epilogue._Conv1x1ResTap)
+            h, residual = fused_epilogue.conv_bias_relu_with_res_tap(self.conv1, x)
+            out = self.conv2(h)
+        else:
+            residual = x if self.downsample is None else self.downsample(x)
+            out = self.conv2(self.conv1(x))
         if isinstance(self.conv3, ConvBias) and isinstance(self.relu, nn.ReLU):
             # bias + residual + ReLU of backbone.py:203-205 in one pass
             return self.conv3(out, residual=residual, relu=True)

@@ -517,6 +517,83 @@ def conv_unit_stride(x, w, padding):
     return (F.conv3d if nd == 3 else F.conv2d)(x, w, None, 1, padding)
 
 
+RES_TAP = True   # module switch (A/B: bench.py --res-tap 0)
+
+
+def conv1x1_dgrad_add(gy, w, res):
+    """res + (input gradient of the 1x1(x1) convolution with weight w for the output gradient gy) in ONE pass over channels-last fp32 rows
+    (csrc/epilogue.hip conv1x1_dgrad_add_kernel).  None when the shapes / layouts are not the kernel's (the caller then uses torch ops)."""
+    nd = gy.dim() - 2
+    mf = torch.channels_last_3d if nd == 3 else torch.channels_last if nd == 2 else None
+    if mf is None or not (gy.is_cuda and gy.dtype == torch.float32 and res.dtype == torch.float32 and _on_current_device(gy)):
+        return None
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    L = _lib.lib()
+    if not L.mdt_conv1x1_dgrad_add_supported(cout, cin) or not gy.is_contiguous(memory_format=mf) or not res.is_contiguous(memory_format=mf):
+        return None
+    out = torch.empty_like(res)
+    wc = w.detach().reshape(cout, cin).contiguous()
+    rc = L.mdt_conv1x1_dgrad_add(gy.data_ptr(), wc.data_ptr(), res.data_ptr(), out.data_ptr(), gy.numel() // cout, cout, cin, _lib.raw_stream())
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        _lib.check(rc, "mdt_conv1x1_dgrad_add")
+    return out
+
+
+class _Conv1x1ResTap(Function):
+    """h = conv1x1(x, w) AND an alias of x for the residual path of a ResBlock (models/backbone.py:197-205: x feeds conv1 and the residual
+    add).  As two consumers of x, autograd produces conv1's input gradient and the residual gradient as two 302 MB tensors (C2 maps) and
+    adds them in a third pass; owning both paths, this node's backward computes  gx = g_residual + W^T g_h  in one pass
+    (mdt_conv1x1_dgrad_add).  The alias is returned as-is (autograd wraps it as a view whose gradient arrives here)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        nd = w.dim() - 2
+        return (F.conv3d if nd == 3 else F.conv2d)(x, w), x
+
+    @staticmethod
+    def backward(ctx, gh, gres):
+        x, w = ctx.saved_tensors
+        nd = w.dim() - 2
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if gres is not None and gh is not None:
+                gx = conv1x1_dgrad_add(gh, w, gres)
+            if gx is None:
+                if gh is not None:
+                    gx = _stride1_grads(x, w, (0,) * nd, gh, True, False)[0]
+                    if gres is not None:
+                        gx = gx + gres
+                else:
+                    gx = gres
+        gw = _stride1_grads(x, w, (0,) * nd, gh, False, True)[1] if (ctx.needs_input_grad[1] and gh is not None) else None
+        return gx, gw
+
+
+def res_tap_applies(seq, x):
+    """ConvBiasReLU 1x1(x1) unit-stride layer on a large channels-last fp32 activation that needs a gradient: the ResBlock input tap"""
+    if not (ENABLED and BWD_DATA_AS_FWD and RES_TAP and isinstance(seq, ConvBiasReLU)):
+        return False
+    conv = seq[0]
+    if not (conv.bias is not None and conv.groups == 1 and all(int(k) == 1 for k in conv.kernel_size) and _unit(conv.stride) and _unit(conv.dilation)
+            and not isinstance(conv.padding, str) and not any(int(p) for p in conv.padding)):
+        return False
+    mf = torch.channels_last_3d if x.dim() == 5 else torch.channels_last if x.dim() == 4 else None
+    if mf is None or not (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad and not torch.is_autocast_enabled()
+                          and x.is_contiguous(memory_format=mf) and not x.is_contiguous() and _on_current_device(x)):
+        return False
+    return x.numel() >= (1 << 22) and bool(_lib.lib().mdt_conv1x1_dgrad_add_supported(int(conv.out_channels), int(conv.in_channels)))
+
+
+def conv_bias_relu_with_res_tap(seq, x):
+    """(relu(conv1(x) + bias), alias of x for the residual add) through _Conv1x1ResTap"""
+    conv = seq[0]
+    h, x_res = _Conv1x1ResTap.apply(x, conv.weight)
+    return bias_act(h, conv.bias, None, True), x_res
+
+
 class ConvBias(object):
     """mixin for the bare-conv form (relu=None in the reference's generator): forward(x, residual=None, relu=False)"""
 

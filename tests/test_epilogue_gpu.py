@@ -494,3 +494,54 @@ def test_conv3x3x3_small_wgrad_vs_aten(case, cuda):
                                               [0, 0, 0], 1, [False, True, False])[1]
     err = (outs[0].double() - want).abs()
     assert torch.all(err <= 1e-5 * mag + 1e-12), float((err / mag).max())
+
+
+# ------------------------------------------------------------------ residual tap: 1x1 input gradient added to the residual gradient (round 4)
+@pytest.mark.parametrize("case", [(18, 72, (2, 8, 8, 64)), (36, 144, (1, 5, 7, 9)), (2, 4, (1, 3, 1, 5)), (72, 168, (1, 4, 4, 4))], ids=lambda c: str(c))
+def test_conv1x1_dgrad_add_vs_fp64(case, cuda):
+    """mdt_conv1x1_dgrad_add: out = res + gy @ W over channels-last rows == the fp64 product to 1e-6 of the summed magnitudes; deterministic;
+    every element of the output written"""
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    cout, cin, sp = case
+    g = torch.Generator(device=cuda).manual_seed(cout * 7 + cin)
+    gy = torch.randn((sp[0], cout) + sp[1:], device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    res = torch.randn((sp[0], cin) + sp[1:], device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    w = torch.randn((cout, cin, 1, 1, 1), device=cuda, generator=g)
+    got = fe.conv1x1_dgrad_add(gy, w, res)
+    assert got is not None and got.shape == res.shape and got.is_contiguous(memory_format=torch.channels_last_3d)
+    G = gy.permute(0, 2, 3, 4, 1).reshape(-1, cout).double()
+    R = res.permute(0, 2, 3, 4, 1).reshape(-1, cin).double()
+    W = w.reshape(cout, cin).double()
+    want = R + G @ W
+    mag = R.abs() + G.abs() @ W.abs()
+    err = (got.permute(0, 2, 3, 4, 1).reshape(-1, cin).double() - want).abs()
+    assert torch.all(err <= 1e-6 * mag + 1e-12), float((err / mag).max())
+    assert torch.equal(got, fe.conv1x1_dgrad_add(gy, w, res))
+
+
+def test_resblock_residual_tap_equals_plain_autograd(cuda):
+    """an identity ResBlock (72 -> 18 -> 18 -> 72 on a 32 x 32 x 64 map) with the residual tap on / off: same output, same input gradient,
+    same parameter gradients (fp32 summation order only); with the tap on the block's autograd graph contains the tap node"""
+    from medicaldetectiontoolkit_amd.models.backbone import ResBlock
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    from medicaldetectiontoolkit_amd.utils.model_utils import NDConvGenerator
+    torch.manual_seed(9)
+    blk = ResBlock(72, 18, conv=NDConvGenerator(3)).to(cuda).to(memory_format=torch.channels_last_3d)
+    x0 = torch.randn((1, 72, 32, 32, 64), device=cuda).contiguous(memory_format=torch.channels_last_3d)
+    pre = torch.nn.Conv3d(72, 72, 1).to(cuda).to(memory_format=torch.channels_last_3d)      # so that the block input needs a gradient, as inside the net
+    res = []
+    for flag in (True, False):
+        fe.RES_TAP = flag
+        blk.zero_grad(); pre.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        xin = pre(x)
+        assert fe.res_tap_applies(blk.conv1, xin) == flag
+        y = blk(xin)
+        (y.square().mean() * 100).backward()
+        res.append(([y.detach().clone(), x.grad.clone()], {n: p.grad.clone() for n, p in list(blk.named_parameters()) + list(pre.named_parameters())}))
+    fe.RES_TAP = True
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max())), float((a - b).abs().max())
+    for n in res[0][1]:
+        a, b = res[0][1][n], res[1][1][n]
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-9), (n, float((a - b).abs().max()))
