@@ -303,7 +303,7 @@ def _graph_preflight(args, device_index, legs=False, timeout_s=600):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--graph-preflight", "legs" if legs else "check", "--patch", args.patch, "--batch", str(args.batch),
            "--gmax", str(args.gmax), "--steps", str(args.steps), "--device-index", str(device_index), "--channels-last", str(args.channels_last),
-           "--merge-rpn-heads", str(args.merge_rpn_heads)] + (["--no-exec-leg"] if args.no_exec_leg else [])
+           "--merge-rpn-heads", str(args.merge_rpn_heads), "--sparse-rpn-loss", str(args.sparse_rpn_loss)] + (["--no-exec-leg"] if args.no_exec_leg else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                           "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     t0 = time.time()
@@ -338,6 +338,7 @@ def graph_preflight_main(args):
     patch = [int(v) for v in args.patch.split(",")]
     cf = Configs(dim=3, model="mrcnn", patch_size=patch, batch_size=args.batch, channels_last=bool(args.channels_last))
     mrcnn.MERGE_RPN_HEADS = bool(args.merge_rpn_heads)
+    mrcnn.SPARSE_RPN_LOSS = bool(args.sparse_rpn_loss)
     torch.manual_seed(0)
     net = mrcnn.net(cf, device=dev)
     opt = training.build_optimizer(net, cf, flat=True)
@@ -553,6 +554,7 @@ def main():
     ap.add_argument("--res-tap", type=int, default=1, help="1 (default): identity ResBlocks produce their input gradient already added to the residual gradient (utils/fused_epilogue._Conv1x1ResTap, csrc/epilogue.hip); 0: conv backward + autograd's accumulation pass (A/B)")
     ap.add_argument("--head-as-linear", type=int, default=1, help="1 (default): the classifier head's full-extent / 1x1x1 convolutions as GEMMs (models/mrcnn.py Classifier); 0: MIOpen convolutions (A/B)")
     ap.add_argument("--merge-rpn-heads", type=int, default=1, help="1 (default): conv_class and conv_bbox of the RPN as one 1x1 convolution over the shared 128-channel map (models/mrcnn.py RPN); 0: two layers (A/B)")
+    ap.add_argument("--sparse-rpn-loss", type=int, default=1, help="1 (default): the RPN losses differentiate through the 48 sampled anchors only (models/mrcnn.rpn_at_anchors; the dense RPN forward carries no graph); 0: through the dense outputs like the reference (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
     ap.add_argument("--pool-cl", type=int, default=1, help="1 (default): channels-last max pooling kernel of the stem (csrc/pool.hip); 0: torch (A/B)")
     ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
@@ -615,6 +617,7 @@ def main():
     from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch, to_device
     mrcnn.HEAD_AS_LINEAR = bool(args.head_as_linear)
     mrcnn.MERGE_RPN_HEADS = bool(args.merge_rpn_heads)
+    mrcnn.SPARSE_RPN_LOSS = bool(args.sparse_rpn_loss)
 
     # MIOpen's immediate-mode heuristics pick naive 3D solvers for the 18/36/72-channel convolutions of this
     # backbone (3.2 s per step); the exhaustive find selects im2col+GEMM / CK kernels (42x faster, profiles/).

@@ -34,6 +34,7 @@ from . import backbone as backbone_module
 ############################################################
 HEAD_AS_LINEAR = True    # module switch (A/B: bench.py --head-as-linear 0): classifier-head convolutions as matrix products
 MERGE_RPN_HEADS = True   # module switch (A/B: bench.py --merge-rpn-heads 0): conv_class and conv_bbox of the RPN as ONE 1x1 convolution
+SPARSE_RPN_LOSS = True   # module switch (A/B: bench.py --sparse-rpn-loss 0): RPN losses differentiate through the SAMPLED anchors only
 
 
 class RPN(nn.Module):
@@ -67,6 +68,102 @@ class RPN(nn.Module):
             rpn_bbox = self.conv_bbox(x).permute(*axes).contiguous().view(x.size(0), -1, self.dim * 2)
         rpn_probs = F.softmax(rpn_class_logits, dim=2)
         return [rpn_class_logits, rpn_probs, rpn_bbox]
+
+
+def rpn_sparse_supported(rpn):
+    """rpn_at_anchors restates the RPN for single voxels: 3^dim unit-stride conv_shared (+ ReLU / LeakyReLU, no norm layer) and 1^dim heads"""
+    cs = rpn.conv_shared
+    if not isinstance(cs, nn.Sequential) or len(cs) != 2 or not isinstance(cs[1], (nn.ReLU, nn.LeakyReLU)):
+        return False
+    Conv = nn.Conv2d if rpn.dim == 2 else nn.Conv3d
+
+    def plain(c, k, pad):
+        return isinstance(c, Conv) and c.groups == 1 and not isinstance(c.padding, str) and all(int(v) == k for v in c.kernel_size) \
+            and all(int(v) == 1 for v in c.stride) and all(int(v) == 1 for v in c.dilation) and all(int(v) == pad for v in c.padding) \
+            and c.padding_mode == "zeros"
+    return plain(cs[0], 3, 1) and plain(rpn.conv_class, 1, 0) and plain(rpn.conv_bbox, 1, 0)
+
+
+class _GatherRows(torch.autograd.Function):
+    """rows of a [V, C] matrix by index; backward = index_add_ into zeros (advanced indexing's backward sorts the indices first: a dozen
+    launches for a few thousand rows)"""
+
+    @staticmethod
+    def forward(ctx, flat, rows):
+        ctx.save_for_backward(rows)
+        ctx.n = flat.shape[0]
+        return flat.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, = ctx.saved_tensors
+        out = torch.zeros((ctx.n, g.shape[1]), dtype=g.dtype, device=g.device)
+        out.index_add_(0, rows, g.contiguous())
+        return out, None
+
+
+def rpn_at_anchors(rpn, feature_maps, idx, n_anchors_per_voxel):
+    """The RPN (mrcnn.py:40-86) evaluated at CHOSEN anchors only: idx [B, n] indexes the anchors in the order of the concatenated pyramid
+    levels, as RPN.forward lays them out ((y, x, z, anchor) row-major per level).  Returns class logits [B, n, 2] and box deltas
+    [B, n, 2 dim], differentiable w.r.t. the feature maps and the RPN's parameters.
+
+    Why: the RPN losses (mrcnn.py:176-240) read the dense outputs at rpn_train_anchors_per_image = 6 anchors per element -- 48 of
+    3.6 M anchors at 8 x 128^3 -- so the gradient that the dense graph sends back through the heads and conv_shared is zero at all but
+    <= 48 voxels, and the reference (and this repo until round 4) still runs the full input-gradient and weight-gradient convolutions
+    of conv_shared on every level for it: 6.6 ms on P2 alone, a sixth of the step.  Here the dense forward runs without a graph (the
+    proposals and the SHEM ranking need every anchor, mrcnn.py:243-330 detaches them anyway) and the sampled anchors are recomputed
+    from their 3^dim x C neighbourhoods: gather -> [S, 3^dim C] x [3^dim C, F] -> activation -> the two 1x1 heads.  Same function of
+    the same parameters, so the same gradients up to fp32 summation order (test_models_gpu.py pins both against the dense graph)."""
+    dim = rpn.dim
+    conv = rpn.conv_shared[0]
+    B, n = idx.shape
+    dev = idx.device
+    A = int(n_anchors_per_voxel)
+    sizes = [tuple(int(v) for v in m.shape[2:]) for m in feature_maps]
+    vox = [int(np.prod(sz)) for sz in sizes]
+    starts = np.concatenate([[0], np.cumsum([v * A for v in vox])])
+    idx = idx.long()
+    b_ix = torch.arange(B, device=dev)[:, None].expand(B, n).reshape(-1)
+    flat_idx = idx.reshape(-1)
+    S = B * n
+    T = 3 ** dim
+    C = conv.in_channels
+    offs = mutils.const_tensor([[t // (3 ** (dim - 1 - d)) % 3 - 1 for d in range(dim)] for t in range(T)], torch.int64, dev)      # [T, dim], (ky, kx[, kz]) order
+    patches = None
+    k_anchor = None
+    for l, (fm, sz) in enumerate(zip(feature_maps, sizes)):
+        in_level = (flat_idx >= int(starts[l])) & (flat_idx < int(starts[l + 1]))
+        local = (flat_idx - int(starts[l])).clamp(0, vox[l] * A - 1)
+        v = local // A
+        coords = []
+        for d in range(dim - 1, -1, -1):
+            coords.append(v % sz[d])
+            v = v // sz[d]
+        coords = torch.stack(coords[::-1], 1)                                   # [S, dim]
+        nb = coords[:, None, :] + offs[None, :, :]                             # [S, T, dim]
+        lim = mutils.const_tensor(list(sz), torch.int64, dev)
+        ok = ((nb >= 0) & (nb < lim)).all(-1) & in_level[:, None]               # zero padding of the convolution + rows of other levels
+        nbc = torch.minimum(nb.clamp(min=0), lim - 1)
+        row = b_ix[:, None]
+        for d in range(dim):
+            row = row * sz[d] + nbc[..., d]
+        perm = (0, 2, 3, 1) if dim == 2 else (0, 2, 3, 4, 1)
+        flat = fm.permute(*perm).reshape(-1, C)                                # a view for channels-last maps
+        g = _GatherRows.apply(flat, row.reshape(-1)).view(S, T, C) * ok.unsqueeze(-1).to(fm.dtype)
+        patches = g if patches is None else patches + g
+        ka = torch.where(in_level, local % A, torch.zeros_like(local))
+        k_anchor = ka if k_anchor is None else k_anchor + ka
+    wperm = (0, 2, 3, 1) if dim == 2 else (0, 2, 3, 4, 1)
+    w = conv.weight.permute(*wperm).reshape(conv.out_channels, T * C)          # (tap, channel) order of the patches
+    h = F.linear(patches.reshape(S, T * C), w, conv.bias)
+    act = rpn.conv_shared[1]
+    h = F.leaky_relu(h, act.negative_slope) if isinstance(act, nn.LeakyReLU) else F.relu(h)
+    Fh = conv.out_channels
+    lc = F.linear(h, rpn.conv_class.weight.reshape(-1, Fh), rpn.conv_class.bias).view(S, A, 2)
+    lb = F.linear(h, rpn.conv_bbox.weight.reshape(-1, Fh), rpn.conv_bbox.bias).view(S, A, 2 * dim)
+    logits = torch.gather(lc, 1, k_anchor.view(S, 1, 1).expand(S, 1, 2)).view(B, n, 2)
+    deltas = torch.gather(lb, 1, k_anchor.view(S, 1, 1).expand(S, 1, 2 * dim)).view(B, n, 2 * dim)
+    return logits, deltas
 
 
 def _forward_valid_rows(fn, feature_maps, rois):
@@ -420,11 +517,13 @@ def refine_detections(rois, probs, deltas, batch_ixs, cf, B):
 #  Loss functions (masked, fixed-size)
 ############################################################
 def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, anchors_f64, gt_boxes_list, cf, generator=None,
-                       shem_poolsize=None, gt_dev=None):
+                       shem_poolsize=None, gt_dev=None, sparse_eval=None):
     """compute_rpn_class_loss (mrcnn.py:176-214) + compute_rpn_bbox_loss (:217-240), batched over B; with K-class
     logits and class-id matches it is also retina_unet.compute_class_loss / compute_bbox_loss (retina_unet.py:126-189).
     rpn_match [B, A] int32 (-1 / 0 / >0) as returned by the matching kernel BEFORE sub-sampling; the
-    sub-sampling of surplus positives (model_utils.py:566-571) and SHEM are done here with random keys."""
+    sub-sampling of surplus positives (model_utils.py:566-571) and SHEM are done here with random keys.
+    sparse_eval (idx [B, n] -> logits [B, n, K], deltas [B, n, 2 dim]; rpn_at_anchors): the dense tensors then carry no graph and only
+    rank / select, the loss terms differentiate through the re-evaluated samples."""
     dev = rpn_class_logits.device
     B, A = rpn_match.shape
     dim = cf.dim
@@ -436,10 +535,9 @@ def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas,
     pos_count = pvalid.sum(1)
     K = rpn_class_logits.shape[-1]
     poolsize = cf.shem_poolsize if shem_poolsize is None else shem_poolsize
-    logits_pos = torch.gather(rpn_class_logits, 1, pidx.unsqueeze(-1).expand(-1, -1, K))
+    if sparse_eval is None:
+        logits_pos = torch.gather(rpn_class_logits, 1, pidx.unsqueeze(-1).expand(-1, -1, K))
     tgt_pos = torch.gather(rpn_match, 1, pidx).clamp(min=0).long()          # 1 for the RPN, class id for Retina
-    ce_pos = F.cross_entropy(logits_pos.reshape(-1, K), tgt_pos.view(-1), reduction="none").view(B, -1)
-    pos_loss = (ce_pos * pvalid).sum(1) / pos_count.clamp(min=1)              # 0 when no positive
     # negatives: SHEM over anchors labelled -1
     neg = rpn_match == -1
     neg_count = pos_count.clamp(min=1)
@@ -452,7 +550,14 @@ def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas,
     nkey, nsel = torch.topk(key2, n_pos_max, dim=1)
     nidx = torch.gather(pool_idx, 1, nsel)
     nvalid = (nkey >= 0) & (torch.arange(n_pos_max, device=dev)[None, :] < neg_count[:, None])
-    logits_neg = torch.gather(rpn_class_logits, 1, nidx.unsqueeze(-1).expand(-1, -1, K))
+    if sparse_eval is None:
+        logits_neg = torch.gather(rpn_class_logits, 1, nidx.unsqueeze(-1).expand(-1, -1, K))
+        pred = torch.gather(rpn_pred_deltas, 1, pidx.unsqueeze(-1).expand(-1, -1, 2 * dim))
+    else:
+        ls, ds = sparse_eval(torch.cat([pidx, nidx], 1))                       # ONE evaluation for positives and negatives
+        logits_pos, logits_neg, pred = ls[:, :n_pos_max], ls[:, n_pos_max:], ds[:, :n_pos_max]
+    ce_pos = F.cross_entropy(logits_pos.reshape(-1, K), tgt_pos.view(-1), reduction="none").view(B, -1)
+    pos_loss = (ce_pos * pvalid).sum(1) / pos_count.clamp(min=1)              # 0 when no positive
     ce_neg = F.cross_entropy(logits_neg.reshape(-1, K), torch.zeros(B * n_pos_max, dtype=torch.long, device=dev), reduction="none").view(B, -1)
     neg_loss = (ce_neg * nvalid).sum(1) / nvalid.sum(1).clamp(min=1)
     class_loss = ((pos_loss + neg_loss) / 2).mean()                           # mean over batch == sum(loss_b / B)
@@ -473,7 +578,6 @@ def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas,
     pv = pvalid.view(-1)
     g_pos = torch.where(pv.unsqueeze(-1), g_pos, a_pos)                       # keep invalid rows finite
     tgt = mutils.anchor_delta_targets(a_pos, g_pos, cf.rpn_bbox_std_dev).float().view(B, n_pos_max, 2 * dim)
-    pred = torch.gather(rpn_pred_deltas, 1, pidx.unsqueeze(-1).expand(-1, -1, 2 * dim))
     sl1 = F.smooth_l1_loss(pred, tgt, reduction="none")
     bbox_loss_b = (sl1 * pvalid.unsqueeze(-1)).sum((1, 2)) / (pos_count.clamp(min=1) * 2 * dim)
     bbox_loss = bbox_loss_b.mean()
@@ -590,9 +694,10 @@ class net(nn.Module):
         return self.anchors_f64.cpu().numpy()
 
     # ------------------------------------------------------------------ forward passes
-    def forward(self, img, is_training=True, with_masks=True):
+    def forward(self, img, is_training=True, with_masks=True, rpn_graph=True):
         """mrcnn.py:987-1050.  with_masks=False skips the mask head over the detections (the reference always runs it and
-        drops the result when return_masks is off, mrcnn.py:1046-1048 / :984): box-only inference."""
+        drops the result when return_masks is off, mrcnn.py:1046-1048 / :984): box-only inference.  rpn_graph=False: the dense RPN
+        outputs carry no autograd graph (train_forward_device differentiates the RPN losses through rpn_at_anchors instead)."""
         cf = self.cf
         B = img.shape[0]
         if self.memory_format is not None:
@@ -602,8 +707,10 @@ class net(nn.Module):
         # the RoIAlign kernels read [B, C, spatial] row-major maps: convert a channels-last map ONCE per forward (every head
         # call would otherwise re-copy all levels, and the heads' gradients would meet in mixed layouts)
         self.mrcnn_feature_maps = [m.contiguous() for m in rpn_feature_maps]
-        layer_outputs = [self.rpn(p) for p in rpn_feature_maps]
-        rpn_pred_logits, rpn_pred_probs, rpn_pred_deltas = [torch.cat(list(o), dim=1) for o in zip(*layer_outputs)]
+        self.rpn_feature_maps = rpn_feature_maps
+        with torch.set_grad_enabled(rpn_graph and torch.is_grad_enabled()):
+            layer_outputs = [self.rpn(p) for p in rpn_feature_maps]
+            rpn_pred_logits, rpn_pred_probs, rpn_pred_deltas = [torch.cat(list(o), dim=1) for o in zip(*layer_outputs)]
         proposal_count = cf.post_nms_rois_training if is_training else cf.post_nms_rois_inference
         batch_rpn_rois, batch_proposal_boxes = proposal_layer(rpn_pred_probs, rpn_pred_deltas, proposal_count, self.anchors, cf)
         batch_ixs = torch.arange(B, device=img.device, dtype=torch.float32).repeat_interleave(batch_rpn_rois.shape[1])
@@ -673,7 +780,9 @@ class net(nn.Module):
         monitoring read-out of exec.py needs ('mon')."""
         cf = self.cf
         B = img.shape[0]
-        rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(img, with_masks=with_masks)
+        sparse_rpn = SPARSE_RPN_LOSS and rpn_sparse_supported(self.rpn)
+        rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid, detection_masks = self.forward(
+            img, with_masks=with_masks, rpn_graph=not sparse_rpn)
         if isinstance(gt_masks, mutils.StagedUpload):
             gt_masks = gt_masks.get()
         (mrcnn_class_logits, mrcnn_pred_deltas, mrcnn_pred_mask, target_class_ids, mrcnn_target_deltas, target_mask,
@@ -683,8 +792,15 @@ class net(nn.Module):
         # mrcnn.py:894); the per-element GT counts are read by the kernel
         neg_thr = 0.1 if cf.dim == 2 else 0.01
         rpn_match, rpn_argmax = mutils.anchor_match_labels_batched(self.anchors_f64, gt_dev.px, gt_dev.n_gt, None, neg_thr, float(cf.anchor_matching_iou))
+        sparse_eval = None
+        if sparse_rpn:
+            maps, n_apv = self.rpn_feature_maps, len(cf.rpn_anchor_ratios)
+
+            def sparse_eval(idx):
+                return rpn_at_anchors(self.rpn, maps, idx, n_apv)
         batch_rpn_class_loss, batch_rpn_bbox_loss, rpn_samples = compute_rpn_losses(
-            rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, self.anchors_f64, None, cf, gt_dev=gt_dev)
+            rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, self.anchors_f64, None, cf, gt_dev=gt_dev, sparse_eval=sparse_eval)
+        self.rpn_feature_maps = None
 
         mrcnn_class_loss = compute_mrcnn_class_loss(target_class_ids, mrcnn_class_logits, s_valid)
         mrcnn_bbox_loss = compute_mrcnn_bbox_loss(mrcnn_target_deltas, mrcnn_pred_deltas, target_class_ids, s_pos)

@@ -431,7 +431,7 @@ class GraphedTrainStep(object):
         # the capture's backward then runs those nodes on the DEFAULT stream and hipStreamEndCapture segfaults (bench.py r04: eager steps,
         # then capture).  Dropping the net's references to the last step makes the old nodes die in the common case:
         import gc
-        for attr in ("mrcnn_feature_maps", "rpn_rois_batch_info", "batch_mrcnn_class_scores"):
+        for attr in ("mrcnn_feature_maps", "rpn_feature_maps", "rpn_rois_batch_info", "batch_mrcnn_class_scores"):
             if hasattr(self.net, attr):
                 setattr(self.net, attr, None)
         gc.collect()

@@ -181,3 +181,44 @@ def test_steady_state_categories_cover_this_repos_kernels():
     for n in ("_ZN2ck16tensor_operation6device", "Cijk_Alik_Bljk_S_B_Bias_HA_S_SAV_UserArgs_MT256x48", "miopenSp3AsmConv"):
         assert ss.category(n).startswith("MIOpen")
     assert ss.category("void at::native::vectorized_elementwise_kernel<4, ...>").startswith("torch elementwise")
+
+
+def test_rpn_at_anchors_equals_the_dense_rpn_in_float64():
+    """models/mrcnn.rpn_at_anchors (the RPN of mrcnn.py:40-86 re-evaluated at chosen anchors: 3^dim x C neighbourhood gather -> matrix
+    products) == gathering the dense RPN outputs at the same anchors, and so are ALL gradients (feature maps of every level, the six
+    RPN parameters): volume corners (zero padding), first / last anchor of a level, duplicates, 2D and 3D; float64, 1e-12"""
+    import pytest
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from medicaldetectiontoolkit_amd.models import mrcnn
+    from medicaldetectiontoolkit_amd.utils import model_utils as mutils
+    torch.manual_seed(0)
+    for dim, sizes in ((3, [(8, 8, 16), (4, 4, 8), (2, 2, 4), (1, 1, 2)]), (2, [(16, 16), (8, 8), (4, 4), (2, 2)])):
+        cf = Configs(dim=dim, model="mrcnn", patch_size=[32] * dim, batch_size=2)
+        rpn = mrcnn.RPN(cf, mutils.NDConvGenerator(dim)).double()
+        assert mrcnn.rpn_sparse_supported(rpn)
+        B, n_apv = 2, len(cf.rpn_anchor_ratios)
+        mf = torch.channels_last_3d if dim == 3 else torch.channels_last
+        for channels_last in (True, False):
+            maps = [torch.randn((B, cf.end_filts) + s, dtype=torch.float64) for s in sizes]
+            maps = [(m.contiguous(memory_format=mf) if channels_last else m).requires_grad_(True) for m in maps]
+            outs = [rpn(m) for m in maps]
+            logits, deltas = torch.cat([o[0] for o in outs], 1), torch.cat([o[2] for o in outs], 1)
+            A = logits.shape[1]
+            first = n_apv * int(np.prod(sizes[0]))
+            idx = torch.randint(0, A, (B, 40))
+            idx[0, :4] = torch.tensor([0, A - 1, first - 1, first])
+            idx[1, :3] = idx[1, 3]                                                  # duplicates accumulate in the scatter
+            ls, ds = mrcnn.rpn_at_anchors(rpn, maps, idx, n_apv)
+            dl = torch.gather(logits, 1, idx.unsqueeze(-1).expand(-1, -1, 2))
+            dd = torch.gather(deltas, 1, idx.unsqueeze(-1).expand(-1, -1, 2 * dim))
+            assert float((ls - dl).abs().max()) < 1e-12 and float((ds - dd).abs().max()) < 1e-12
+            wl, wd = torch.randn_like(dl), torch.randn_like(dd)
+            wrt = maps + list(rpn.parameters())
+            g_dense = torch.autograd.grad((dl * wl).sum() + (dd * wd).sum(), wrt, retain_graph=True)
+            g_sparse = torch.autograd.grad((ls * wl).sum() + (ds * wd).sum(), wrt)
+            for a, b in zip(g_dense, g_sparse):
+                assert a.shape == b.shape and float((a - b).abs().max()) < 1e-11 * max(1.0, float(a.abs().max()))
+    # a normalisation layer or a strided conv_shared is outside the restatement: the dense graph is used
+    cf = Configs(dim=3, model="mrcnn", patch_size=[32, 32, 32], batch_size=2)
+    cf.rpn_anchor_stride = 2
+    assert not mrcnn.rpn_sparse_supported(mrcnn.RPN(cf, mutils.NDConvGenerator(3)))

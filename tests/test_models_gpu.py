@@ -295,6 +295,42 @@ def test_rpn_merged_heads_equal_separate_layers(channels_last, cuda):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-7), (n, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("dim,patch", [(3, [64, 64, 32]), (2, [64, 64])])
+def test_sparse_rpn_loss_step_equals_dense_graph_step(dim, patch, cuda):
+    """train_forward_device with the RPN losses differentiated through the sampled anchors only (models/mrcnn.SPARSE_RPN_LOSS,
+    rpn_at_anchors; the dense RPN forward carries no graph) == the same step through the dense RPN graph, as the reference builds it
+    (mrcnn.py:870-946): all five loss terms, the sampled anchors, and the gradient of EVERY parameter (fp32 summation order only)"""
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import batch_with_gt_from_proposals
+    B = 2
+    cf = Configs(dim=dim, model="mrcnn", patch_size=patch, batch_size=B, channels_last=True)
+    torch.manual_seed(3)
+    net = mrcnn.net(cf, device=cuda)
+    batch = batch_with_gt_from_proposals(net, cf, make_batch(patch, B, seed=5), cuda)
+    res = []
+    try:
+        for flag in (True, False):
+            mrcnn.SPARSE_RPN_LOSS = flag
+            net.zero_grad(set_to_none=True)
+            torch.manual_seed(17)                                                  # same random sub-sampling keys in both runs
+            prep = net.prepare_batch(batch)
+            out = net.train_forward_device(prep["img"], prep["gt"], prep["masks"])
+            out["loss"].backward()
+            res.append(({k: float(v) for k, v in out["terms"].items()}, [t.clone() for t in out["mon"]["rpn_samples"]],
+                        {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        mrcnn.SPARSE_RPN_LOSS = True
+    (ta, sa, ga), (tb, sb, gb) = res
+    assert sum(int(v.sum()) for v in (sa[1], sa[3])) > 0, "no anchor was sampled: the comparison would be empty"
+    for k in tb:
+        assert abs(ta[k] - tb[k]) <= 1e-5 * max(1.0, abs(tb[k])), (k, ta[k], tb[k])
+    for a, b in zip(sa, sb):
+        assert torch.equal(a, b)
+    assert set(ga) == set(gb) and any(n.startswith("rpn.") for n in ga)
+    for n in gb:
+        a, b = ga[n], gb[n]
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-5 * float(b.abs().max()) + 1e-8), (n, float((a - b).abs().max()), float(b.abs().max()))
+
+
 def test_train_py_exec_loop_graphed_then_resumed_eager(cuda, tmp_path):
     """train.py = the stand-in for exec.py's training loop: batches through training.DevicePrefetcher, the monitoring read-out and log line
     every batch, reference-format checkpoint per epoch.  Epoch 1 with the graphed step (--graph 1), then --resume for epoch 2 with the

@@ -13,4 +13,5 @@ echo "$LINE" | cut -c1-300
 MS=$(echo "$LINE" | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
 T=$(find $ROOT/gpurun_out/prof_step -name "*kernel_trace.csv" | head -1)
 python $ROOT/tools/steady_state.py "$T" $STEPS $MS $ROOT/gpurun_out/${OUT_NAME:-r03_step_steady_state}.csv
+if [ -n "$GLUE_OUT" ]; then python $ROOT/tools/glue_breakdown.py "$T" 3 > $ROOT/gpurun_out/$GLUE_OUT; fi
 rm -rf $ROOT/gpurun_out/prof_step
