@@ -30,6 +30,13 @@ class ResBlock(nn.Module):
             self.downsample = None
         self.stride = stride
 
+    def forward_subsampled(self, x_s):
+        """the block on an input that was sub-sampled by this block's stride already (fused_epilogue.stride_tap): conv1 and downsample
+        -- both 1x1, same stride -- run at unit stride on x_s; everything else as in forward"""
+        residual = fused_epilogue.conv1x1_unit_stride_bias_act(self.downsample, x_s)
+        out = self.conv2(fused_epilogue.conv1x1_unit_stride_bias_act(self.conv1[0], x_s, relu=True))
+        return self.conv3(out, residual=residual, relu=True)
+
     def forward(self, x):
         if self.downsample is None and fused_epilogue.res_tap_applies(self.conv1, x):
             # identity block: x feeds conv1 AND the residual add -- one autograd node owns both paths, so that its backward produces
@@ -117,15 +124,29 @@ class FPN(nn.Module):
             self.P6_conv1 = conv(sf * 64, oc, ks=1, stride=1, relu=None)
             self.P6_conv2 = conv(oc, oc, ks=3, stride=1, pad=1, relu=None)
 
+    @staticmethod
+    def _stage(seq, x):
+        """One of C3..C6 on the previous stage's output x.  Returns (stage output, the tensor the lateral of x's level must read): with
+        the stride tap the first block's two strided 1x1 layers share ONE sub-sampled copy of x and the lateral reads the tap's alias,
+        so that the three gradients of x meet in one place (fused_epilogue._StrideTap)."""
+        blk = seq[0]
+        if isinstance(blk, ResBlock) and isinstance(blk.conv3, ConvBias) and isinstance(blk.relu, nn.ReLU) and fused_epilogue.stride_tap_applies(blk, x):
+            x_lat, x_s = fused_epilogue.stride_tap(x, blk.conv1[0].stride)
+            out = blk.forward_subsampled(x_s)
+            for b in list(seq)[1:]:
+                out = b(out)
+            return out, x_lat
+        return seq(x), x
+
     def forward(self, x):
         c0_out = self.C0(x) if self.operate_stride1 else x
         c1_out = self.C1(c0_out)
         c2_out = self.C2(c1_out)
-        c3_out = self.C3(c2_out)
-        c4_out = self.C4(c3_out)
-        c5_out = self.C5(c4_out)
+        c3_out, c2_out = self._stage(self.C3, c2_out)
+        c4_out, c3_out = self._stage(self.C4, c3_out)
+        c5_out, c4_out = self._stage(self.C5, c4_out)
         if self.sixth_pooling:
-            c6_out = self.C6(c5_out)
+            c6_out, c5_out = self._stage(self.C6, c5_out)
             p6_pre_out = self.P6_conv1(c6_out)
             p5_pre_out = _lateral(self.P5_conv1, c5_out, F.interpolate(p6_pre_out, scale_factor=2))
         else:

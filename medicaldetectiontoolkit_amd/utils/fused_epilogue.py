@@ -594,6 +594,74 @@ def conv_bias_relu_with_res_tap(seq, x):
     return bias_act(h, conv.bias, None, True), x_res
 
 
+STRIDE_TAP = True   # module switch (A/B: bench.py --stride-tap 0)
+
+
+class _StrideTap(Function):
+    """x -> (alias of x for the FPN lateral, x_s = x[..., ::s, ::s, ::s] for the strided 1x1 layers of the next stage's first ResBlock).
+
+    A stage output c_k has three consumers (models/backbone.py:128-153): conv1 and downsample of the next stage's first block -- both 1x1
+    convolutions with stride 2, i.e. unit-stride layers on the SAME sub-sampled tensor -- and the lateral P_k_conv1.  As three autograd
+    consumers, each strided layer's input gradient is a full-size tensor that is zero at 7 of 8 voxels (2 x 302 MB on c2 at 8 x 128^3,
+    written by MIOpen's backward-data kernels) and two more full-size passes add them to the lateral's gradient.  Sub-sampled ONCE here,
+    the two layers run at unit stride (their gradients meet at 1/8 size), and this node's backward adds that sum into the lateral's
+    gradient at the even voxels, in place: one strided pass over 1/8 of the rows."""
+
+    @staticmethod
+    def forward(ctx, x, stride):
+        ctx.set_materialize_grads(False)
+        ctx.stride = tuple(int(s) for s in stride)
+        ctx.mf = torch.channels_last_3d if x.dim() == 5 else torch.channels_last
+        ctx.x_shape = tuple(x.shape)
+        sl = (slice(None), slice(None)) + tuple(slice(None, None, s) for s in ctx.stride)
+        return x, x[sl].contiguous(memory_format=ctx.mf)
+
+    @staticmethod
+    def backward(ctx, g_lat, g_s):
+        sl = (slice(None), slice(None)) + tuple(slice(None, None, s) for s in ctx.stride)
+        if g_lat is None:
+            if g_s is None:
+                return None, None
+            g = torch.zeros(ctx.x_shape, dtype=g_s.dtype, device=g_s.device).contiguous(memory_format=ctx.mf)
+            g[sl].copy_(g_s)
+            return g, None
+        if g_s is None:
+            return g_lat, None
+        # g_lat is the lateral convolution's input gradient: a fresh dense tensor this node is the only consumer of (the alias has ONE
+        # user by construction, backbone.FPN._stage) -- dense and non-overlapping is checked, anything else is copied first
+        g = g_lat if (g_lat.is_contiguous(memory_format=ctx.mf) or g_lat.is_contiguous()) and g_lat._base is None else g_lat.clone(memory_format=ctx.mf)
+        g[sl].add_(g_s)
+        return g, None
+
+
+def stride_tap_applies(block, x):
+    """first ResBlock of a stage: 1x1 conv1 (+bias+ReLU) and 1x1 downsample (+bias) with the SAME stride > 1, fused-epilogue modules, fp32 CUDA
+    activation that needs a gradient"""
+    if not (ENABLED and STRIDE_TAP and BWD_DATA_AS_FWD) or block.downsample is None or not isinstance(block.conv1, ConvBiasReLU) \
+            or not isinstance(block.downsample, ConvBias):
+        return False
+    c1, ds = block.conv1[0], block.downsample
+
+    def one_by_one(c):
+        return c.bias is not None and c.groups == 1 and all(int(k) == 1 for k in c.kernel_size) and _unit(c.dilation) \
+            and not isinstance(c.padding, str) and not any(int(p) for p in c.padding)
+    if not (one_by_one(c1) and one_by_one(ds) and tuple(c1.stride) == tuple(ds.stride) and any(int(v) > 1 for v in c1.stride)):
+        return False
+    return x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad and not torch.is_autocast_enabled() \
+        and x.dim() in (4, 5) and _on_current_device(x)
+
+
+def stride_tap(x, stride):
+    """(alias of x for the lateral, x sub-sampled by `stride`)"""
+    return _StrideTap.apply(x, tuple(int(s) for s in stride))
+
+
+def conv1x1_unit_stride_bias_act(conv, x_s, residual=None, relu=False):
+    """a 1x1 convolution module applied at UNIT stride to an already sub-sampled input (same parameters, same result as the strided
+    layer on the full tensor) + its bias / ReLU epilogue"""
+    return bias_act(conv_unit_stride(x_s, conv.weight, 0), conv.bias, residual, relu)
+
+
 class ConvBias(object):
     """mixin for the bare-conv form (relu=None in the reference's generator): forward(x, residual=None, relu=False)"""
 

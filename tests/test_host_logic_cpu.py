@@ -222,3 +222,46 @@ def test_rpn_at_anchors_equals_the_dense_rpn_in_float64():
     cf = Configs(dim=3, model="mrcnn", patch_size=[32, 32, 32], batch_size=2)
     cf.rpn_anchor_stride = 2
     assert not mrcnn.rpn_sparse_supported(mrcnn.RPN(cf, mutils.NDConvGenerator(3)))
+
+
+def test_stride_tap_equals_three_consumers_of_a_stage_output_in_float64():
+    """utils/fused_epilogue._StrideTap + ResBlock.forward_subsampled (a stage output sub-sampled ONCE for the two strided 1x1 layers of the
+    next stage's first block, the FPN lateral reading the tap's alias; the sub-sampled gradient added IN PLACE into the lateral's) ==
+    the plain graph of models/backbone.py:128-153 / 183-206 with its three consumers: block output, lateral output, the input gradient
+    and every parameter gradient; odd extents, 2D and 3D; float64 1e-13.  Single-consumer cases (either gradient absent) as well."""
+    from medicaldetectiontoolkit_amd.models.backbone import ResBlock
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe, model_utils as mutils
+    torch.manual_seed(0)
+    for dim, shape in ((3, (2, 8, 8, 6, 10)), (3, (1, 8, 7, 5, 9)), (2, (2, 8, 9, 7))):
+        conv = mutils.NDConvGenerator(dim)
+        blk = ResBlock(8, 4, conv=conv, stride=2, downsample=(8, 2, 2)).double()
+        lat = conv(8, 5, ks=1, stride=1, relu=None).double()
+        mf = torch.channels_last_3d if dim == 3 else torch.channels_last
+        x0 = torch.randn(shape, dtype=torch.float64).contiguous(memory_format=mf)
+        res = []
+        for tap in (False, True):
+            x = x0.clone().requires_grad_(True)
+            h = x * 1.0
+            blk.zero_grad()
+            lat.zero_grad()
+            if tap:
+                x_lat, x_s = fe.stride_tap(h, blk.conv1[0].stride)
+                out = blk.forward_subsampled(x_s)
+            else:
+                x_lat, out = h, blk(h)
+            lo = lat(x_lat)
+            ((out * out).sum() + (lo * lo * lo).sum()).backward()
+            res.append([out.detach(), lo.detach(), x.grad.clone()] + [p.grad.clone() for p in list(blk.parameters()) + list(lat.parameters())])
+        for a, b in zip(*res):
+            assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-13 * max(1.0, float(a.abs().max()))
+        x = x0.clone().requires_grad_(True)
+        _, x_s = fe.stride_tap(x * 1.0, (2,) * dim)
+        x_s.sum().backward()
+        sl = (slice(None), slice(None)) + (slice(None, None, 2),) * dim
+        want = torch.zeros_like(x0)
+        want[sl] = 1.0
+        assert torch.equal(x.grad, want)
+        x.grad = None
+        x_lat, _ = fe.stride_tap(x * 1.0, (2,) * dim)
+        (x_lat * 3.0).sum().backward()
+        assert torch.equal(x.grad, torch.full_like(x0, 3.0))
