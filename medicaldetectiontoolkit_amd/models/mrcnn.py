@@ -129,30 +129,36 @@ def rpn_at_anchors(rpn, feature_maps, idx, n_anchors_per_voxel):
     T = 3 ** dim
     C = conv.in_channels
     offs = mutils.const_tensor([[t // (3 ** (dim - 1 - d)) % 3 - 1 for d in range(dim)] for t in range(T)], torch.int64, dev)      # [T, dim], (ky, kx[, kz]) order
+    # index arithmetic ONCE for all levels (per-sample level, extents and start through small lookup tables) ...
+    L = len(sizes)
+    starts_t = mutils.const_tensor([int(v) for v in starts], torch.int64, dev)
+    size_t = mutils.const_tensor([list(sz) for sz in sizes], torch.int64, dev)  # [L, dim]
+    level = torch.bucketize(flat_idx, starts_t[1:L], right=True)               # [S] in 0 .. L-1
+    local = flat_idx - starts_t[level]
+    sz = size_t[level]                                                          # [S, dim]
+    v = local // A
+    k_anchor = local - v * A
+    coords = []
+    for d in range(dim - 1, -1, -1):
+        q = v // sz[:, d]
+        coords.append(v - q * sz[:, d])
+        v = q
+    coords = torch.stack(coords[::-1], 1)                                       # [S, dim]
+    nb = coords[:, None, :] + offs[None, :, :]                                 # [S, T, dim]
+    lim = sz[:, None, :]
+    ok = ((nb >= 0) & (nb < lim)).all(-1)                                       # the zero padding of the convolution
+    nbc = torch.minimum(nb.clamp(min=0), lim - 1)
+    row = b_ix[:, None]
+    for d in range(dim):
+        row = row * sz[:, d:d + 1] + nbc[..., d]                                # [S, T] row inside the sample's own level
+    # ... then one masked gather per level (rows of the other levels read row 0 and are multiplied by zero)
     patches = None
-    k_anchor = None
-    for l, (fm, sz) in enumerate(zip(feature_maps, sizes)):
-        in_level = (flat_idx >= int(starts[l])) & (flat_idx < int(starts[l + 1]))
-        local = (flat_idx - int(starts[l])).clamp(0, vox[l] * A - 1)
-        v = local // A
-        coords = []
-        for d in range(dim - 1, -1, -1):
-            coords.append(v % sz[d])
-            v = v // sz[d]
-        coords = torch.stack(coords[::-1], 1)                                   # [S, dim]
-        nb = coords[:, None, :] + offs[None, :, :]                             # [S, T, dim]
-        lim = mutils.const_tensor(list(sz), torch.int64, dev)
-        ok = ((nb >= 0) & (nb < lim)).all(-1) & in_level[:, None]               # zero padding of the convolution + rows of other levels
-        nbc = torch.minimum(nb.clamp(min=0), lim - 1)
-        row = b_ix[:, None]
-        for d in range(dim):
-            row = row * sz[d] + nbc[..., d]
+    for l, fm in enumerate(feature_maps):
+        m = ok & (level == l)[:, None]
         perm = (0, 2, 3, 1) if dim == 2 else (0, 2, 3, 4, 1)
         flat = fm.permute(*perm).reshape(-1, C)                                # a view for channels-last maps
-        g = _GatherRows.apply(flat, row.reshape(-1)).view(S, T, C) * ok.unsqueeze(-1).to(fm.dtype)
+        g = _GatherRows.apply(flat, (row * m).reshape(-1)).view(S, T, C) * m.unsqueeze(-1).to(fm.dtype)
         patches = g if patches is None else patches + g
-        ka = torch.where(in_level, local % A, torch.zeros_like(local))
-        k_anchor = ka if k_anchor is None else k_anchor + ka
     wperm = (0, 2, 3, 1) if dim == 2 else (0, 2, 3, 4, 1)
     w = conv.weight.permute(*wperm).reshape(conv.out_channels, T * C)          # (tap, channel) order of the patches
     h = F.linear(patches.reshape(S, T * C), w, conv.bias)
