@@ -554,6 +554,7 @@ def main():
     ap.add_argument("--res-tap", type=int, default=1, help="1 (default): identity ResBlocks produce their input gradient already added to the residual gradient (utils/fused_epilogue._Conv1x1ResTap, csrc/epilogue.hip); 0: conv backward + autograd's accumulation pass (A/B)")
     ap.add_argument("--head-as-linear", type=int, default=1, help="1 (default): the classifier head's full-extent / 1x1x1 convolutions as GEMMs (models/mrcnn.py Classifier); 0: MIOpen convolutions (A/B)")
     ap.add_argument("--merge-rpn-heads", type=int, default=1, help="1 (default): conv_class and conv_bbox of the RPN as one 1x1 convolution over the shared 128-channel map (models/mrcnn.py RPN); 0: two layers (A/B)")
+    ap.add_argument("--upsample-nearest-cl", type=int, default=1, help="1 (default): the FPN's nearest x2 up-sampling on channels-last storage (utils/fused_epilogue._UpsampleNearestCL); 0: F.interpolate with its layout conversions (A/B)")
     ap.add_argument("--stride-tap", type=int, default=1, help="1 (default): a stage output is sub-sampled once for the two strided 1x1 layers of the next stage and the three gradients meet in one node (utils/fused_epilogue._StrideTap); 0: three autograd consumers (A/B)")
     ap.add_argument("--sparse-rpn-loss", type=int, default=1, help="1 (default): the RPN losses differentiate through the 48 sampled anchors only (models/mrcnn.rpn_at_anchors; the dense RPN forward carries no graph); 0: through the dense outputs like the reference (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
@@ -610,6 +611,7 @@ def main():
     fused_epilogue.CONV3_SMALL = bool(args.conv3_small)
     fused_epilogue.RES_TAP = bool(args.res_tap)
     fused_epilogue.STRIDE_TAP = bool(args.stride_tap)
+    fused_epilogue.UPSAMPLE_NEAREST_CL = bool(args.upsample_nearest_cl)
     fused_epilogue.CONV3_SMALL_EPILOGUE = bool(args.conv3_small_epilogue)
     fused_epilogue.STEM_WGRAD = bool(args.stem_wgrad)
     fused_epilogue.STEM_FWD = bool(args.stem_fwd)

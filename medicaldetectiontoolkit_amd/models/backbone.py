@@ -148,12 +148,12 @@ class FPN(nn.Module):
         if self.sixth_pooling:
             c6_out, c5_out = self._stage(self.C6, c5_out)
             p6_pre_out = self.P6_conv1(c6_out)
-            p5_pre_out = _lateral(self.P5_conv1, c5_out, F.interpolate(p6_pre_out, scale_factor=2))
+            p5_pre_out = _lateral(self.P5_conv1, c5_out, fused_epilogue.upsample_nearest(p6_pre_out, 2))
         else:
             p5_pre_out = self.P5_conv1(c5_out)
-        p4_pre_out = _lateral(self.P4_conv1, c4_out, F.interpolate(p5_pre_out, scale_factor=2))
-        p3_pre_out = _lateral(self.P3_conv1, c3_out, F.interpolate(p4_pre_out, scale_factor=2))
-        p2_pre_out = _lateral(self.P2_conv1, c2_out, F.interpolate(p3_pre_out, scale_factor=2))
+        p4_pre_out = _lateral(self.P4_conv1, c4_out, fused_epilogue.upsample_nearest(p5_pre_out, 2))
+        p3_pre_out = _lateral(self.P3_conv1, c3_out, fused_epilogue.upsample_nearest(p4_pre_out, 2))
+        p2_pre_out = _lateral(self.P2_conv1, c2_out, fused_epilogue.upsample_nearest(p3_pre_out, 2))
         out_list = [self.P2_conv2(p2_pre_out), self.P3_conv2(p3_pre_out), self.P4_conv2(p4_pre_out), self.P5_conv2(p5_pre_out)]
         if self.sixth_pooling:
             out_list.append(self.P6_conv2(p6_pre_out))

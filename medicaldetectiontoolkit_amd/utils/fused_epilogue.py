@@ -595,6 +595,61 @@ def conv_bias_relu_with_res_tap(seq, x):
 
 
 STRIDE_TAP = True   # module switch (A/B: bench.py --stride-tap 0)
+UPSAMPLE_NEAREST_CL = True   # module switch (A/B: bench.py --upsample-nearest-cl 0)
+
+
+class _UpsampleNearestCL(Function):
+    """Nearest-neighbour up-sampling by an integer factor per axis ON channels-last storage (the FPN's top-down path,
+    models/backbone.py:147-153: F.interpolate(p, scale_factor=2)).  torch's nearest kernels for 5-D tensors are row-major only: a
+    channels-last input is converted, the row-major result is converted back in front of the lateral's fused add (151 MB copies on P2 at
+    8 x 128^3), and the backward makes the same two conversions.  In channels-last memory the operation is a broadcast of whole C-rows:
+    forward = ONE expanding copy, backward = ONE strided sum over the s_y x s_x x s_z replicas; no layout change either way."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        nd = x.dim() - 2
+        ctx.scale = scale
+        ctx.in_shape = tuple(x.shape)
+        perm = (0,) + tuple(range(2, 2 + nd)) + (1,)
+        xv = x.permute(*perm)                                        # [B, *spatial, C], contiguous for channels-last x
+        B, C = x.shape[0], x.shape[1]
+        idx, exp, outsp = [slice(None)], [B], []
+        for d in range(nd):
+            idx += [slice(None), None]
+            exp += [x.shape[2 + d], scale[d]]
+            outsp.append(x.shape[2 + d] * scale[d])
+        idx.append(slice(None))
+        exp.append(C)
+        out = xv[tuple(idx)].expand(*exp).reshape(B, *outsp, C)       # the one copy
+        inv = (0, nd + 1) + tuple(range(1, nd + 1))
+        return out.permute(*inv)
+
+    @staticmethod
+    def backward(ctx, g):
+        nd = len(ctx.in_shape) - 2
+        mf = torch.channels_last_3d if nd == 3 else torch.channels_last
+        if not g.is_contiguous(memory_format=mf):
+            g = g.contiguous(memory_format=mf)
+        perm = (0,) + tuple(range(2, 2 + nd)) + (1,)
+        B, C = ctx.in_shape[0], ctx.in_shape[1]
+        shp, red = [B], []
+        for d in range(nd):
+            shp += [ctx.in_shape[2 + d], ctx.scale[d]]
+            red.append(2 + 2 * d)
+        gs = g.permute(*perm).reshape(*shp, C).sum(tuple(red))        # [B, *spatial_in, C]
+        inv = (0, nd + 1) + tuple(range(1, nd + 1))
+        return gs.permute(*inv), None
+
+
+def upsample_nearest(x, scale_factor):
+    """F.interpolate(x, scale_factor=s) (mode 'nearest') -- on channels-last storage without layout changes where that applies"""
+    nd = x.dim() - 2
+    sc = tuple(scale_factor) if isinstance(scale_factor, (tuple, list)) else (scale_factor,) * nd
+    mf = torch.channels_last_3d if nd == 3 else torch.channels_last if nd == 2 else None
+    if ENABLED and UPSAMPLE_NEAREST_CL and mf is not None and all(float(v) == int(v) and int(v) >= 1 for v in sc) and x.is_contiguous(memory_format=mf) \
+            and not x.is_contiguous() and not torch.is_autocast_enabled():
+        return _UpsampleNearestCL.apply(x, tuple(int(v) for v in sc))
+    return F.interpolate(x, scale_factor=scale_factor)
 
 
 class _StrideTap(Function):

@@ -265,3 +265,29 @@ def test_stride_tap_equals_three_consumers_of_a_stage_output_in_float64():
         x_lat, _ = fe.stride_tap(x * 1.0, (2,) * dim)
         (x_lat * 3.0).sum().backward()
         assert torch.equal(x.grad, torch.full_like(x0, 3.0))
+
+
+def test_channels_last_nearest_upsampling_equals_f_interpolate():
+    """utils/fused_epilogue.upsample_nearest (channels-last broadcast copy forward, strided sum over the replicas backward: the FPN's
+    top-down path without the two layout conversions torch's row-major nearest kernels need) == F.interpolate(mode='nearest') bit for
+    bit forward, 1e-14 backward (float64), result and gradient channels-last; factors 2, (2, 2, 1), 3; 2D and 3D; row-major input
+    falls through to F.interpolate"""
+    import torch.nn.functional as F
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+    torch.manual_seed(0)
+    for shape, sc in (((2, 5, 3, 4, 6), 2), ((1, 3, 2, 2, 5), (2, 2, 1)), ((2, 5, 3, 4), 2), ((2, 4, 3, 3, 2), 3)):
+        mf = torch.channels_last_3d if len(shape) == 5 else torch.channels_last
+        x0 = torch.randn(shape, dtype=torch.float64).contiguous(memory_format=mf)
+        res = []
+        for own in (False, True):
+            x = x0.clone().requires_grad_(True)
+            h = x * 1.0
+            y = fe.upsample_nearest(h, sc) if own else F.interpolate(h, scale_factor=sc)
+            assert not own or y.is_contiguous(memory_format=mf)
+            w = torch.randn(y.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+            (y * w).sum().backward()
+            res.append((y.detach(), x.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0])
+        assert float((res[0][1] - res[1][1]).abs().max()) < 1e-13 and res[1][1].is_contiguous(memory_format=mf)
+    xr = torch.randn(2, 5, 3, 4, 6)
+    assert torch.equal(fe.upsample_nearest(xr, 2), F.interpolate(xr, scale_factor=2))

@@ -77,5 +77,15 @@ def main():
                                                               int(r["LDS_Block_Size"]), kind, re.sub(r"\(anonymous namespace\)::|void ", "", n)[:48]))
 
 
+    print("# last step in time order: every OTHER launch >= 40 us:  t_ms  us  threads  name")
+    for r in last:
+        n = r["Kernel_Name"]
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        is_conv = n.startswith("ck::") or n.startswith("_ZN2ck") or "Cijk_" in n or "conv" in n.lower()
+        if not is_conv and d >= 40:
+            g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            print("{:8.2f} {:8.1f} {:9d}  {}".format((int(r["Start_Timestamp"]) - t0) / 1e6, d, g, short(n)[:100]))
+
+
 if __name__ == "__main__":
     main()
