@@ -540,6 +540,7 @@ def main():
     ap.add_argument("--graph-preflight", type=str, default="", help=argparse.SUPPRESS)
     ap.add_argument("--device-index", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-eager-leg", action="store_true", help="skip the eager A/B steps after the timed loop")
+    ap.add_argument("--no-dense-rpn-leg", action="store_true", help="skip the A/B steps with the RPN losses differentiated through the dense RPN outputs")
     ap.add_argument("--no-exec-leg", action="store_true", help="skip the exec.py-equivalent leg (host batches + monitoring read-out + mask head over detections)")
     ap.add_argument("--fused-adam", type=int, default=0)
     ap.add_argument("--flat-adam", type=int, default=1, help="1 (default): training.FlatAdam -- parameters, gradients and Adam moments in flat buffers, the update one launch of csrc/adam.hip; 0: torch.optim.Adam (A/B)")
@@ -711,6 +712,26 @@ def main():
         eager_rec = {"value": round(args.batch * world * n_ab / te, 3), "unit": "patches/s", "steps": n_ab, "ms_per_step": round(te / n_ab * 1e3, 2),
                      "host_issue_ms_per_step": round(th_e / n_ab * 1e3, 2),
                      "note": "training.train_step: the same step with every kernel launched eagerly"}
+    # ---- the same step with the RPN losses differentiated through the DENSE RPN outputs, as the reference's autograd graph does
+    # (mrcnn.py:176-240 on the outputs of :987-1003): identical gradients (tests/test_models_gpu.py::test_sparse_rpn_loss_step_equals_
+    # dense_graph_step), 6.6 ms more convolution work on zeros -- reported beside `value` so that the gain of the sampled-anchor form is visible
+    dense_rpn_rec = None
+    if args.model == "mrcnn" and not use_graph and args.sparse_rpn_loss and not args.no_dense_rpn_leg:
+        mrcnn.SPARSE_RPN_LOSS = False
+        try:
+            for i in range(3):
+                training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+            barrier()
+            td = time.time()
+            for i in range(n_ab):
+                training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+            barrier()
+            td = time.time() - td
+            dense_rpn_rec = {"value": round(args.batch * world * n_ab / td, 3), "unit": "patches/s", "steps": n_ab, "ms_per_step": round(td / n_ab * 1e3, 2),
+                             "note": "same net / optimizer / batches with --sparse-rpn-loss 0: RPN losses differentiated through the dense RPN outputs like the "
+                                     "reference's graph (same gradients; the dense graph back-propagates zeros through conv_shared on every level)"}
+        finally:
+            mrcnn.SPARSE_RPN_LOSS = True
     child_legs = None
     if not use_graph and args.model == "mrcnn" and not args.no_graph_leg and rank == 0 and world == 1:
         ok, note, child_legs = _graph_preflight(args, local_dev, legs=True)      # all graph work of an eager line: in a child process
@@ -807,7 +828,7 @@ def main():
                            "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),
                        "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over %s)" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "global_batch": args.batch * world},
-            "graph": graph_rec, "eager_step": eager_rec, "graphed_step": graphed_rec, "exec_equivalent": exec_eq,
+            "graph": graph_rec, "eager_step": eager_rec, "graphed_step": graphed_rec, "dense_rpn_graph_step": dense_rpn_rec, "exec_equivalent": exec_eq,
             "roofline": roofline, "cpu_baseline": cpu, "h2d_inclusive": h2d, "distributed": dist_rec,
         }
         if world == 1 and not args.no_rccl_selftest:
