@@ -2,6 +2,7 @@
 models/backbone.py (FPN :22-179, ResBlock :183-206, Interpolate :209-217) so its checkpoints load;
 the convolutions run on MIOpen through torch (the north star leaves the conv path on MIOpen).
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -139,7 +140,19 @@ class FPN(nn.Module):
         return seq(x), x
 
     def forward(self, x):
-        c0_out = self.C0(x) if self.operate_stride1 else x
+        if self.operate_stride1:
+            # a ONE-channel image is "contiguous" in both layouts, so MIOpen returns C0[0]'s 18-channel output row-major even in a
+            # channels-last net -- and C0[1] (18 -> 18 on the full-resolution volume, the most expensive layer of the Retina U-Net step)
+            # then misses this repo's few-channel MFMA kernel (channels-last only) and runs on MIOpen's row-major path at 7 TF/s
+            # (39.6 ms forward, 57.9 + 45.8 ms backward at 8 x 128^3; profiles/r04/r04_step_launch_by_launch_retina_unet.txt)
+            h = self.C0[0](x)
+            w1 = self.C0[1][0].weight if isinstance(self.C0[1], nn.Sequential) else self.C0[1].weight
+            mf = torch.channels_last_3d if h.dim() == 5 else torch.channels_last
+            if w1.is_contiguous(memory_format=mf) and not w1.is_contiguous() and not h.is_contiguous(memory_format=mf):
+                h = h.contiguous(memory_format=mf)
+            c0_out = self.C0[1](h)
+        else:
+            c0_out = x
         c1_out = self.C1(c0_out)
         c2_out = self.C2(c1_out)
         c3_out, c2_out = self._stage(self.C3, c2_out)
