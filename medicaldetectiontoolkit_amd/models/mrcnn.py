@@ -713,7 +713,7 @@ class net(nn.Module):
         # the RoIAlign kernels read [B, C, spatial] row-major maps: convert a channels-last map ONCE per forward (every head
         # call would otherwise re-copy all levels, and the heads' gradients would meet in mixed layouts)
         self.mrcnn_feature_maps = [m.contiguous() for m in rpn_feature_maps]
-        self.rpn_feature_maps = rpn_feature_maps
+        self.rpn_feature_maps = rpn_feature_maps if is_training else None       # read by rpn_at_anchors, released after the RPN losses
         with torch.set_grad_enabled(rpn_graph and torch.is_grad_enabled()):
             layer_outputs = [self.rpn(p) for p in rpn_feature_maps]
             rpn_pred_logits, rpn_pred_probs, rpn_pred_deltas = [torch.cat(list(o), dim=1) for o in zip(*layer_outputs)]
