@@ -827,7 +827,11 @@ def main():
             "config": {"workload": "LIDC-shape 3D %s, %s fp32 patches, batch %d per GPU, random-init weights, Adam lr 1e-4" % (
                            "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),
                        "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over %s)" % (world, "RCCL" if args.backend == "nccl" else args.backend),
-                       "global_batch": args.batch * world},
+                       "global_batch": args.batch * world,
+                       "step_form": ("forward + backward + Adam of exec.py:68-74, every loss term and every parameter gradient of the reference step "
+                                     "(tests/test_step_parity_gpu.py pins them against the reference at this configuration); RPN losses back-propagated "
+                                     + ("through the sampled anchors only (same gradients as the dense graph, which is timed as dense_rpn_graph_step)"
+                                        if (args.model == "mrcnn" and args.sparse_rpn_loss) else "through the dense RPN outputs"))},
             "graph": graph_rec, "eager_step": eager_rec, "graphed_step": graphed_rec, "dense_rpn_graph_step": dense_rpn_rec, "exec_equivalent": exec_eq,
             "roofline": roofline, "cpu_baseline": cpu, "h2d_inclusive": h2d, "distributed": dist_rec,
         }

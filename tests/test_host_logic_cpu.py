@@ -291,3 +291,46 @@ def test_channels_last_nearest_upsampling_equals_f_interpolate():
         assert float((res[0][1] - res[1][1]).abs().max()) < 1e-13 and res[1][1].is_contiguous(memory_format=mf)
     xr = torch.randn(2, 5, 3, 4, 6)
     assert torch.equal(fe.upsample_nearest(xr, 2), F.interpolate(xr, scale_factor=2))
+
+
+def test_rpn_losses_through_sampled_anchors_equal_the_dense_graph_losses():
+    """models/mrcnn.compute_rpn_losses with sparse_eval = rpn_at_anchors (dense RPN outputs detached: they only rank and select) ==
+    the same function on the dense RPN graph (mrcnn.py:176-240 on the outputs of :987-1003): class loss, box loss, the sampled
+    anchors, and the gradients w.r.t. every pyramid map and every RPN parameter; float64, same generator seed for the random keys"""
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from medicaldetectiontoolkit_amd.models import mrcnn
+    from medicaldetectiontoolkit_amd.utils import model_utils as mutils
+    torch.manual_seed(1)
+    dim, B = 3, 2
+    cf = Configs(dim=dim, model="mrcnn", patch_size=[32, 32, 32], batch_size=B)
+    sizes = [(8, 8, 16), (4, 4, 8), (2, 2, 4), (1, 1, 2)]
+    rpn = mrcnn.RPN(cf, mutils.NDConvGenerator(dim)).double()
+    n_apv = len(cf.rpn_anchor_ratios)
+    A = n_apv * sum(int(np.prod(s)) for s in sizes)
+    anchors = torch.rand(A, 2 * dim, dtype=torch.float64) * 10
+    anchors[:, [2, 3, 5]] = anchors[:, [0, 1, 4]] + 4 + torch.rand(A, 3, dtype=torch.float64) * 8
+    match = torch.full((B, A), 0, dtype=torch.int32)
+    match[:, ::7] = -1
+    match[0, [5, 700, A - 1]] = 1
+    match[1, [3 * int(np.prod(sizes[0])), 11]] = 1
+    argmax = torch.zeros((B, A), dtype=torch.int32)
+    gt = [np.array([[2.0, 3.0, 14.0, 12.0, 1.0, 9.0]]), np.array([[1.0, 1.0, 9.0, 7.0, 2.0, 8.0]])]
+    res = []
+    for sparse in (False, True):
+        maps = [torch.randn((B, cf.end_filts) + s, dtype=torch.float64, generator=torch.Generator().manual_seed(7 + i))
+                .contiguous(memory_format=torch.channels_last_3d).requires_grad_(True) for i, s in enumerate(sizes)]
+        rpn.zero_grad()
+        with torch.set_grad_enabled(not sparse):
+            outs = [rpn(m) for m in maps]
+            logits, deltas = torch.cat([o[0] for o in outs], 1), torch.cat([o[2] for o in outs], 1)
+        ev = (lambda idx: mrcnn.rpn_at_anchors(rpn, maps, idx, n_apv)) if sparse else None
+        gen = torch.Generator().manual_seed(3)
+        cl, bl, samples = mrcnn.compute_rpn_losses(match, argmax, logits, deltas, anchors, gt, cf, generator=gen, sparse_eval=ev)
+        (cl + 2.0 * bl).backward()
+        res.append((float(cl), float(bl), [t.clone() for t in samples], [m.grad.clone() for m in maps] + [p.grad.clone() for p in rpn.parameters()]))
+    (ca, ba, sa, ga), (cb, bb, sb, gb) = res
+    assert abs(ca - cb) < 1e-12 and abs(ba - bb) < 1e-12 and ca > 0 and ba > 0
+    assert all(torch.equal(a, b) for a, b in zip(sa, sb)) and int(sa[1].sum()) == 5
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(a.abs().max()))
+    assert any(float(g.abs().max()) > 0 for g in ga[:4])
