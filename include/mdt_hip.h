@@ -257,6 +257,13 @@ int mdt_nms_mask_3d(const float *dets_sorted, int n, float thresh, int rule,
                     unsigned long long *mask, void *stream);
 int mdt_nms_mask_2d(const float *dets_sorted, int n, float thresh, int rule,
                     unsigned long long *mask, void *stream);
+/* the same mask INCLUDING the blocks below the diagonal, word for word what the reference kernel writes (its early-out
+ * `if (row_start > col_start) return;` is commented out, nms_kernel.cu:35): in a lower block, bit j of word (i, c) is set
+ * iff IoU(box i, box 64c+j) passes the rule.  This is what the link-compatible `_nms` of include/mdt_launchers.h runs. */
+int mdt_nms_mask_full_3d(const float *dets_sorted, int n, float thresh, int rule,
+                         unsigned long long *mask, void *stream);
+int mdt_nms_mask_full_2d(const float *dets_sorted, int n, float thresh, int rule,
+                         unsigned long long *mask, void *stream);
 
 /*
  * Device-resident NMS.  Replaces gpu_nms

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "mdt_bias_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_size_t, c_void_p]),
     "mdt_nms_mask_3d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdt_nms_mask_2d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "mdt_nms_mask_full_3d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "mdt_nms_mask_full_2d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdt_nms_workspace_bytes": (c_size_t, [c_int]),
     "mdt_nms_3d": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_nms_2d": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -83,7 +83,10 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
     mask += (long long)blockIdx.z * (block_major ? (long long)col_blocks * col_blocks * 64 : (long long)n * col_blocks);
 
     const int row_idx = row_start * 64 + lane;
-    if (row_start > col_start) {
+    // fill_lower: 0 = leave the blocks below the diagonal untouched, 1 = write them as zero, 2 = compute them like the
+    // reference kernel does (its early-out is commented out, nms_kernel.cu:35; its host scan never reads them, nms_cuda.c:54)
+    const bool lower_block = row_start > col_start;
+    if (lower_block && fill_lower != 2) {
         if (fill_lower && row_idx < n) mask[(long long)row_idx * col_blocks + col_start] = 0ULL;
         return;
     }
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
         // diagonal blocks hold the SYMMETRIC relation (the IoU is bitwise symmetric), which lets the scan kernel
         // resolve a block with ballots instead of a 64-step serial loop.
         const int row_g = row_start * 64 + i;
-        pred = pred && (col_idx < n) && (block_major ? (col_idx != row_g) : (col_idx > row_g));
+        pred = pred && (col_idx < n) && (block_major ? (col_idx != row_g) : (lower_block || col_idx > row_g));
         const u64 bal = __ballot(pred);
         if (lane == i) word = bal;
     }
@@ -320,6 +323,20 @@ int mdt_nms_mask_2d(const float *dets_sorted, int n, float thresh, int rule, uns
     if (n < 0) return MDT_ERR_INVALID_ARGUMENT;
     if (n == 0) return MDT_OK;
     return launch_mask<5>(dets_sorted, 1, n, thresh, rule, 1, 0, mask, (hipStream_t)stream);
+}
+
+int mdt_nms_mask_full_3d(const float *dets_sorted, int n, float thresh, int rule, unsigned long long *mask, void *stream)
+{
+    if (n < 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return MDT_OK;
+    return launch_mask<7>(dets_sorted, 1, n, thresh, rule, 2, 0, mask, (hipStream_t)stream);
+}
+
+int mdt_nms_mask_full_2d(const float *dets_sorted, int n, float thresh, int rule, unsigned long long *mask, void *stream)
+{
+    if (n < 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return MDT_OK;
+    return launch_mask<5>(dets_sorted, 1, n, thresh, rule, 2, 0, mask, (hipStream_t)stream);
 }
 
 int mdt_nms_3d(const float *dets_sorted, int n, float thresh, int rule, int max_keep,

@@ -33,6 +33,37 @@ def test_workspace_queries_need_no_gpu():
     assert L.mdt_wbc_workspace_bytes(45000, 1500) >= 45000 + 1500 * 4
 
 
+def test_launcher_libraries_export_the_reference_names_with_the_reference_prototypes():
+    """libmdt_launchers_{2,3}d.so (include/mdt_launchers.h): `_nms`, `CropAndResizeLaucher`, `CropAndResizeBackpropImageLaucher` resolve, and
+    the header's prototypes are token for token the reference's (nms_kernel.h:11-12, crop_and_resize_kernel.h:8-18) with hipStream_t
+    for cudaStream_t -- checked against the reference headers when the checkout is present (build container)"""
+    import ctypes
+    import re
+    from medicaldetectiontoolkit_amd import _lib
+    _lib.lib()
+    for dim in (2, 3):
+        L = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libmdt_launchers_%dd.so" % dim))
+        for name in ("_nms", "CropAndResizeLaucher", "CropAndResizeBackpropImageLaucher"):
+            assert getattr(L, name) is not None
+
+    def protos(text):
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        return {m.group(1): re.sub(r"\s+", " ", m.group(2)).strip().replace(" * ", " *").replace("* ", "*")
+                for m in re.finditer(r"void\s+(_nms|CropAndResizeLaucher|CropAndResizeBackpropImageLaucher)\s*\(([^;{]*?)\)\s*;", text, re.S)}
+    mine = open(os.path.join(ROOT, "include", "mdt_launchers.h")).read()
+    pre, rest = mine.split("#if MDT_LAUNCHERS_DIM == 3")
+    d3, d2 = rest.split("#else")
+    ref = "/root/reference/cuda_functions"
+    if os.path.isdir(ref):
+        for dim, body in ((3, d3), (2, d2)):
+            got = dict(protos(pre), **protos(body))
+            want = dict(protos(open("%s/nms_%dD/src/cuda/nms_kernel.h" % (ref, dim)).read()),
+                        **protos(open("%s/roi_align_%dD/roi_align/src/cuda/crop_and_resize_kernel.h" % (ref, dim)).read()))
+            assert set(got) == set(want) == {"_nms", "CropAndResizeLaucher", "CropAndResizeBackpropImageLaucher"}
+            for k in want:
+                assert got[k] == want[k].replace("cudaStream_t", "hipStream_t"), (dim, k, got[k], want[k])
+
+
 def test_dropin_import_paths():
     import medicaldetectiontoolkit_amd as m
     m.install_dropin()

@@ -322,6 +322,107 @@ def test_nms3d_mask_vs_reference_cuda_kernel_on_gpu(cuda):
     assert np.all(mine[~upper] == 0)
 
 
+# ------------------------------------------------------------------ link-compatible launcher names (include/mdt_launchers.h)
+def _launchers(dim):
+    """libmdt_launchers_{2,3}d.so: the reference's `_nms` / `CropAndResizeLaucher` / `CropAndResizeBackpropImageLaucher` names and
+    prototypes (nms_kernel.h:11-12, crop_and_resize_kernel.h:8-18) over libmdt_hip.so"""
+    _lib.lib()
+    p = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmdt_launchers_%dd.so" % dim)
+    assert os.path.exists(p), "%s missing: make -C medicaldetectiontoolkit_amd/csrc" % p
+    return ctypes.CDLL(p)
+
+
+def test_launcher_names_3d_same_argument_lists_as_the_reference_objects(cuda):
+    """the very calls made on oracle/_ref/libref_gpu_{roialign3d,nms3d}.so above, made on libmdt_launchers_3d.so: forward bit-exact vs
+    the oracle and <= 1e-4 vs the reference object, backward within the default kernel's bar, mask words == the reference kernel's
+    INCLUDING the blocks below the diagonal"""
+    R, Rn, M = _ref_gpu("libref_gpu_roialign3d.so"), _ref_gpu("libref_gpu_nms3d.so"), _launchers(3)
+    rng = np.random.default_rng(21)
+    vp = ctypes.c_void_p
+    for (B, C, Y, X, Z, N, crop) in [(4, 8, 16, 16, 32, 64, (7, 7, 3)), (2, 4, 16, 16, 16, 200, (7, 7, 3))]:   # second: N > 128 (exact-order fallback)
+        image = torch.randn(B, C, Y, X, Z, device=cuda)
+        boxes_np = random_boxes_3d(rng, N, spill=True)
+        ind_np = rng.integers(0, B, size=N).astype(np.int32)
+        boxes, box_ind = _t(boxes_np, cuda), _t(ind_np, cuda)
+        ref = torch.zeros(N, C, *crop, device=cuda)
+        got = torch.full((N, C) + crop, 7.0, device=cuda)          # NOT pre-cleared: the launcher writes every row
+        torch.cuda.synchronize()
+        for L, out in ((R, ref), (M, got)):
+            L.CropAndResizeLaucher(vp(image.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X, Z,
+                                   crop[0], crop[1], crop[2], C, ctypes.c_float(0), vp(out.data_ptr()), vp(0))
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), oracle.crop_and_resize_forward(image.cpu().numpy(), boxes_np, ind_np, crop))
+        assert (got - ref).abs().max().item() <= TOL
+        g = torch.randn_like(ref)
+        ref_g = torch.zeros_like(image)
+        got_g = torch.full_like(image, 3.0)
+        torch.cuda.synchronize()
+        for L, out in ((R, ref_g), (M, got_g)):
+            L.CropAndResizeBackpropImageLaucher(vp(g.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X, Z,
+                                                crop[0], crop[1], crop[2], C, vp(out.data_ptr()), vp(0))
+        torch.cuda.synchronize()
+        assert ((got_g - ref_g).abs() <= TOL * ref_g.abs().clamp(min=1.0)).all()
+        want_g = oracle.crop_and_resize_backward(g.cpu().numpy(), boxes_np, ind_np, tuple(image.shape))
+        scale = np.maximum(1.0, oracle.crop_and_resize_backward(np.abs(g.cpu().numpy()), boxes_np, ind_np, tuple(image.shape)))
+        assert np.all(np.abs(got_g.cpu().numpy() - want_g) <= FAST_TOL * scale)
+    for n in (1, 64, 65, 1000):
+        dets = nms_boxes(rng, n)
+        ds = _t(dets[oracle.sort_order(dets[:, -1])], cuda)
+        cb = (n + 63) // 64
+        ref = torch.zeros(n, cb, dtype=torch.int64, device=cuda)
+        mine = torch.full((n, cb), -1, dtype=torch.int64, device=cuda)
+        torch.cuda.synchronize()
+        Rn._nms(n, vp(ds.data_ptr()), vp(ref.data_ptr()), ctypes.c_float(0.7))
+        M._nms(n, vp(ds.data_ptr()), vp(mine.data_ptr()), ctypes.c_float(0.7))
+        torch.cuda.synchronize()
+        diff = np.unpackbits((ref.cpu().numpy() ^ mine.cpu().numpy()).view(np.uint8)).sum()
+        assert diff <= 1e-5 * n * cb * 64, (n, diff)          # contraction in the reference object may flip a pair at the threshold
+        # and word for word the oracle's (uncontracted) full mask, blocks below the diagonal included
+        assert np.array_equal(mine.cpu().numpy().view(np.uint64), oracle.nms_mask(ds.cpu().numpy(), 0.7)), n
+
+
+def test_launcher_names_2d_same_argument_lists_as_the_reference_objects(cuda):
+    R, Rn, M = _ref_gpu("libref_gpu_roialign2d.so"), _ref_gpu("libref_gpu_nms2d.so"), _launchers(2)
+    rng = np.random.default_rng(22)
+    vp = ctypes.c_void_p
+    B, C, Y, X, N, crop = 4, 16, 72, 72, 60, (7, 7)
+    image = torch.randn(B, C, Y, X, device=cuda)
+    boxes_np = random_boxes_2d(rng, N, patch=288.0, size=(8, 128), spill=True)
+    ind_np = rng.integers(0, B, size=N).astype(np.int32)
+    boxes, box_ind = _t(boxes_np, cuda), _t(ind_np, cuda)
+    ref = torch.zeros(N, C, *crop, device=cuda)
+    got = torch.full((N, C) + crop, 7.0, device=cuda)
+    torch.cuda.synchronize()
+    for L, out in ((R, ref), (M, got)):
+        L.CropAndResizeLaucher(vp(image.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X,
+                               crop[0], crop[1], C, ctypes.c_float(0), vp(out.data_ptr()), vp(0))
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), oracle.crop_and_resize_forward(image.cpu().numpy(), boxes_np, ind_np, crop))
+    assert (got - ref).abs().max().item() <= TOL
+    g = torch.randn_like(ref)
+    ref_g = torch.zeros_like(image)
+    got_g = torch.full_like(image, 3.0)
+    torch.cuda.synchronize()
+    for L, out in ((R, ref_g), (M, got_g)):
+        L.CropAndResizeBackpropImageLaucher(vp(g.data_ptr()), vp(boxes.data_ptr()), vp(box_ind.data_ptr()), N, B, Y, X,
+                                            crop[0], crop[1], C, vp(out.data_ptr()), vp(0))
+    torch.cuda.synchronize()
+    assert ((got_g - ref_g).abs() <= TOL * ref_g.abs().clamp(min=1.0)).all()
+    n = 1000
+    dets = nms_boxes(rng, n, dim=2, patch=320.0)
+    ds = _t(dets[oracle.sort_order(dets[:, -1])], cuda)
+    cb = (n + 63) // 64
+    ref = torch.zeros(n, cb, dtype=torch.int64, device=cuda)
+    mine = torch.full((n, cb), -1, dtype=torch.int64, device=cuda)
+    torch.cuda.synchronize()
+    Rn._nms(n, vp(ds.data_ptr()), vp(ref.data_ptr()), ctypes.c_float(0.7))
+    M._nms(n, vp(ds.data_ptr()), vp(mine.data_ptr()), ctypes.c_float(0.7))
+    torch.cuda.synchronize()
+    diff = np.unpackbits((ref.cpu().numpy() ^ mine.cpu().numpy()).view(np.uint8)).sum()
+    assert diff <= 1e-5 * n * cb * 64
+    assert np.array_equal(mine.cpu().numpy().view(np.uint64), oracle.nms_mask(ds.cpu().numpy(), 0.7))
+
+
 # ------------------------------------------------------------------ NMS
 @pytest.mark.parametrize("dim", [2, 3])
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 6000])
