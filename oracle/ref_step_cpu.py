@@ -1,0 +1,145 @@
+"""TEST / BASELINE INFRASTRUCTURE (like everything under oracle/): the REFERENCE's own training step on the HOST CPU, timed.
+
+    python oracle/ref_step_cpu.py [--patch 128,128,128] [--batch 8] [--model mrcnn] [--threads N]
+
+Runs `net.train_forward(batch)` + `zero_grad()` + `backward()` + `torch.optim.Adam.step()` (exec.py:39,68-74) of the reference's
+UNMODIFIED models/mrcnn.py (or retina_unet.py) on torch-CPU, on one full synthetic batch of the benchmarked configuration, and prints
+one JSON line with the wall time.  This is `cpu_baseline.kind = "reference"` of bench.py (VERDICT r4 "What's weak" 4: the round-4
+baseline was a one-patch port and 4-8x too pessimistic).
+
+Where the reference comes from: oracle/_ref/py/ (verbatim copies made by `make -C oracle _ref_py`, shipped to the GPU box with the
+snapshot) or, in the build container, /root/reference itself.  What stands in for the four cuda_functions extensions -- CUDA-only
+in the reference ("the 3D CPU RoIAlign does not exist") -- is the CPU oracle (oracle/mdt_oracle.c: OpenMP over
+boxes, the reference's own CPU strategy, crop_and_resize.c:30), exactly as in tests/golden/make_step_golden.py; `Tensor.cuda()` is the
+identity and integer `/` floor-divides (torch 0.4.1).  bench.py runs this file in a CHILD process (the `.cuda()` patch must never
+reach the process that measures the GPU) with the GPU hidden.
+"""
+import argparse
+import importlib.util
+import json
+import logging
+import os
+import sys
+import time
+import types
+import warnings
+
+warnings.filterwarnings("ignore")
+os.environ.setdefault("HIP_VISIBLE_DEVICES", "")      # nothing here may touch a GPU
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import oracle  # noqa: E402
+
+
+def nms_gpu(dets, thresh):
+    keep = oracle.gpu_nms(dets.detach().numpy().astype(np.float32), float(thresh), True)
+    return torch.from_numpy(np.asarray(keep, dtype=np.int64))
+
+
+class _OracleCrop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, boxes, box_ind, crop):
+        img = image.detach().numpy().astype(np.float32)
+        while img.ndim > len(crop) + 2 and img.shape[-1] == 1:
+            img = img[..., 0]
+        bx = np.ascontiguousarray(boxes.detach().numpy().astype(np.float32))
+        bi = np.ascontiguousarray(box_ind.detach().numpy().astype(np.int32))
+        ctx.meta = (bx, bi, img.shape, tuple(image.shape))
+        return torch.from_numpy(oracle.crop_and_resize_forward(np.ascontiguousarray(img), bx, bi, crop))
+
+    @staticmethod
+    def backward(ctx, g):
+        bx, bi, shp, orig = ctx.meta
+        gi = oracle.crop_and_resize_backward(np.ascontiguousarray(g.detach().numpy().astype(np.float32)), bx, bi, shp)
+        return torch.from_numpy(gi).reshape(orig), None, None, None
+
+
+class CropAndResizeFunction(object):
+    def __init__(self, *args):
+        self.crop = tuple(int(a) for a in args[:-1])
+
+    def __call__(self, image, boxes, box_ind):
+        return _OracleCrop.apply(image, boxes, box_ind, self.crop)
+
+
+def _install():
+    for name in ["cuda_functions", "cuda_functions.nms_2D", "cuda_functions.nms_2D.pth_nms", "cuda_functions.nms_3D",
+                 "cuda_functions.nms_3D.pth_nms", "cuda_functions.roi_align_2D", "cuda_functions.roi_align_2D.roi_align",
+                 "cuda_functions.roi_align_2D.roi_align.crop_and_resize", "cuda_functions.roi_align_3D",
+                 "cuda_functions.roi_align_3D.roi_align", "cuda_functions.roi_align_3D.roi_align.crop_and_resize"]:
+        m = types.ModuleType(name)
+        m.nms_gpu = nms_gpu
+        m.CropAndResizeFunction = CropAndResizeFunction
+        sys.modules[name] = m
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    div0 = torch.Tensor.__truediv__
+
+    def div(a, b):
+        if not a.is_floating_point() and not (torch.is_tensor(b) and b.is_floating_point()) and not isinstance(b, float):
+            return torch.div(a, b, rounding_mode="floor")
+        return div0(a, b)
+    torch.Tensor.__truediv__ = div
+
+
+def _ref_dir():
+    for d in (os.path.join(HERE, "_ref", "py"), "/root/reference"):
+        if os.path.exists(os.path.join(d, "models", "mrcnn.py")):
+            return d
+    raise SystemExit("ref_step_cpu: no reference model files (oracle/_ref/py is made by `make -C oracle _ref_py` in the build container)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--patch", default="128,128,128")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--model", default="mrcnn", choices=["mrcnn", "retina_unet"])
+    ap.add_argument("--threads", type=int, default=0, help="torch intra-op / OpenMP threads (0 = all cores)")
+    ap.add_argument("--steps", type=int, default=1)
+    args = ap.parse_args()
+    threads = args.threads or (os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    _install()
+    ref = _ref_dir()
+    sys.path.insert(0, ref)
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref, path))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    mod = load("models/%s.py" % args.model, "ref_cpu_" + args.model)
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch
+    patch = [int(v) for v in args.patch.split(",")]
+    cf = Configs(dim=3, model=args.model, patch_size=patch, batch_size=args.batch)
+    cf.backbone_path = os.path.join(ref, "models/backbone.py")
+    log = logging.getLogger("ref_step_cpu")
+    log.addHandler(logging.NullHandler())
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = mod.net(cf, log)
+    opt = torch.optim.Adam(net.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay)      # exec.py:39
+    batches = [make_batch(patch, args.batch, seed=1000 + i) for i in range(args.steps)]
+    times = []
+    for b in batches:
+        t0 = time.time()
+        res = net.train_forward(b)                 # exec.py:68
+        opt.zero_grad()                            # :72
+        res["torch_loss"].backward()               # :73
+        opt.step()                                 # :74
+        times.append(time.time() - t0)
+    sec = float(np.mean(times))
+    print(json.dumps({"seconds_per_step": round(sec, 3), "patches_per_s": round(args.batch / sec, 4), "batch": args.batch, "patch": patch,
+                      "threads": int(threads), "steps": args.steps, "model": args.model, "loss": float(res["torch_loss"].item()),
+                      "logger_string": res["logger_string"], "reference_files": ref}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,7 @@
 """CPU tests: pin the oracle (oracle/mdt_oracle.c) against independent statements of the same rule
 and against the reference's own nms.c compiled where it lies (oracle/_ref)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -135,7 +137,10 @@ def test_oracle_cpu_nms_equals_reference_nms_c(dim, n):
     """oracle/_ref/libref_nms*.so is the reference's own nms.c (compiled by oracle/Makefile)."""
     name = "libref_nms3d.so" if dim == 3 else "libref_nms2d.so"
     if not oracle.ref_available(name):
-        pytest.skip("oracle/_ref not built (needs /root/reference)")
+        if os.path.isdir("/root/reference/cuda_functions"):      # a skip would read as green: with the checkout present the object must exist
+            pytest.fail("oracle/_ref/%s is missing although /root/reference is present: run `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (make -C oracle _ref)" % name)
+        pytest.skip("oracle/_ref not built and no reference checkout on this machine")
     rng = np.random.default_rng(n)
     dets = nms_boxes(rng, n, dim=dim)
     for thresh in (0.7, 0.1, 1e-5):
