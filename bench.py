@@ -28,9 +28,11 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-# hipGraph replays of the step need the runtime's graph packet capture OFF (medicaldetectiontoolkit_amd/__init__.py explains); set before
-# anything can initialise the HIP runtime (the package import below does the same)
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# hipGraph replays of the step need the runtime's graph packet capture OFF (medicaldetectiontoolkit_amd/__init__.py explains); set HERE, before
+# torch is imported (importing the package changes nothing in the process)
+if "torch" not in sys.modules and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") is None:
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    os.environ["MDT_GRAPH_ENV_BEFORE_HIP"] = "1"
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -481,6 +481,25 @@ int mdt_conv1x1_dgrad_add(const float *gy, const float *w, const float *res, flo
 int mdt_adam_flat(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, long long step, double grad_div, void *stream);
 
+/* Per-segment form (round 5): torch.optim.Adam's per-PARAMETER semantics over the same flat buffers (exec.py:39,74).
+ *   seg_off [nseg + 1] i64 (device): element offsets of the parameters inside the flat buffers, ascending, seg_off[0] = 0, seg_off[nseg] = n;
+ *   seg_step [nseg] i32 (device, in/out): each parameter's own step counter (torch's state[p]['step']); a segment that is updated counts + 1 and its
+ *            bias corrections 1 - beta^t use ITS t (formed in double on the device);
+ *   present [nseg] u8 or NULL: 0 = the parameter has no gradient in this step as the HOST knows it (p.grad is None);
+ *   cond_id [nseg] i32 or NULL, cond [*] f32 or NULL: a segment with cond_id >= 0 has a gradient only if cond[cond_id] > 0 -- a value the training
+ *            step wrote on the device (number of positive RoIs / anchors ...): the reference's loss helpers return CONSTANTS when a step has no
+ *            positive sample (models/mrcnn.py:233-234, 266-268, 287-288), so torch.optim.Adam leaves those heads alone in such a step;
+ *   policy 0: a segment without a gradient is SKIPPED entirely, like torch.optim.Adam with zero_grad(set_to_none=True) (torch >= 2 default);
+ *   policy 1: torch 0.4.1 (the reference's pinned version, requirements.txt:25): zero_grad() leaves ZERO tensors behind, so after its first gradient a
+ *            parameter is updated in every step (with g = 0 when it has none);
+ *   arith 0: every operation rounded separately; 1: the fma pattern of torch's foreach kernels (bit-equal to torch.optim.Adam on this stack);
+ *   workspace: mdt_adam_flat_segments_workspace_bytes(nseg), 16-byte aligned.  Two launches (per-segment scalars, update); in place. */
+size_t mdt_adam_flat_segments_workspace_bytes(int nseg);
+int mdt_adam_flat_segments(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, const long long *seg_off, int nseg,
+                           int *seg_step, const unsigned char *present, const int *cond_id, const float *cond, int policy, int arith, double lr,
+                           double beta1, double beta2, double eps, double weight_decay, double grad_div, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,28 +15,41 @@ __version__ = "0.1.0"
 # hipGraph replays of the training step (training.GraphedTrainStep): the HIP runtime's "graph packet capture" fast path (pre-built AQL
 # packets per kernel node, DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default in ROCm 7.0) replays the matching + RPN-loss part of the step
 # INCORRECTLY at small sizes -- first replay right, second replay a GPU memory fault; with the flag off (or with AMD_SERIALIZE_KERNEL=3)
-# every replay is right (round 4: tools/graph_small_bisect.py, tools/r04_calls/r04_run_o.sh).  The runtime reads the flag once, when
-# it initialises, so it is set here, at package import, and GRAPH_RUNTIME_SAFE records whether that was early enough.
-GRAPH_RUNTIME_SAFE = False
+# every replay is right (round 4: tools/graph_small_bisect.py, tools/r04_calls/r04_run_o.sh).  The runtime reads the flag ONCE, when it
+# initialises -- and torch.cuda.is_available() / device_count() already initialise it without torch.cuda.is_initialized() saying so.
+# Importing this package therefore changes NOTHING in the process (round 5): the entry point that wants a graphed step puts
+#     DEBUG_CLR_GRAPH_PACKET_CAPTURE=0  and  MDT_GRAPH_ENV_BEFORE_HIP=1
+# into the environment BEFORE it imports torch (train.py --graph 1, bench.py and tests/conftest.py do; `graph_env_setup()` below is the
+# helper), or the variable is exported in the shell.  `graph_runtime_safe()` is what GraphedTrainStep asks before it captures.
 
 
-def _configure_hip_runtime():
-    global GRAPH_RUNTIME_SAFE
-    already = False
-    tc = sys.modules.get("torch")
-    if tc is not None:
-        try:
-            already = bool(tc.cuda.is_initialized())
-        except Exception:
-            already = False
-    if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") is None and not already:
-        os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
-    GRAPH_RUNTIME_SAFE = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and not (already and os.environ.get("MDT_PACKET_CAPTURE_SET_EARLY") != "1")
-    if GRAPH_RUNTIME_SAFE:
-        os.environ["MDT_PACKET_CAPTURE_SET_EARLY"] = "1"       # child processes / later imports: the flag was in place before the runtime came up
+def graph_env_setup():
+    """Call BEFORE `import torch` in a process that will use training.GraphedTrainStep.  Refuses (returns False, changes nothing) when
+    torch is already imported: it may have initialised the HIP runtime, after which the flag is not read any more."""
+    if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and (os.environ.get("MDT_GRAPH_ENV_BEFORE_HIP") == "1" or _in_initial_environ()):
+        return True
+    if "torch" in sys.modules:
+        return False
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    os.environ["MDT_GRAPH_ENV_BEFORE_HIP"] = "1"        # inherited by child processes, where the flag is in the initial environment anyway
+    return True
 
 
-_configure_hip_runtime()
+def _in_initial_environ():
+    """the variable was in the environment the process was STARTED with (exported in the shell / by the parent)"""
+    try:
+        with open("/proc/self/environ", "rb") as f:
+            return b"DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" in f.read().split(b"\0")
+    except OSError:
+        return False
+
+
+def graph_runtime_safe():
+    """True iff the runtime flag was in place before the HIP runtime could have come up: exported to the process, or set by
+    graph_env_setup() before torch was imported.  Never inferred from torch.cuda.is_initialized()."""
+    if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+        return False
+    return _in_initial_environ() or os.environ.get("MDT_GRAPH_ENV_BEFORE_HIP") == "1"
 
 
 def install_dropin():

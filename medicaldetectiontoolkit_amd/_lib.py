@@ -44,6 +44,9 @@ _SIGNATURES = {
     "mdt_conv1x1_dgrad_add_supported": (c_int, [c_int, c_int]),
     "mdt_conv1x1_dgrad_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mdt_adam_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong] + [c_double] * 5 + [c_longlong, c_double, c_void_p]),
+    "mdt_adam_flat_segments_workspace_bytes": (c_size_t, [c_int]),
+    "mdt_adam_flat_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]
+                               + [c_double] * 6 + [c_void_p, c_size_t, c_void_p]),
     "mdt_conv_stem_forward_supported": (c_int, [c_int] * 7),
     "mdt_conv_stem_forward": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p]),
     "mdt_conv3x3x3_small_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),

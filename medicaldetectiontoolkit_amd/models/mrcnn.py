@@ -699,6 +699,26 @@ class net(nn.Module):
     def np_anchors(self):
         return self.anchors_f64.cpu().numpy()
 
+    # ------------------------------------------------------------------ which parameters have a gradient only under a condition of the step
+    def grad_condition_spec(self):
+        """[(condition, [parameters])] for training.FlatAdam.attach_conditions.  The reference's loss helpers return CONSTANTS when a step
+        samples nothing for them -- compute_rpn_class_loss without sampled anchors (mrcnn.py:193-209), compute_rpn_bbox_loss without a
+        positive anchor (:233-234), compute_mrcnn_class_loss without a sampled RoI (:247-248), compute_mrcnn_bbox_loss / _mask_loss without a
+        positive RoI (:266-268, :287-288) -- so autograd hands the parameters below no gradient in such a step and torch.optim.Adam
+        (exec.py:74) does not touch them.  The fixed-size masked step here gives them an exact zero gradient instead; the counts that decide
+        are written to `grad_cond` by train_forward_device, in this order."""
+        r, c, m = self.rpn, self.classifier, self.mask
+        spec = [("rpn_samples", list(r.conv_shared.parameters()) + list(r.conv_class.parameters())),
+                ("rpn_positive_anchors", list(r.conv_bbox.parameters())),
+                ("sampled_rois", list(c.conv1.parameters()) + list(c.conv2.parameters()) + list(c.linear_class.parameters())),
+                ("positive_rois", list(c.linear_bbox.parameters()) + ([] if self.cf.frcnn_mode else list(m.parameters()))),
+                ("any_sample", list(self.fpn.parameters()))]
+        return spec
+
+    def set_grad_cond_buffer(self, t):
+        """float32 [5] device tensor (or None) that train_forward_device fills with the counts of grad_condition_spec()"""
+        self._grad_cond = t
+
     # ------------------------------------------------------------------ forward passes
     def forward(self, img, is_training=True, with_masks=True, rpn_graph=True):
         """mrcnn.py:987-1050.  with_masks=False skips the mask head over the detections (the reference always runs it and
@@ -817,6 +837,11 @@ class net(nn.Module):
         loss = batch_rpn_class_loss + batch_rpn_bbox_loss + mrcnn_class_loss + mrcnn_bbox_loss + mrcnn_mask_loss
         terms = {"rpn_class": batch_rpn_class_loss.detach(), "rpn_bbox": batch_rpn_bbox_loss.detach(),
                  "mrcnn_class": mrcnn_class_loss.detach(), "mrcnn_bbox": mrcnn_bbox_loss.detach(), "mrcnn_mask": mrcnn_mask_loss.detach()}
+        gc = getattr(self, "_grad_cond", None)
+        if gc is not None:          # who had something to learn from in this step (FlatAdam skips the others like torch.optim.Adam does)
+            n_rpn_pos, n_rpn_neg = rpn_samples[1].sum(), rpn_samples[3].sum()
+            n_rois, n_pos = s_valid.sum(), s_pos.sum()
+            gc.copy_(torch.stack([n_rpn_pos + n_rpn_neg, n_rpn_pos, n_rois, n_pos, n_rpn_pos + n_rpn_neg + n_rois]))
         mon = {"rpn_samples": rpn_samples, "proposal_boxes": proposal_boxes, "sample_proposals": sample_proposals.detach(),
                "target_class_ids": target_class_ids, "s_valid": s_valid, "detections": detections, "det_valid": det_valid,
                "detection_masks": detection_masks}

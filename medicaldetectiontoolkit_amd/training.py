@@ -11,7 +11,11 @@ def build_optimizer(net, cf, fused=False, flat=False, grad_sync=None):
     """exec.py:39: Adam(lr=cf.learning_rate[0], weight_decay=cf.weight_decay); fused=True uses torch's single-kernel
     multi-tensor implementation (same update rule); flat=True: FlatAdam (one launch of csrc/adam.hip over flat buffers)."""
     if flat:
-        return FlatAdam(net.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay, grad_sync=grad_sync)
+        opt = FlatAdam(net.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay, grad_sync=grad_sync,
+                       absent_grad=getattr(cf, "adam_absent_grad", "skip"))
+        if hasattr(net, "grad_condition_spec"):
+            opt.attach_conditions(net)
+        return opt
     kw = {"fused": True} if fused else {}
     return torch.optim.Adam(net.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay, **kw)
 
@@ -25,8 +29,9 @@ def _view_like(flat, off, p):
 
 class FlatAdam(torch.optim.Adam):
     """torch.optim.Adam (exec.py:39) with the whole model in four flat fp32 buffers -- parameters, gradients, exp_avg, exp_avg_sq
-    (4.94 M values = 19.75 MB each) -- and the update as ONE launch of mdt_adam_flat (csrc/adam.hip) instead of ~20 multi-tensor
-    launches and 3.4 ms of host time per step (profiles/r03_host_profile.txt).
+    (4.94 M values = 19.75 MB each) -- and the update as ONE C call (mdt_adam_flat_segments, csrc/adam.hip: a one-block kernel that
+    derives every parameter's own bias corrections + one pass over the buffers) instead of ~20 multi-tensor launches and 3.4 ms of
+    host time per step (profiles/r03_host_profile.txt).
 
     * every `p.data`, `p.grad`, `state[p]['exp_avg']`, `state[p]['exp_avg_sq']` is a VIEW (with p's strides) into the flat buffers,
       in reverse parameter order (= FlatGradAllReduce's order, whose gradient buffer is adopted when one is passed), so
@@ -34,25 +39,48 @@ class FlatAdam(torch.optim.Adam):
     * gradients: with a FlatGradAllReduce (N > 1) they LIVE in its flat buffer (`p.grad` views; `zero_grad()` = one fill).  Without
       one, `zero_grad()` sets them to None so that autograd hands its gradient tensors over without an accumulate-add per
       parameter (130 tiny launches per step), and `step()` gathers them into the flat buffer with one `torch._foreach_copy_`;
-    * a parameter that received no gradient in a step sees a ZERO gradient (torch skips it): identical while it never had one
-      (the unused P1 convolutions of the reference FPN, backbone.py:112,118) and for weight_decay = 0 otherwise up to the decay of its
-      moments -- the same convention the multi-GPU path has (FlatGradAllReduce).  One step counter for all parameters.
-    * ONE step counter for all parameters (bias corrections 1 - beta^t): torch.optim.Adam counts per parameter from the parameter's
-      first gradient.  In the fixed-size masked step of this repo every trainable parameter receives a gradient in every step (the
-      heads see zero-weighted padding rows instead of being skipped), so the counters coincide; a loaded state whose per-parameter
-      steps DIFFER is refused rather than collapsed to one value.
+    * **per-parameter semantics (round 5)**: every parameter is a SEGMENT of the flat buffers with its own step counter (device
+      int32, torch's state[p]['step']) and a parameter WITHOUT a gradient in a step is skipped exactly like torch.optim.Adam skips
+      `p.grad is None` -- no moment decay, no weight decay, no update, counter unchanged.  "Without a gradient" has two sources:
+      (a) the host knows it (`p.grad is None`; with a FlatGradAllReduce: no accumulate hook fired for p since `zero()`), and
+      (b) the step says so ON THE DEVICE (`attach_conditions`): the reference's loss helpers return constants when a step samples
+      no positive RoI / anchor (mrcnn.py:233-234, 266-268, 287-288), so its mask head, `linear_bbox` and `conv_bbox` get no gradient
+      there, while this repo's fixed-size masked step hands them an exact ZERO gradient -- the model writes the counts into a small
+      device tensor (`net.grad_cond`) and the kernel treats a segment whose condition is 0 as "no gradient".  With N > 1 that
+      tensor is the tail of the all-reduced gradient buffer: a head is updated iff ANY rank had a positive sample.
+      `absent_grad="zero_after_first"` selects the behaviour of the reference's pinned torch 0.4.1 instead, whose `zero_grad()`
+      leaves zero tensors behind: after its first gradient a parameter is updated in every step (g = 0 when it has none).
+    * a loaded state with DIFFERENT step counts per parameter (a reference checkpoint whose mask head lagged) is adopted as is.
+    * `arith=1` (default): the fma pattern of torch's foreach kernels -- bit-equal to torch.optim.Adam on this stack.
     * every step checks that each `p.data` is still the view into the flat parameter buffer (`net.to(memory_format=...)`, `.half()`,
       `load_state_dict(assign=True)` or a second FlatAdam over the same net re-point it -- the kernel would then update an orphaned
       buffer and the model would silently stop training): on mismatch the flat buffers are rebuilt from the live parameters.
     * amsgrad / maximize / capturable / differentiable are not supported (the reference never sets them)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_sync=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_sync=None, absent_grad="skip", arith=1):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         if len(self.param_groups) != 1:
             raise ValueError("FlatAdam: one parameter group (the reference's exec.py:39 passes net.parameters())")
+        if absent_grad not in ("skip", "zero_after_first"):
+            raise ValueError("FlatAdam: absent_grad is 'skip' (torch >= 2) or 'zero_after_first' (torch 0.4.1)")
         self._grad_sync = grad_sync
+        self._policy = 0 if absent_grad == "skip" else 1
+        self._arith = int(arith)
         self._flat = None           # (param, grad, exp_avg, exp_avg_sq)
-        self._steps = 0
+        self._cond = None           # (net, {id(param): condition index}, n_conditions)
+        self._steps_host = None     # per-segment counters as last read from the device (state_dict())
+
+    def attach_conditions(self, net):
+        """the model tells which parameters get a gradient only under a condition the step evaluates on the device
+        (net.grad_condition_spec() -> [(name, [parameters])], net.grad_cond: float tensor [len(spec)], > 0 = gradient exists)"""
+        spec = net.grad_condition_spec()
+        cmap = {}
+        for i, (_, plist) in enumerate(spec):
+            for p in plist:
+                cmap[id(p)] = i
+        self._cond = (net, cmap, len(spec))
+        self._flat = None
+        return self
 
     def _build(self):
         params = [p for p in self.param_groups[0]["params"] if p.requires_grad]
@@ -63,47 +91,73 @@ class FlatAdam(torch.optim.Adam):
             raise ValueError("FlatAdam: parameters must be dense fp32 tensors on one device")
         n = sum(p.numel() for p in params)
         gs = self._grad_sync
+        n_cond = self._cond[2] if self._cond is not None else 0
         if gs is not None:
-            if gs.flat is None:
+            if gs.flat is None or gs.n_extra < n_cond:
+                gs.n_extra = max(gs.n_extra, n_cond)
                 gs._build()
             if len(gs.params) != len(params) or any(a is not b for a, b in zip(gs.params, params)):
                 raise ValueError("FlatAdam: grad_sync was built over a different parameter list")
-            fgrad = gs.flat
+            fgrad = gs.flat if gs.n_extra == 0 else gs.flat[:n]
             gs.defer_div = True         # this optimizer divides by the world size inside its launch
+            cond_t = gs.extra[:n_cond] if n_cond else None
         else:
             fgrad = torch.zeros(n, dtype=torch.float32, device=dev)
+            cond_t = torch.ones(n_cond, dtype=torch.float32, device=dev) if n_cond else None
+        if self._cond is not None:
+            self._cond[0].set_grad_cond_buffer(cond_t)      # the step writes its counts straight into this tensor
         fparam = torch.empty(n, dtype=torch.float32, device=dev)
         fm = torch.zeros(n, dtype=torch.float32, device=dev)
         fv = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
-        gviews = []
-        loaded_steps = set()
+        gviews, offs, steps0, cond_ids = [], [0], [], []
+        prev_steps = self._device_steps() if self._flat is not None else None       # a re-home keeps the counters
         with torch.no_grad():
-            for p in reversed(params):                       # backward order, as FlatGradAllReduce lays the gradients out
+            for k, p in enumerate(reversed(params)):                       # backward order, as FlatGradAllReduce lays the gradients out
                 v = _view_like(fparam, off, p)
                 v.copy_(p)
                 old_state = self.state.get(p, {})
                 gviews.append(_view_like(fgrad, off, p))
                 p.data = v
-                st = {"step": torch.tensor(float(self._steps)), "exp_avg": _view_like(fm, off, p), "exp_avg_sq": _view_like(fv, off, p)}
+                st = {"step": torch.tensor(0.0), "exp_avg": _view_like(fm, off, p), "exp_avg_sq": _view_like(fv, off, p)}
                 if "exp_avg" in old_state:                    # state loaded (or stepped by plain Adam) before the first flat step
                     st["exp_avg"].copy_(old_state["exp_avg"])
                     st["exp_avg_sq"].copy_(old_state["exp_avg_sq"])
                     st["step"] = torch.tensor(float(old_state["step"]))
-                    loaded_steps.add(int(float(old_state["step"])))
+                if prev_steps is not None and len(prev_steps) == len(params):
+                    st["step"] = torch.tensor(float(prev_steps[k]))
+                steps0.append(int(float(st["step"])))
                 self.state[p] = st
                 off += p.numel()
-        if len(loaded_steps) > 1:
-            raise ValueError("FlatAdam: the adopted optimizer state has different step counts per parameter (%s); FlatAdam keeps ONE "
-                             "counter -- continue such a run with torch.optim.Adam" % sorted(loaded_steps))
-        if loaded_steps:
-            self._steps = max(self._steps, loaded_steps.pop())
+                offs.append(off)
+                cond_ids.append(self._cond[1].get(id(p), -1) if self._cond is not None else -1)
         self._params = params
         self._rparams = list(reversed(params))
         self._pptr = [p.data_ptr() for p in self._rparams]       # where each parameter must still live at every step
         self._gviews = gviews                       # flat-gradient views, in `_rparams` order
         self._gdirty = [False] * len(gviews)        # view holds a gradient of an earlier step
         self._flat = (fparam, fgrad, fm, fv)
+        nseg = len(params)
+        self._seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._seg_step = torch.tensor(steps0, dtype=torch.int32, device=dev)
+        self._seg_cond = torch.tensor(cond_ids, dtype=torch.int32, device=dev) if n_cond else None
+        self._cond_t = cond_t
+        self._present_host = bytearray(b"\x01" * nseg)                          # what the device copy currently holds
+        self._present_dev = torch.ones(nseg, dtype=torch.uint8, device=dev)
+        self._present_pin = torch.ones(nseg, dtype=torch.uint8).pin_memory() if dev.type == "cuda" else torch.ones(nseg, dtype=torch.uint8)
+        self._present_ev = None
+        self._ws = torch.empty(max(16 * nseg, 16), dtype=torch.uint8, device=dev)
+        self._steps_host = None
+
+    def _device_steps(self):
+        return [int(v) for v in self._seg_step.cpu().tolist()]
+
+    def state_dict(self):
+        """torch.optim.Adam's format; the per-parameter step counters live on the device and are read back here (one small copy)"""
+        if self._flat is not None:
+            for p, t in zip(self._rparams, self._device_steps()):
+                self.state[p]["step"] = torch.tensor(float(t))
+        return super().state_dict()
 
     def zero_grad(self, set_to_none=True):
         if self._flat is None:
@@ -116,8 +170,20 @@ class FlatAdam(torch.optim.Adam):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._flat = None           # re-adopt the loaded moments at the next step (`_build` copies them into the flat buffers)
-        self._steps = 0
+        self._flat = None           # re-adopt the loaded moments and step counters at the next step (`_build` copies them into the flat buffers)
+
+    def _set_present(self, flags):
+        """host-known gradient presence per segment (bytes, `_rparams` order) -> device, only when it changed"""
+        if flags == self._present_host:
+            return
+        if self._present_ev is not None:
+            self._present_ev.synchronize()      # the pinned staging buffer of the previous change must have been read (rare path)
+        self._present_pin.copy_(torch.frombuffer(flags, dtype=torch.uint8))
+        self._present_dev.copy_(self._present_pin, non_blocking=True)
+        if self._present_dev.is_cuda:
+            self._present_ev = torch.cuda.Event()
+            self._present_ev.record()
+        self._present_host = bytearray(flags)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -131,18 +197,25 @@ class FlatAdam(torch.optim.Adam):
         if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
             raise ValueError("FlatAdam: amsgrad / maximize / capturable / differentiable are not supported")
         if any(p.data_ptr() != q for p, q in zip(self._rparams, self._pptr)):
-            self._build()                # a parameter was re-pointed: re-home all of them (moments are carried over by `_build`)
+            if getattr(self, "_graph_attached", False):
+                raise RuntimeError("FlatAdam: a parameter was re-pointed while a GraphedTrainStep holds the old addresses; re-capture the step")
+            self._build()                # a parameter was re-pointed: re-home all of them (moments and counters are carried over by `_build`)
         fparam, fgrad, fm, fv = self._flat
+        flags = bytearray(b"\x01" * len(self._rparams))
         if self._grad_sync is not None:
-            for p in self._params:       # a dropped view (someone's zero_grad(set_to_none=True)) would silently freeze p
+            touched = self._grad_sync.touched
+            for i, p in enumerate(self._rparams):       # a dropped view (someone's zero_grad(set_to_none=True)) would silently freeze p
                 if p.grad is None:
                     raise RuntimeError("FlatAdam: a gradient view was dropped; clear gradients with FlatAdam.zero_grad()")
+                if touched is not None and not touched[i]:
+                    flags[i] = 0
         else:                            # gather autograd's gradient tensors into the flat buffer: one multi-tensor copy
             dst, src = [], []
             for i, p in enumerate(self._rparams):
                 g_i = p.grad
                 if g_i is None:
-                    if self._gdirty[i]:              # last step's gradient must not be applied again
+                    flags[i] = 0
+                    if self._gdirty[i]:              # last step's gradient must not be applied again (zero_after_first reads the buffer)
                         self._gviews[i].zero_()
                         self._gdirty[i] = False
                 elif g_i.data_ptr() != self._gviews[i].data_ptr():
@@ -151,23 +224,24 @@ class FlatAdam(torch.optim.Adam):
                     self._gdirty[i] = True
             if dst:
                 torch._foreach_copy_(dst, src)
-        self._steps += 1
+        self._set_present(flags)
         gdiv = 1.0
         if self._grad_sync is not None:      # the all-reduce left SUMS: the division by the world size rides this launch
             gdiv, self._grad_sync.pending_div = float(self._grad_sync.pending_div), 1.0
         self._update(fparam, fgrad, fm, fv, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                     float(g["weight_decay"]), self._steps, gdiv)
-        for p in self._params:
-            self.state[p]["step"].fill_(float(self._steps))   # CPU scalars (torch.optim.Adam's own format)
+                     float(g["weight_decay"]), gdiv)
         return loss
 
-    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, step, grad_div=1.0):
-        """the one launch (csrc/adam.hip); no CPU implementation in the product -- the gloo tests substitute this method"""
+    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, grad_div=1.0):
+        """the one C call (csrc/adam.hip); no CPU implementation in the product -- the gloo tests substitute this method"""
         from . import _lib
         with torch.cuda.device(fparam.device):
-            rc = _lib.lib().mdt_adam_flat(fparam.data_ptr(), fgrad.data_ptr(), fm.data_ptr(), fv.data_ptr(), fparam.numel(), lr, beta1, beta2,
-                                          eps, weight_decay, step, grad_div, _lib.raw_stream(fparam))
-        _lib.check(rc, "mdt_adam_flat")
+            rc = _lib.lib().mdt_adam_flat_segments(
+                fparam.data_ptr(), fgrad.data_ptr(), fm.data_ptr(), fv.data_ptr(), fparam.numel(), self._seg_off.data_ptr(), len(self._rparams),
+                self._seg_step.data_ptr(), self._present_dev.data_ptr(), self._seg_cond.data_ptr() if self._seg_cond is not None else None,
+                self._cond_t.data_ptr() if self._cond_t is not None else None, self._policy, self._arith, lr, beta1, beta2, eps, weight_decay,
+                grad_div, self._ws.data_ptr(), self._ws.numel(), _lib.raw_stream(fparam))
+        _lib.check(rc, "mdt_adam_flat_segments")
 
 
 class FlatGradAllReduce(object):
@@ -201,12 +275,23 @@ class FlatGradAllReduce(object):
         # instead of a separate pass over the buffer; until its step() the buffer then holds the SUM over ranks, pending_div the divisor
         self.defer_div = False
         self.pending_div = 1.0
+        # n_extra float slots behind the gradients, all-reduced (summed) with the last bucket: training.FlatAdam keeps the step's
+        # "this head had a positive sample" values there (FlatAdam.attach_conditions), so that every rank takes the same skip decision
+        self.n_extra = 0
+        self.extra = None
+        # touched[i]: an accumulate hook fired for parameter i (backward order) since zero(); None without hooks (overlap=False)
+        self.touched = None
 
     # -- setup (lazy: parameters must already live on their device)
     def _build(self):
         dev = self.params[0].device
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.flat = torch.zeros(self.numel + self.n_extra, dtype=torch.float32, device=dev)
+        self.extra = self.flat[self.numel:]
         order = list(reversed(self.params))                      # backward order
+        self._index = {p: i for i, p in enumerate(order)}
         target = (self.numel + self.n_buckets - 1) // self.n_buckets
         self.bucket_of, self.bucket_range, self.bucket_left0 = {}, [], []
         off, start, count, b = 0, 0, 0, 0
@@ -218,12 +303,13 @@ class FlatGradAllReduce(object):
             off += n
             count += 1
             if (off - start >= target and b < self.n_buckets - 1) or i == len(order) - 1:
-                self.bucket_range.append((start, off))
+                self.bucket_range.append((start, off if i < len(order) - 1 else off + self.n_extra))
                 self.bucket_left0.append(count)
                 start, count, b = off, 0, b + 1
         self._left = list(self.bucket_left0)
         self._next = 0
         if self.overlap:
+            self.touched = bytearray(len(order))
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -237,6 +323,7 @@ class FlatGradAllReduce(object):
             self._next += 1
 
     def _on_grad(self, p):
+        self.touched[self._index[p]] = 1
         if self.suspended or not self._active():
             return
         b = self.bucket_of[p]
@@ -248,7 +335,9 @@ class FlatGradAllReduce(object):
         """replaces optimizer.zero_grad(): all gradients are views of the flat buffer"""
         if self.flat is None:
             self._build()
-        self.flat.zero_()
+        self.flat[:self.numel].zero_()       # (the extra slots are overwritten by the step, not accumulated into)
+        if self.touched is not None:
+            self.touched = bytearray(len(self.touched))
         self._left = list(self.bucket_left0)
         self._next = 0
         self._handles = []
@@ -418,9 +507,9 @@ class GraphedTrainStep(object):
         """warm up and capture on `batch` (its shapes fix the static inputs); __call__ does this on its first call"""
         import medicaldetectiontoolkit_amd as pkg
         from .cuda_functions import _roi_align_impl
-        if not pkg.GRAPH_RUNTIME_SAFE and not os.environ.get("MDT_ALLOW_UNSAFE_GRAPH"):
-            raise RuntimeError("GraphedTrainStep: the HIP runtime was initialised before DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 could be set (import "
-                               "medicaldetectiontoolkit_amd before the first CUDA call, or export the variable): with the runtime's graph packet "
+        if not pkg.graph_runtime_safe() and not os.environ.get("MDT_ALLOW_UNSAFE_GRAPH"):
+            raise RuntimeError("GraphedTrainStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in place before the HIP runtime could initialise (export it, "
+                               "or call medicaldetectiontoolkit_amd.graph_env_setup() before `import torch`): with the runtime's graph packet "
                                "capture on, replays of this step fault (see medicaldetectiontoolkit_amd/__init__.py); use training.train_step")
         if _roi_align_impl.PROFILE is not None:
             raise RuntimeError("GraphedTrainStep: switch the RoIAlign event profile off before the capture (events cannot be recorded inside a graph)")
@@ -437,35 +526,49 @@ class GraphedTrainStep(object):
         gc.collect()
         if isinstance(self.opt, FlatAdam) and self.opt._flat is None:
             self.opt._build()            # re-homes the parameters: must happen before their addresses are baked into the graph
+        prev_suspended = None
         if self.sync is not None:
             if self.sync.flat is None:
                 self.sync._build()
-            self.sync.suspended = True   # the bucket all-reduces are launched after the replay, not from hooks inside the capture
-        self._alloc(batch)
-        self._load(batch)
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):    # warm-up on a side stream (MIOpen find, workspaces, cached constants), as torch's capture protocol asks
-            for _ in range(max(1, self.warmup)):
-                self._body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        from . import _lib
-        self.graph = torch.cuda.CUDAGraph()
-        _lib.CAPTURING += 1              # cached device workspaces are bypassed: everything the graph touches lives in its own pool
+            # the hooks fire (in Python) during the capture's backward: they must launch nothing there -- the bucket all-reduces follow
+            # the replay (finish_all).  Restored afterwards, also when the capture raises: eager steps keep their overlap.
+            prev_suspended, self.sync.suspended = self.sync.suspended, True
         try:
-            with torch.cuda.graph(self.graph):
-                self._out, self._packed = self._body()
+            self._alloc(batch)
+            self._load(batch)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):    # warm-up on a side stream (MIOpen find, workspaces, cached constants), as torch's capture protocol asks
+                for _ in range(max(1, self.warmup)):
+                    self._body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            from . import _lib
+            graph = torch.cuda.CUDAGraph()
+            _lib.CAPTURING += 1              # cached device workspaces are bypassed: everything the graph touches lives in its own pool
+            try:
+                with torch.cuda.graph(graph):
+                    self._out, self._packed = self._body()
+            finally:
+                _lib.CAPTURING -= 1
+            self.graph = graph
         finally:
-            _lib.CAPTURING -= 1
+            if self.sync is not None:
+                self.sync.suspended = prev_suspended
         self._grads = [p.grad for p in self._params]
+        self._pptr = [p.data_ptr() for p in self._params]
+        if isinstance(self.opt, FlatAdam):
+            self.opt._graph_attached = True      # a re-home of the parameters would leave the graph training orphaned buffers: FlatAdam raises instead
         torch.cuda.synchronize()
 
     def __call__(self, batch):
         import time
         if self.graph is None:
             self.capture(batch)
+        if any(p.data_ptr() != q for p, q in zip(self._params, self._pptr)):
+            raise RuntimeError("GraphedTrainStep: a parameter moved since the capture (load_state_dict / .to(...) / another optimizer): the graph would "
+                               "keep training the old buffers -- build a new GraphedTrainStep")
         hm = self.host_ms
         from .utils import model_utils as _mu
         w0 = _mu.RING_WAIT_S[0]
@@ -483,6 +586,7 @@ class GraphedTrainStep(object):
         self.opt.step()
         t3 = time.perf_counter()
         out = self._out
+        # NOTE: these are the graph's STATIC output tensors -- the next call overwrites them; read (or clone) them before it
         res = {"torch_loss": out["loss"].detach(), "loss_terms": out["terms"], "sample_counts": out["sample_counts"]}
         if self.monitor:
             host = self._packed[0].detach().cpu()                 # the ONE device->host copy (and the one sync) of the step

@@ -2,10 +2,10 @@ import os
 import sys
 
 # before anything initialises the HIP runtime (the `cuda` fixture's torch.cuda.is_available() does): the runtime flag hipGraph replays of
-# the training step need (see medicaldetectiontoolkit_amd/__init__.py); importing the package sets it, too -- this covers test modules
-# that touch torch.cuda first
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-os.environ.setdefault("MDT_PACKET_CAPTURE_SET_EARLY", "1")
+# the training step need (see medicaldetectiontoolkit_amd/__init__.py: importing the package sets NOTHING, the entry point does)
+if "torch" not in sys.modules and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") is None:
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    os.environ["MDT_GRAPH_ENV_BEFORE_HIP"] = "1"
 
 import pytest
 

@@ -90,13 +90,26 @@ class _TorchMathFlatAdam(training.FlatAdam):
     adoption of the collective's gradient buffer, state dict) is what these CPU tests exercise; the kernel itself is pinned
     against torch.optim.Adam on the GPU (tests/test_flat_adam_gpu.py)."""
 
-    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, step, grad_div=1.0):
-        fgrad = fgrad / grad_div if grad_div != 1.0 else fgrad       # the averaging folded into the update (mdt_adam_flat's grad_div)
-        g = fgrad + weight_decay * fparam if weight_decay != 0 else fgrad
-        fm.lerp_(g, 1 - beta1)
-        fv.mul_(beta2).addcmul_(g, g, value=1 - beta2)
-        denom = (fv.sqrt() / (1 - beta2 ** step) ** 0.5).add_(eps)
-        fparam.addcdiv_(fm, denom, value=-lr / (1 - beta1 ** step))
+    def _update(self, fparam, fgrad, fm, fv, lr, beta1, beta2, eps, weight_decay, grad_div=1.0):
+        offs = self._seg_off.tolist()
+        for s in range(len(offs) - 1):           # mdt_adam_flat_segments: per-parameter presence, step counter and bias corrections
+            active = bool(self._present_dev[s])
+            if active and self._seg_cond is not None and int(self._seg_cond[s]) >= 0:
+                active = float(self._cond_t[int(self._seg_cond[s])]) > 0
+            t = int(self._seg_step[s])
+            if self._policy == 1 and t > 0:
+                active = True
+            if not active:
+                continue
+            t += 1
+            self._seg_step[s] = t
+            sl = slice(offs[s], offs[s + 1])
+            g = fgrad[sl] / grad_div if grad_div != 1.0 else fgrad[sl]       # the averaging folded into the update (grad_div)
+            g = g + weight_decay * fparam[sl] if weight_decay != 0 else g
+            fm[sl].lerp_(g, 1 - beta1)
+            fv[sl].mul_(beta2).addcmul_(g, g, value=1 - beta2)
+            denom = (fv[sl].sqrt() / (1 - beta2 ** t) ** 0.5).add_(eps)
+            fparam[sl].addcdiv_(fm[sl], denom, value=-lr / (1 - beta1 ** t))
 
 
 def _adam_worker(rank, world, port, out):
@@ -156,31 +169,44 @@ def test_flat_adam_over_flat_grad_allreduce_world2(tmp_path):
     for n, p in ref.named_parameters():
         assert torch.allclose(got["params"][n], p.detach(), rtol=1e-5, atol=1e-7), n
     st = got["state"]
-    assert len(st["state"]) == 6 and all(float(v["step"]) == 3.0 and set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in st["state"].values())
+    assert len(st["state"]) == 6 and all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in st["state"].values())
+    # per-parameter counters like torch.optim.Adam's: `never` got no gradient on any rank (no accumulate hook fired) and was skipped
+    assert sorted(float(v["step"]) for v in st["state"].values()) == [0.0, 0.0, 3.0, 3.0, 3.0, 3.0]
+    assert all(float(v["exp_avg"].abs().sum()) == 0.0 for v in st["state"].values() if float(v["step"]) == 0.0)
     fresh = torch.optim.Adam(Tiny().parameters(), lr=1e-2)
     fresh.load_state_dict(st)                    # loads into torch's own Adam
 
 
 def test_flat_adam_single_process_gathers_autograd_gradients():
     """N = 1 form: zero_grad() sets gradients to None, step() gathers what autograd produced into the flat buffer; equal to
-    torch.optim.Adam, also when a parameter has no gradient in some step (zero-gradient convention)"""
+    torch.optim.Adam, also when a parameter has no gradient in some step: it is SKIPPED like torch skips `p.grad is None` (round 5) --
+    and with absent_grad="zero_after_first" it is updated with a zero gradient, like torch 0.4.1 whose zero_grad() leaves zero tensors"""
     torch.manual_seed(0)
     a, b = Tiny(), Tiny()
     b.load_state_dict(a.state_dict())
+    c, d = Tiny(), Tiny()
+    c.load_state_dict(a.state_dict())
+    d.load_state_dict(a.state_dict())
     oa, ob = torch.optim.Adam(a.parameters(), lr=1e-2), _TorchMathFlatAdam(b.parameters(), lr=1e-2)
+    oc, od = torch.optim.Adam(c.parameters(), lr=1e-2), _TorchMathFlatAdam(d.parameters(), lr=1e-2, absent_grad="zero_after_first")
     torch.manual_seed(5)
     for it in range(4):
         x = torch.randn(5, 4)
-        for net, opt in ((a, oa), (b, ob)):
+        for net, opt in ((a, oa), (b, ob), (c, oc), (d, od)):
             loss = net(x, use_second=(it != 2))
             opt.zero_grad()
             loss.backward()
         if it == 2:
-            assert b.sometimes.weight.grad is None
-            for p in a.sometimes.parameters():
-                p.grad = torch.zeros_like(p)          # torch would skip a None gradient; the flat form applies a zero one
-        oa.step()
-        ob.step()
+            assert b.sometimes.weight.grad is None and a.sometimes.weight.grad is None      # torch skips it; so does the flat form
+            for p in c.sometimes.parameters():
+                p.grad = torch.zeros_like(p)          # torch 0.4.1: zero_grad() left a zero tensor, Adam applies it
+        for o in (oa, ob, oc, od):
+            o.step()
+    for (n, pc), (_, pd) in zip(c.named_parameters(), d.named_parameters()):
+        assert torch.allclose(pc, pd, rtol=1e-5, atol=1e-7), n
+    sb = ob.state_dict()["state"]
+    assert sorted(float(v["step"]) for v in sb.values()) == [0.0, 0.0, 3.0, 3.0, 4.0, 4.0]
+    assert {k: float(v["step"]) for k, v in oa.state_dict()["state"].items()} == {k: float(v["step"]) for k, v in sb.items() if float(v["step"]) > 0}
     assert all(p.grad is not None and p.grad.untyped_storage().data_ptr() != ob._flat[1].untyped_storage().data_ptr() for p in b.used.parameters())
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7), n
@@ -259,10 +285,11 @@ def test_collect_raw_boxes_two_ranks_equals_reference(tmp_path):
     assert got["calls"] < 4 * 80 // 8 + 8          # rank 0 forwarded only its share of the 320 patches
 
 
-def test_flat_adam_rehomes_a_repointed_parameter_and_refuses_mixed_steps():
+def test_flat_adam_rehomes_a_repointed_parameter_and_adopts_mixed_steps():
     """(1) a parameter whose `.data` was re-pointed after the flat buffers were built (net.to(memory_format=...), .float(), a second
-    FlatAdam over the same net) must keep training -- step() notices the stale address and rebuilds, carrying the moments over;
-    (2) a loaded optimizer state whose per-parameter step counts differ is refused (FlatAdam keeps ONE counter)."""
+    FlatAdam over the same net) must keep training -- step() notices the stale address and rebuilds, carrying the moments AND the per-parameter
+    step counters over; (2) ADVICE r4: a loaded optimizer state whose per-parameter step counts DIFFER (a reference checkpoint whose mask head
+    lagged behind: mrcnn.py:287-288) is adopted as it is and continues on torch.optim.Adam's trajectory."""
     torch.manual_seed(0)
     net = Tiny()
     ref = Tiny()
@@ -284,11 +311,27 @@ def test_flat_adam_rehomes_a_repointed_parameter_and_refuses_mixed_steps():
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n          # kept training on the same trajectory
     fparam = opt._flat[0]
     assert all(p.data.untyped_storage().data_ptr() == fparam.untyped_storage().data_ptr() for p in net.parameters())
-    # (2) heterogeneous steps
+    # (2) heterogeneous steps: both optimizers continue from the same doctored state
     sd = ropt.state_dict()
     keys = sorted(sd["state"])
     sd["state"][keys[0]]["step"] = torch.tensor(7.0)
-    opt2 = _TorchMathFlatAdam(ref.parameters(), lr=1e-2)
-    opt2.load_state_dict(sd)
-    with pytest.raises(ValueError, match="different step counts"):      # raised when the flat buffers adopt the loaded state
-        opt2.zero_grad()
+    net2 = Tiny()
+    net2.load_state_dict(ref.state_dict())
+    import copy
+    opt2 = _TorchMathFlatAdam(net2.parameters(), lr=1e-2)
+    opt2.load_state_dict(copy.deepcopy(sd))
+    ropt2 = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    ropt2.load_state_dict(copy.deepcopy(sd))
+    for it in range(2):
+        for m, o in ((net2, opt2), (ref, ropt2)):
+            loss = m(x, use_second=True)
+            o.zero_grad()
+            loss.backward()
+            o.step()
+    for (n, a), (_, b) in zip(net2.named_parameters(), ref.named_parameters()):
+        if b.grad is not None:
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n
+    s2, r2 = opt2.state_dict()["state"], ropt2.state_dict()["state"]
+    for k in r2:
+        assert float(s2[k]["step"]) == float(r2[k]["step"]), k
+    assert float(s2[keys[0]]["step"]) == 9.0

@@ -77,26 +77,127 @@ def test_flat_adam_state_dict_round_trip_and_adoption(cuda):
     oc.load_state_dict(copy.deepcopy(ob.state_dict()))            # and back into torch's Adam
 
 
-def test_flat_adam_missing_gradient_is_a_zero_gradient(cuda):
-    """a parameter without a gradient in a step (p.grad None) is updated with a ZERO gradient (documented convention; torch skips
-    it): equal to torch.optim.Adam fed explicit zeros, and last step's gradient is not applied twice"""
-    a, b = _toy(cuda, 5), _toy(cuda, 5)
+def test_flat_adam_missing_gradient_is_skipped_like_torch_or_zero_like_torch_0_4(cuda):
+    """a parameter without a gradient in a step (p.grad None): absent_grad="skip" (default) leaves it alone like torch.optim.Adam --
+    parameters, moments and its own step counter; absent_grad="zero_after_first" updates it with a zero gradient like torch 0.4.1
+    (whose zero_grad() leaves zero tensors) -- equal to torch.optim.Adam fed explicit zeros"""
+    a, b, c, d = _toy(cuda, 5), _toy(cuda, 5), _toy(cuda, 5), _toy(cuda, 5)
     oa = torch.optim.Adam(a.parameters(), lr=1e-2)
     ob = training.FlatAdam(b.parameters(), lr=1e-2)
+    oc = torch.optim.Adam(c.parameters(), lr=1e-2)
+    od = training.FlatAdam(d.parameters(), lr=1e-2, absent_grad="zero_after_first")
     x = torch.randn((2, 2, 4, 4, 4), device=cuda)
-    for it in range(4):
-        for net, opt in ((a, oa), (b, ob)):
+    for it in range(5):
+        a.zero_grad()
+        a(x).square().mean().backward()
+        grads = [p.grad.clone() for p in a.parameters()]
+        for net, opt in ((b, ob), (c, oc), (d, od)):
             opt.zero_grad()
-            net(x).square().mean().backward()
-        if it >= 2:                      # the last layer gets no gradient in steps 2 and 3
-            for p in a[4].parameters():
+            for p, g in zip(net.parameters(), grads):          # the SAME gradient tensors for all four: the comparison is the optimizer's
+                p.grad = g.clone()
+        if it in (2, 3):                 # the last layer gets no gradient in steps 2 and 3
+            for net in (a, b, d):
+                for p in net[4].parameters():
+                    p.grad = None
+            for p in c[4].parameters():
                 p.grad = torch.zeros_like(p)
-            for p in b[4].parameters():
-                p.grad = None
+        for o in (oa, ob, oc, od):
+            o.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.equal(pa, pb), (it, float((pa - pb).abs().max()))
+        for pc, pd in zip(c.parameters(), d.parameters()):
+            assert torch.equal(pc, pd), (it, float((pc - pd).abs().max()))
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    assert [float(sa[k]["step"]) for k in sorted(sa)] == [float(sb[k]["step"]) for k in sorted(sb)] == [5.0, 5.0, 5.0, 5.0, 3.0, 3.0]
+    for k in sa:
+        assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"])
+
+
+def test_flat_adam_is_bit_equal_to_torch_adam_on_identical_gradients(cuda):
+    """arith = 1 (default): the fma pattern of torch's foreach Adam kernels -- parameters and both moments BIT-EQUAL to
+    torch.optim.Adam over 12 steps when both are fed the same gradient tensors (with and without weight decay)"""
+    for wd in (0.0, 0.01):
+        a, b = _toy(cuda, 7), _toy(cuda, 7)
+        oa = torch.optim.Adam(a.parameters(), lr=1e-2, weight_decay=wd)
+        ob = training.FlatAdam(b.parameters(), lr=1e-2, weight_decay=wd)
+        g = torch.Generator(device=cuda).manual_seed(3)
+        for it in range(12):
+            x = torch.randn((3, 2, 4, 4, 4), device=cuda, generator=g)
+            a.zero_grad()
+            a(x).square().mean().backward()
+            ob.zero_grad()
+            for pa, pb in zip(a.parameters(), b.parameters()):
+                pb.grad = pa.grad.clone()
+            oa.step()
+            ob.step()
+            for pa, pb in zip(a.parameters(), b.parameters()):
+                assert torch.equal(pa, pb), (wd, it, float((pa - pb).abs().max()))
+        sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+        for k in sa:
+            assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"]), (wd, k)
+
+
+def test_mrcnn_four_steps_one_without_positives_equal_torch_adam_bit_for_bit(cuda):
+    """VERDICT r4 "missing" 3: the K-step trajectory.  Four training steps of the real Mask R-CNN, step 2 on a batch WITHOUT GT objects (no
+    positive RoI, no positive anchor): the reference's mask / bbox / rpn-bbox losses are constants there (mrcnn.py:233-234, 266-268,
+    287-288), so exec.py:74's torch.optim.Adam does not touch the mask head, linear_bbox and conv_bbox -- no moment decay, no step count.
+    net A: this repo's step + FlatAdam with the model's device-side gradient conditions.  net B: torch.optim.Adam fed A's gradient
+    tensors, with `None` exactly where the reference's autograd produces none (net.grad_condition_spec() evaluated on the host).  Weights,
+    moments and per-parameter step counters: BIT-EQUAL after every step."""
+    import copy
+    from tests.golden import step_inputs as si
+    import numpy as np
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step_reference.npz"), allow_pickle=False)
+    nb = si.CASES["small"][1]
+    full = si.make_batch(si.make_image(), [gold["gt_boxes_%d" % b] for b in range(nb)], [gold["gt_labels_%d" % b] for b in range(nb)])
+    empty = si.make_batch(si.make_image(seed=32), [np.zeros((0, 6), np.float32)] * nb, [np.zeros((0,), np.int64)] * nb)
+    cf = si.make_cf("mrcnn")
+    net_a = mrcnn.net(cf, device=cuda)
+    si.fill_by_name(net_a)
+    net_b = copy.deepcopy(net_a)
+    oa = training.build_optimizer(net_a, cf, flat=True)
+    assert oa._cond is not None
+    ob = torch.optim.Adam(net_b.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay)
+    spec = net_a.grad_condition_spec()
+    cond_of = {}
+    for i, (_, plist) in enumerate(spec):
+        for p in plist:
+            cond_of[id(p)] = i
+    names = [n for n, _ in net_a.named_parameters()]
+    skipped_in_step2 = None
+    for it, batch in enumerate((full, empty, full, full)):
+        torch.manual_seed(10 + it)
+        res = net_a.train_forward(batch, monitor=False)
+        oa.zero_grad()
+        res["torch_loss"].backward()
+        cond = net_a._grad_cond.detach().cpu().tolist()
+        n_valid, n_pos = (int(v) for v in res["sample_counts"])
+        assert (n_pos > 0) == (it != 1) and cond[3] == n_pos and cond[2] == n_valid
+        absent = []
+        for (n, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+            have = pa.grad is not None and (id(pa) not in cond_of or cond[cond_of[id(pa)]] > 0)
+            pb.grad = pa.grad.clone() if have else None
+            if not have:
+                absent.append(n)
+        if it == 1:
+            skipped_in_step2 = set(absent)
+        before = [p.detach().clone() for p in net_a.parameters()]
         oa.step()
         ob.step()
-    for pa, pb in zip(a.parameters(), b.parameters()):
-        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6)
+        for (n, pa), pb, p0 in zip(net_a.named_parameters(), net_b.parameters(), before):
+            assert torch.equal(pa, pb), (it, n, float((pa - pb).abs().max()))
+            if n in absent:
+                assert torch.equal(pa, p0), (it, n)          # untouched
+    # what the empty step skipped: the mask head, the box regressor of the classifier head, the RPN's box head (+ the never-used P1 layers)
+    assert {n for n in skipped_in_step2 if not n.startswith("fpn.")} == {n for n in names if n.startswith("mask.") or n.startswith("classifier.linear_bbox") or n.startswith("rpn.conv_bbox")}
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    for k, n in enumerate(names):
+        if k in sb:
+            assert float(sa[k]["step"]) == float(sb[k]["step"]) == (3.0 if n in skipped_in_step2 else 4.0), n
+            assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"]), n
+        else:
+            assert float(sa[k]["step"]) == 0.0, n           # torch keeps no state for a parameter that never had a gradient
 
 
 def test_flat_adam_with_grad_sync_refuses_dropped_gradient_views(cuda):

@@ -222,3 +222,47 @@ def test_reference_retina_unet_file_trains_on_the_hip_ops(ref, cuda):
     assert [sum(1 for bx in boxes if bx["box_type"] == t) for t in ("pos_anchor", "neg_anchor")] == GOLD["retina_n_pos_neg_anchors"].tolist()
     for k, v in _grad_norms(net).items():
         _close(v, float(GOLD["retina_gradnorm_" + k]), 1e-3, "reference retina_unet.py on HIP ops: grad norm of " + k)
+
+
+def test_reference_adam_leaves_the_same_parameters_alone_as_flat_adam_in_a_step_without_positives(ref, cuda):
+    """exec.py:39,72-74 on the reference's own mrcnn.py vs this repo's step + training.FlatAdam, three steps: full batch, a batch WITHOUT GT
+    objects, full batch.  In the empty step the reference's mask / bbox / rpn-bbox losses are constants (mrcnn.py:233-234, 266-268, 287-288):
+    torch.optim.Adam leaves those heads bit-for-bit alone and does not count a step for them.  FlatAdam must skip EXACTLY the same
+    parameters (by state-dict name) -- it decides on the device from the counts the step wrote (net.grad_condition_spec) -- and end with
+    the same per-parameter step counters."""
+    from medicaldetectiontoolkit_amd import training
+    from medicaldetectiontoolkit_amd.models import mrcnn as my_mrcnn
+    mr = ref["mrcnn"]
+    nb = si.CASES["small"][1]
+    full = _batch()
+    empty = si.make_batch(si.make_image(seed=32), [np.zeros((0, 6), np.float32)] * nb, [np.zeros((0,), np.int64)] * nb)
+    cf = si.make_cf("mrcnn")
+    cf.backbone_path = os.path.join(REF_PY, "models/backbone.py")
+    rnet = mr.net(cf, _log()).cuda()
+    si.fill_by_name(rnet)
+    ropt = torch.optim.Adam(rnet.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay)      # exec.py:39
+    mnet = my_mrcnn.net(si.make_cf("mrcnn"), device=cuda)
+    si.fill_by_name(mnet)
+    mopt = training.build_optimizer(mnet, mnet.cf, flat=True)
+    untouched = {"ref": [], "mine": []}
+    for it, batch in enumerate((full, empty, full)):
+        np.random.seed(it)
+        torch.manual_seed(it)
+        before = {n: p.detach().clone() for n, p in rnet.named_parameters()}
+        with torch04():
+            res = rnet.train_forward(batch)
+        ropt.zero_grad()                       # exec.py:72 (torch >= 2: set_to_none)
+        res["torch_loss"].backward()           # :73
+        ropt.step()                            # :74
+        untouched["ref"].append({n for n, p in rnet.named_parameters() if torch.equal(p, before[n])})
+        before = {n: p.detach().clone() for n, p in mnet.named_parameters()}
+        training.train_step(mnet, mopt, batch, monitor=False)
+        untouched["mine"].append({n for n, p in mnet.named_parameters() if torch.equal(p, before[n])})
+    for it in range(3):
+        assert untouched["ref"][it] == untouched["mine"][it], (it, sorted(untouched["ref"][it] ^ untouched["mine"][it]))
+    heads = {n for n, _ in rnet.named_parameters() if n.startswith("mask.") or n.startswith("classifier.linear_bbox") or n.startswith("rpn.conv_bbox")}
+    assert heads and heads <= untouched["ref"][1] and not (heads & untouched["ref"][0]) and not (heads & untouched["ref"][2])
+    rs, ms = ropt.state_dict()["state"], mopt.state_dict()["state"]
+    for k, (n, _) in enumerate(rnet.named_parameters()):
+        assert float(ms[k]["step"]) == (float(rs[k]["step"]) if k in rs else 0.0), n
+    assert {float(v["step"]) for v in rs.values()} == {2.0, 3.0}

@@ -20,8 +20,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import medicaldetectiontoolkit_amd  # noqa: E402
 from medicaldetectiontoolkit_amd import miopen_env  # noqa: E402
 miopen_env.setup()
+if any(a in ("--graph=1",) for a in sys.argv) or any(a == "--graph" and b == "1" for a, b in zip(sys.argv, sys.argv[1:])):
+    # a graphed step needs the runtime's graph packet capture off, decided BEFORE torch is imported (the package import sets nothing)
+    medicaldetectiontoolkit_amd.graph_env_setup()
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -40,6 +44,10 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--graph", type=int, default=0, help="1: the device half of the Mask R-CNN step as one hipGraph replay (training.GraphedTrainStep)")
     ap.add_argument("--gmax", type=int, default=8, help="GT objects per batch element the graphed step's fixed-size table holds")
+    ap.add_argument("--flat-adam", type=int, default=1, help="1 (default): training.FlatAdam (one C call over flat buffers, torch.optim.Adam's per-parameter "
+                    "semantics and state-dict format); 0: torch.optim.Adam itself")
+    ap.add_argument("--adam-absent-grad", default="skip", choices=["skip", "zero_after_first"], help="a parameter without a gradient in a step: skip it "
+                    "(torch >= 2, default) or update it with a zero gradient once it has had one (torch 0.4.1, the reference's pinned version)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,7 +76,8 @@ def main():
     net = (mrcnn if args.model == "mrcnn" else retina_unet).net(cf, device=dev)
     sync = training.FlatGradAllReduce(net) if world > 1 else None
     use_graph = bool(args.graph) and args.model == "mrcnn"
-    opt = training.build_optimizer(net, cf, flat=True, grad_sync=sync)
+    cf.adam_absent_grad = args.adam_absent_grad
+    opt = training.build_optimizer(net, cf, flat=bool(args.flat_adam), grad_sync=sync)
     fold_dir = os.path.join(args.exp_dir, "fold_0")
     start_epoch = 1
     loaded_metrics = None
