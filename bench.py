@@ -122,7 +122,10 @@ def cpu_baseline_reference(args, timeout_s=420):
     (exec.py:39,68-74) on ONE full batch of the benchmarked configuration, on this box's host cores, in a child process
     (oracle/ref_step_cpu.py: reference files from oracle/_ref/py, the CPU oracle behind the four CUDA-only cuda_functions imports)."""
     import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_step_cpu.py"), "--patch", args.patch, "--batch", str(args.batch), "--model", args.model]
+    # torch-CPU's 3D convolutions scale badly past a few dozen threads on these hosts (256 threads: 266 s for the step that takes 32 s on the 8
+    # cores of the build container): the baseline is run at --cpu-threads (default 16), `cores` says so
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "ref_step_cpu.py"), "--patch", args.patch, "--batch", str(args.batch), "--model", args.model,
+           "--threads", str(min(args.cpu_threads, os.cpu_count() or 1))]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["HIP_VISIBLE_DEVICES"] = ""
     t0 = time.time()
@@ -563,6 +566,7 @@ def main():
     ap.add_argument("--model", type=str, default="mrcnn", choices=["mrcnn", "retina_unet"],
                     help="mrcnn = BASELINE config 3 (headline); retina_unet = config 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads of the cpu_baseline's reference step (oracle/ref_step_cpu.py)")
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 2 and 5 (run in child processes after the headline line is assembled, N = 1 only)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the RoIAlign-backward roofline section (child runs of --secondary)")
     ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the world-size-1 RCCL self-test after the timed loop")
@@ -896,11 +900,13 @@ def main():
                        "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over %s)" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "global_batch": args.batch * world,
                        "step_form": ("forward + backward + Adam of exec.py:68-74, every loss term and every parameter gradient of the reference step "
-                                     "(tests/test_step_parity_gpu.py pins them against the reference at this configuration).  NOT in `value`, IN `exec_equivalent`: "
-                                     "(1) train_forward(monitor=False): the per-batch read-out exec.py:76-79 consumes (logger_string, box lists, monitor_values) is not "
-                                     "built and nothing is copied to the host; (2) the mask head over the DETECTIONS (mrcnn.py:1046-1048, :946-964) is not run -- "
-                                     "no loss term or gradient depends on it, the reference computes it in every training step and only its validation pass reads it.  "
-                                     "`exec_equivalent` is the step with both, fed host numpy batches: the figure to quote for SURVEY 8(d) M1 as exec.py runs it.  "
+                                     "(tests/test_step_parity_gpu.py pins them against the reference at this configuration).  "
+                                     + ("NOT in `value`, IN `exec_equivalent`: "
+                                        "(1) train_forward(monitor=False): the per-batch read-out exec.py:76-79 consumes (logger_string, box lists, monitor_values) is not "
+                                        "built and nothing is copied to the host; (2) the mask head over the DETECTIONS (mrcnn.py:1046-1048, :946-964) is not run -- "
+                                        "no loss term or gradient depends on it, the reference computes it in every training step and only its validation pass reads it.  "
+                                        "`exec_equivalent` is the step with both, fed host numpy batches: the figure to quote for SURVEY 8(d) M1 as exec.py runs it.  "
+                                        if args.model == "mrcnn" else "train_forward(monitor=False): the per-batch read-out of exec.py:76-79 is not built.  ") +
                                      "The timed batches are random-GT batches on random-init weights: see `timed_batches` for how full the RoI heads were, "
                                      "`heads_full_step` for the same step with full RoI heads.  RPN losses back-propagated "
                                      + ("through the sampled anchors only (same gradients as the dense graph, which is timed as dense_rpn_graph_step)"

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "mdt_pyramid_roi_align_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mdt_debug_bwd_timestamps": (None, [c_void_p]),
     "mdt_debug_bwd3": (None, [c_void_p, c_int, c_int]),
+    "mdt_debug_fwd_stamps": (None, [c_void_p]),
     "mdt_upsample2x_yx_cl_forward": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_longlong, c_void_p]),
     "mdt_upsample2x_yx_cl_backward": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_longlong, c_void_p]),
     "mdt_conv3x3x3_small_supported": (c_int, [c_int] * 5),

@@ -100,7 +100,7 @@ __device__ __forceinline__ void adam_seg_one(float &p, float g, float &m, float 
         if (a.wd != 0.0f) g = __builtin_fmaf(a.wd, p, g);                 // _foreach_add(grads, params, alpha=wd)
         m = __builtin_fmaf(a.one_minus_b1, g - m, m);                     // _foreach_lerp_(exp_avgs, grads, 1 - beta1)
         v = v * a.b2;                                                     // _foreach_mul_(exp_avg_sqs, beta2)
-        v = __builtin_fmaf(a.one_minus_b2 * g, g, v);                     // _foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2)
+        v = __builtin_fmaf(a.one_minus_b2, g * g, v);                     // _foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2): a + s * (b * c)
         const float denom = sqrtf(v) / sc.bc2_sqrt + a.eps;               // _foreach_sqrt, _foreach_div_, _foreach_add_
         p = __builtin_fmaf(sc.neg_step_size, m / denom, p);               // _foreach_addcdiv_(params, exp_avgs, denom, step_size)
     }

@@ -40,16 +40,6 @@ constexpr int FWD_SLAB = FWD_THREADS * FWD_PER_THREAD;
 
 // DIM == 3: image [B,C,H,W,D], boxes [N,6], crops [N,C,ch,cw,cd]
 // DIM == 2: image [B,C,H,W],   boxes [N,4], crops [N,C,ch,cw]      (D = cd = 1)
-// input element: fp32, or bf16 (raw 16-bit pattern, widened exactly to fp32 on load -- the interpolation itself is
-// always fp32; used by the autocast inference path, where it halves the gathered bytes)
-struct bf16raw { unsigned short v; };
-// uint8 (round 4): the GT masks of a training batch travel and stay as uint8 (2 MB per 128^3 mask); the mask-target crop of
-// detection_target_layer (mrcnn.py:551-563) reads them as they are, each byte widened exactly, instead of a 4x larger fp32 copy
-struct u8raw { unsigned char v; };
-__device__ __forceinline__ float ld(const float *p, long long i) { return p[i]; }
-__device__ __forceinline__ float ld(const bf16raw *p, long long i) { return __uint_as_float(((unsigned int)p[i].v) << 16); }
-__device__ __forceinline__ float ld(const u8raw *p, long long i) { return (float)p[i].v; }
-
 template <int DIM, typename TIN>
 __device__ __forceinline__ void crop_fwd_body(
     const TIN *__restrict__ image, const float *__restrict__ boxes,
@@ -147,207 +137,8 @@ __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_kernel(
     crop_fwd_body<DIM, TIN>(image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, crops);
 }
 
-// ---------------------------------------------------------------------------
-// forward, wave-staged form (round 4): one WAVE per (RoI, channel)
-// ---------------------------------------------------------------------------
-// The direct kernel above issues 8 scattered 4-byte loads per output: a wave's load touches up to 64 different cache lines and the
-// texture-address unit serialises them (N = 240 RoIs x 36 channels x (14,14,5): 58 us for 34 MB of output = 7 % of HBM -- bound by
-// line look-ups, not by bytes).  Here a wave owns one (RoI, channel) pair: it reads every voxel row the RoI touches ONCE, as 16-byte
-// (4-element) loads along the contiguous z axis -- ~10-60 line look-ups per pair instead of ~1000 -- into its private LDS region, then
-// interpolates all ch x cw x cd outputs of the pair from LDS (scattered 4-byte LDS reads are what LDS is good at) and writes them as
-// one contiguous run.  The sample tables are built once per workgroup (4 waves = 4 channels of one RoI).  The arithmetic per output is
-// the direct kernel's, term for term (bit-exact against the oracle).  A pair whose source box does not fit the wave's LDS region (or a
-// map whose z extent is not a multiple of 4) takes the direct path inside the same kernel.
-constexpr int FW_WAVES = 4;
-constexpr int FW_THREADS = 64 * FW_WAVES;
-constexpr int FW_REGION_FLOATS = 3072;          // 12 KB per wave
-
-struct u8x4 { unsigned char v[4]; };
-struct bf16x4 { unsigned short v[4]; };
-__device__ __forceinline__ void ld4(const float *p, long long i, float o[4]) { const v4f q = *reinterpret_cast<const v4f *>(p + i); o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; }
-__device__ __forceinline__ void ld4(const bf16raw *p, long long i, float o[4])
-{
-    const uint2 q = *reinterpret_cast<const uint2 *>(p + i);
-    o[0] = __uint_as_float(q.x << 16); o[1] = __uint_as_float(q.x & 0xffff0000u); o[2] = __uint_as_float(q.y << 16); o[3] = __uint_as_float(q.y & 0xffff0000u);
-}
-__device__ __forceinline__ void ld4(const u8raw *p, long long i, float o[4])
-{
-    const unsigned int q = *reinterpret_cast<const unsigned int *>(p + i);
-    o[0] = (float)(q & 255u); o[1] = (float)((q >> 8) & 255u); o[2] = (float)((q >> 16) & 255u); o[3] = (float)(q >> 24);
-}
-
-template <int DIM, typename TIN>
-__device__ __forceinline__ void crop_fwd_wave_body(
-    const TIN *__restrict__ image, const float *__restrict__ boxes, const int *__restrict__ box_ind, int B, int H, int W, int D,
-    int ch, int cw, int cd, int C, int cpw, float *__restrict__ crops)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *region_all = reinterpret_cast<float *>(smem_raw);                                   // [FW_WAVES][FW_REGION_FLOATS]
-    AxisEntry *tab = reinterpret_cast<AxisEntry *>(region_all + FW_WAVES * FW_REGION_FLOATS);   // [ch + cw + cd]
-    int *ext = reinterpret_cast<int *>(tab + (ch + cw + cd));                                   // ymin, ny, xmin, nx, zmin4, nz4
-
-    const int n = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // a wave owns `cpw` consecutive channels of the RoI (small pools: one channel is too little work to pay for the staging latency)
-    const int c0 = (blockIdx.y * FW_WAVES + wave) * cpw;
-    const int nc = min(cpw, C - c0);
-    const int P = ch * cw * cd;
-    const int b_in = box_ind[n];
-    float *out = crops + ((long long)n * C + c0) * P;
-    if (b_in < 0 || b_in >= B) {  // skipped RoI: reference leaves the zero-fill
-        if (nc > 0) for (int e = lane; e < nc * P; e += 64) out[e] = 0.0f;
-        return;
-    }
-    const float *bx = boxes + (long long)n * (2 * DIM);
-    for (int t = threadIdx.x; t < ch + cw + cd; t += FW_THREADS) {
-        AxisEntry e;
-        if (t < ch) e = axis_entry(bx[0], bx[2], H, ch, t);
-        else if (t < ch + cw) e = axis_entry(bx[1], bx[3], W, cw, t - ch);
-        else if (DIM == 3) e = axis_entry(bx[4], bx[5], D, cd, t - ch - cw);
-        else { e.lo = 0; e.lerp = 0.0f; }
-        tab[t] = e;
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {        // extent of the touched voxel box per axis (a box may be inverted: min / max over the whole table)
-        const int a = threadIdx.x;
-        const int t0 = a == 0 ? 0 : (a == 1 ? ch : ch + cw), cnt = a == 0 ? ch : (a == 1 ? cw : cd);
-        int lo = 0x7fffffff, hi = -1;
-        for (int t = 0; t < cnt; ++t) { const AxisEntry e = tab[t0 + t]; lo = min(lo, e.lo); hi = max(hi, entry_hi(e)); }
-        if (a == 2) { const int lo4 = lo & ~3; ext[4] = lo4; ext[5] = (hi - lo4) / 4 + 1; }
-        else { ext[2 * a] = lo; ext[2 * a + 1] = hi - lo + 1; }
-    }
-    __syncthreads();
-    if (nc <= 0) return;
-    const int ymin = ext[0], ny = ext[1], xmin = ext[2], nx = ext[3], zmin4 = ext[4], nz4 = ext[5];
-    const int rowf = nz4 * 4;                     // floats per staged row
-    const int chanf = ny * nx * rowf;             // floats per staged channel
-    const long long vol = (long long)H * W * D;
-    const TIN *pimage = image + ((long long)b_in * C + c0) * vol;
-    // as many channels per staging pass as fit the wave's region (a big source box: one at a time; beyond the region: direct loads)
-    // staging pays when the samples are dense in the source box: the box is read whole (chanf / 4 vector loads) against 8 P scattered
-    // loads of the direct form -- a (7,7,3) pool over a 16^3-voxel box needs 1176 of its 4096+ voxels and is faster direct (measured:
-    // N = 600 on P2 43.8 us staged-always vs 34.1 us direct; with this rule 37 us; (14,14,5): 42 us vs 60 us direct)
-    const bool staged = (D % 4 == 0) && (chanf <= FW_REGION_FLOATS) && (chanf <= 4 * P);
-    const int kfit = staged ? min(nc, FW_REGION_FLOATS / chanf) : nc;
-    float *reg = region_all + wave * FW_REGION_FLOATS;
-    const int s_z = 64 % cd, s_xq = 64 / cd;
-    const int s_x = s_xq % cw, s_yq = s_xq / cw;
-    const int s_y = s_yq % ch, s_c = s_yq / ch;
-    for (int cs = 0; cs < nc; cs += kfit) {
-        const int kk = min(kfit, nc - cs);
-        const TIN *pgrp = pimage + (long long)cs * vol;
-        if (staged) {
-            if (cs > 0) {      // the previous group's LDS reads are done before its slots are overwritten
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            const int qpc = ny * nx * nz4, quads = qpc * kk;
-            for (int q = lane; q < quads; q += 64) {
-                const int cc = q / qpc, qq = q - cc * qpc;
-                const int row = qq / nz4, zq = qq - row * nz4;
-                const int ry = row / nx, rx = row - ry * nx;
-                float v[4];
-                ld4(pgrp, (long long)cc * vol + (long long)D * ((xmin + rx) + (long long)W * (ymin + ry)) + zmin4 + 4 * zq, v);
-                *reinterpret_cast<v4f *>(reg + q * 4) = v4f{v[0], v[1], v[2], v[3]};
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        // outputs of the group's channels, z fastest, channel slowest: lane-strided walk with a mixed-radix counter (no division per output)
-        int z = lane % cd, t = lane / cd;
-        int x = t % cw; t /= cw;
-        int y = t % ch, cc = t / ch;
-        const int total = kk * P;
-        float *og = out + (long long)cs * P;
-        for (int e = lane; e < total; e += 64) {
-            const AxisEntry ey = tab[y];
-            const AxisEntry ex = tab[ch + x];
-            const int top = ey.lo, bottom = entry_hi(ey);
-            const int left = ex.lo, right = entry_hi(ex);
-            float res;
-            if (DIM == 3) {
-                const AxisEntry ez = tab[ch + cw + z];
-                const int front = ez.lo, back = entry_hi(ez);
-                float tlf, trf, blf, brf, tlb, trb, blb, brb;
-                if (staged) {
-                    const int rt = (top - ymin) * nx, rb = (bottom - ymin) * nx, cl = left - xmin, cr = right - xmin;
-                    const int f = front - zmin4, k = back - zmin4;
-                    const float *rc = reg + cc * chanf;
-                    const float *a = rc + (rt + cl) * rowf, *bq = rc + (rt + cr) * rowf, *cq = rc + (rb + cl) * rowf, *d = rc + (rb + cr) * rowf;
-                    tlf = a[f]; trf = bq[f]; blf = cq[f]; brf = d[f];
-                    tlb = a[k]; trb = bq[k]; blb = cq[k]; brb = d[k];
-                } else {
-                    const TIN *pc = pgrp + (long long)cc * vol;
-                    const long long rt_l = (long long)D * (left + (long long)W * top), rt_r = (long long)D * (right + (long long)W * top);
-                    const long long rb_l = (long long)D * (left + (long long)W * bottom), rb_r = (long long)D * (right + (long long)W * bottom);
-                    tlf = ld(pc, front + rt_l); trf = ld(pc, front + rt_r); blf = ld(pc, front + rb_l); brf = ld(pc, front + rb_r);
-                    tlb = ld(pc, back + rt_l); trb = ld(pc, back + rt_r); blb = ld(pc, back + rb_l); brb = ld(pc, back + rb_r);
-                }
-                const float top_front = tlf + (trf - tlf) * ex.lerp;
-                const float bottom_front = blf + (brf - blf) * ex.lerp;
-                const float top_back = tlb + (trb - tlb) * ex.lerp;
-                const float bottom_back = blb + (brb - blb) * ex.lerp;
-                const float frontv = top_front + (bottom_front - top_front) * ey.lerp;
-                const float backv = top_back + (bottom_back - top_back) * ey.lerp;
-                res = frontv + (backv - frontv) * ez.lerp;
-            } else {
-                const TIN *pc = pgrp + (long long)cc * vol;
-                const float tl = ld(pc, (long long)top * W + left), tr = ld(pc, (long long)top * W + right);
-                const float bl = ld(pc, (long long)bottom * W + left), br = ld(pc, (long long)bottom * W + right);
-                const float topv = tl + (tr - tl) * ex.lerp;
-                const float bottomv = bl + (br - bl) * ex.lerp;
-                res = topv + (bottomv - topv) * ey.lerp;
-            }
-            og[e] = res;
-            z += s_z; x += s_x; y += s_y; cc += s_c;
-            if (z >= cd) { z -= cd; x += 1; }
-            if (x >= cw) { x -= cw; y += 1; }
-            if (y >= ch) { y -= ch; cc += 1; }
-        }
-    }
-}
-
-template <int DIM, typename TIN>
-__global__ __launch_bounds__(FW_THREADS) void crop_fwd_wave_kernel(
-    const TIN *__restrict__ image, const float *__restrict__ boxes, const int *__restrict__ box_ind, int B, int H, int W, int D,
-    int ch, int cw, int cd, int C, int cpw, float *__restrict__ crops)
-{
-    crop_fwd_wave_body<DIM, TIN>(image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, cpw, crops);
-}
-
-// channels per wave: ~512 outputs per wave (a (7,7,3) pool has 147 outputs per channel: 4 channels; (14,14,5): 1), never more than
-// needed to give every CU a few workgroups
-inline int fwd_wave_cpw(int P, int C, int N)
-{
-    const char *f = getenv("MDT_FWD_CPW");
-    if (f && f[0]) { const int v = atoi(f); if (v >= 1 && v <= 16) return v; }
-    int cpw = 512 / (P > 0 ? P : 1);
-    if (cpw < 1) cpw = 1;
-    if (cpw > 4) cpw = 4;
-    while (cpw > 1 && (long long)N * ((C + FW_WAVES * cpw - 1) / (FW_WAVES * cpw)) < 1024) --cpw;
-    return cpw;
-}
-
-inline size_t fwd_wave_lds(int ch, int cw, int cd) { return (size_t)FW_WAVES * FW_REGION_FLOATS * sizeof(float) + (size_t)(ch + cw + cd) * sizeof(AxisEntry) + 8 * sizeof(int); }
-
-// MDT_FWD_KERNEL=direct selects the round-1 direct kernel (A/B)
-inline bool fwd_use_wave_kernel(int dim)
-{
-    static int mode = -1;
-    if (mode < 0) { const char *f = getenv("MDT_FWD_KERNEL"); mode = (f && f[0] == 'd') ? 0 : 1; }
-    return mode == 1 && dim == 3;
-}
-
 // All pyramid levels in one launch (mrcnn.py:373-457 pools every RoI on exactly one level and restores the order:
 // here the RoI's workgroups read their level's map directly and write the RoI's row, so the order never changes).
-constexpr int PYR_MAX_LEVELS = 5;
-struct PyramidMaps {
-    const void *image[PYR_MAX_LEVELS];
-    int H[PYR_MAX_LEVELS], W[PYR_MAX_LEVELS], D[PYR_MAX_LEVELS];
-    int n_levels;
-};
-
 template <int DIM, typename TIN>
 __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_pyramid_kernel(
     PyramidMaps maps, const float *__restrict__ boxes, const int *__restrict__ box_ind, const int *__restrict__ level,
@@ -358,18 +149,6 @@ __global__ __launch_bounds__(FWD_THREADS) void crop_fwd_pyramid_kernel(
     if (l < 0 || l >= maps.n_levels) { l = 0; b_limit = 0; }      // no level: the row is zero-filled like a skipped RoI
     crop_fwd_body<DIM, TIN>(reinterpret_cast<const TIN *>(maps.image[l]), boxes, box_ind, b_limit,
                             maps.H[l], maps.W[l], maps.D[l], ch, cw, cd, C, crops);
-}
-
-template <int DIM, typename TIN>
-__global__ __launch_bounds__(FW_THREADS) void crop_fwd_wave_pyramid_kernel(
-    PyramidMaps maps, const float *__restrict__ boxes, const int *__restrict__ box_ind, const int *__restrict__ level,
-    int B, int ch, int cw, int cd, int C, int cpw, float *__restrict__ crops)
-{
-    int l = level[blockIdx.x];
-    int b_limit = B;
-    if (l < 0 || l >= maps.n_levels) { l = 0; b_limit = 0; }      // no level: the row is zero-filled like a skipped RoI
-    crop_fwd_wave_body<DIM, TIN>(reinterpret_cast<const TIN *>(maps.image[l]), boxes, box_ind, b_limit,
-                                 maps.H[l], maps.W[l], maps.D[l], ch, cw, cd, C, cpw, crops);
 }
 
 // ---------------------------------------------------------------------------
@@ -1155,119 +934,6 @@ __global__ __launch_bounds__(256) void crop_bwd3d_atomic_kernel(
     }
 }
 
-// Forward, LDS-staged form: one workgroup per (RoI, channel group).  The RoI's bounding sub-box of the feature
-// map (rows along the contiguous axis) is staged in LDS with coalesced loads, one channel at a time, and all
-// ch*cw*cd outputs of that channel are interpolated from LDS: each feature voxel is read from global memory once
-// per RoI instead of up to 8 times through scattered 4-byte gathers.  Same arithmetic (bit-exact) as
-// crop_fwd_kernel.  NOT the default: it measured slower than the direct gather (see launch_fwd).
-constexpr int FWDS_THREADS = 256;
-constexpr int FWDS_BOX_FLOATS = 6144;   // 24 KB sub-box budget
-
-template <int DIM>
-__global__ __launch_bounds__(FWDS_THREADS) void crop_fwd_staged_kernel(
-    const float *__restrict__ image, const float *__restrict__ boxes,
-    const int *__restrict__ box_ind, int B, int H, int W, int D,
-    int ch, int cw, int cd, int C, int ch_per_wg, float *__restrict__ crops)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *sbox = reinterpret_cast<float *>(smem_raw);                      // [FWDS_BOX_FLOATS]
-    AxisEntry *tab = reinterpret_cast<AxisEntry *>(sbox + FWDS_BOX_FLOATS);  // [ch + cw + cd]
-    __shared__ int s_ext[8];                                                 // ylo, ny, xlo, nx, zlo, nz, fits
-
-    const int n = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int P = ch * cw * cd;
-    const int c0 = blockIdx.y * ch_per_wg;
-    const int c1 = min(C, c0 + ch_per_wg);
-    const int b_in = box_ind[n];
-    float *out = crops + ((long long)n * C + c0) * P;
-    if (b_in < 0 || b_in >= B) {
-        for (int e = tid; e < (c1 - c0) * P; e += FWDS_THREADS) out[e] = 0.0f;
-        return;
-    }
-    const float *bx = boxes + (long long)n * (2 * DIM);
-    for (int t = tid; t < ch + cw + cd; t += FWDS_THREADS) {
-        AxisEntry e;
-        if (t < ch) e = axis_entry(bx[0], bx[2], H, ch, t);
-        else if (t < ch + cw) e = axis_entry(bx[1], bx[3], W, cw, t - ch);
-        else {
-            if (DIM == 3) e = axis_entry(bx[4], bx[5], D, cd, t - ch - cw);
-            else { e.lo = 0; e.lerp = 0.0f; }
-        }
-        tab[t] = e;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
-        const int off[3] = {0, ch, ch + cw}, np_[3] = {ch, cw, cd};
-        for (int a = 0; a < 3; ++a)
-            for (int q = 0; q < np_[a]; ++q) { lo[a] = min(lo[a], tab[off[a] + q].lo); hi[a] = max(hi[a], entry_hi(tab[off[a] + q])); }
-        s_ext[0] = lo[0]; s_ext[1] = hi[0] - lo[0] + 1;
-        s_ext[2] = lo[1]; s_ext[3] = hi[1] - lo[1] + 1;
-        s_ext[4] = lo[2]; s_ext[5] = hi[2] - lo[2] + 1;
-        s_ext[6] = ((long long)s_ext[1] * s_ext[3] * s_ext[5] <= FWDS_BOX_FLOATS) ? 1 : 0;
-    }
-    __syncthreads();
-    const int ylo = s_ext[0], ny = s_ext[1], xlo = s_ext[2], nx = s_ext[3], zlo = s_ext[4], nz = s_ext[5];
-    const bool fits = s_ext[6] != 0;
-    const long long vol = (long long)H * W * D;
-    const int nbox = ny * nx * nz;
-
-    for (int c = c0; c < c1; ++c) {
-        const float *pimage = image + ((long long)b_in * C + c) * vol;
-        if (fits) {
-            __syncthreads();   // previous channel's reads of sbox are done
-            for (int t = tid; t < nbox; t += FWDS_THREADS) {
-                const int z = t % nz;
-                const int r = t / nz;
-                const int x = r % nx;
-                const int y = r / nx;
-                sbox[t] = pimage[((long long)(ylo + y) * W + (xlo + x)) * D + (zlo + z)];
-            }
-            __syncthreads();
-        }
-        float *o = crops + ((long long)n * C + c) * P;
-        for (int e = tid; e < P; e += FWDS_THREADS) {
-            int idx = e, z = 0;
-            if (DIM == 3) { z = idx % cd; idx /= cd; }
-            const int x = idx % cw;
-            const int y = idx / cw;
-            const AxisEntry ey = tab[y], ex = tab[ch + x];
-            const int top = ey.lo, bottom = entry_hi(ey), left = ex.lo, right = entry_hi(ex);
-            int front = 0, back = 0;
-            float zl = 0.0f;
-            if (DIM == 3) { const AxisEntry ez = tab[ch + cw + z]; front = ez.lo; back = entry_hi(ez); zl = ez.lerp; }
-            float tlf, trf, blf, brf, tlb, trb, blb, brb;
-            if (fits) {
-                const int t_ = (top - ylo) * nx, b_ = (bottom - ylo) * nx, l_ = left - xlo, r_ = right - xlo;
-                const int f_ = front - zlo, k_ = back - zlo;
-                tlf = sbox[(t_ + l_) * nz + f_]; trf = sbox[(t_ + r_) * nz + f_];
-                blf = sbox[(b_ + l_) * nz + f_]; brf = sbox[(b_ + r_) * nz + f_];
-                tlb = sbox[(t_ + l_) * nz + k_]; trb = sbox[(t_ + r_) * nz + k_];
-                blb = sbox[(b_ + l_) * nz + k_]; brb = sbox[(b_ + r_) * nz + k_];
-            } else {
-                const long long rt_l = (long long)D * (left + (long long)W * top), rt_r = (long long)D * (right + (long long)W * top);
-                const long long rb_l = (long long)D * (left + (long long)W * bottom), rb_r = (long long)D * (right + (long long)W * bottom);
-                tlf = pimage[front + rt_l]; trf = pimage[front + rt_r]; blf = pimage[front + rb_l]; brf = pimage[front + rb_r];
-                tlb = pimage[back + rt_l]; trb = pimage[back + rt_r]; blb = pimage[back + rb_l]; brb = pimage[back + rb_r];
-            }
-            if (DIM == 3) {
-                const float top_front = tlf + (trf - tlf) * ex.lerp;
-                const float bottom_front = blf + (brf - blf) * ex.lerp;
-                const float top_back = tlb + (trb - tlb) * ex.lerp;
-                const float bottom_back = blb + (brb - blb) * ex.lerp;
-                const float frontv = top_front + (bottom_front - top_front) * ey.lerp;
-                const float backv = top_back + (bottom_back - top_back) * ey.lerp;
-                o[e] = frontv + (backv - frontv) * zl;
-            } else {
-                const float topv = tlf + (trf - tlf) * ex.lerp;
-                const float bottomv = blf + (brf - blf) * ex.lerp;
-                o[e] = topv + (bottomv - topv) * ey.lerp;
-            }
-        }
-    }
-}
-
 template <int DIM, typename TIN>
 int launch_fwd(const TIN *image, const float *boxes, const int *box_ind, int N, int B,
                int H, int W, int D, int ch, int cw, int cd, int C, float *crops, hipStream_t s)
@@ -1279,32 +945,14 @@ int launch_fwd(const TIN *image, const float *boxes, const int *box_ind, int N, 
     if (per_roi > 0x7fffffffLL) return MDT_ERR_UNSUPPORTED;
     const size_t tab_bytes = (size_t)(ch + cw + cd) * sizeof(AxisEntry);
     if (tab_bytes > 24 * 1024) return MDT_ERR_UNSUPPORTED;
-    // Measured on MI355X (profiles/r01_microbench.jsonl): the direct gather wins at every reference shape
-    // (N=600 (7,7,3): 35 vs 58 us; N=240 (14,14,5): 56 vs 73 us) -- L1/L2 absorb the corner re-reads and the staged
-    // form pays two barriers per channel -- so direct is the default; MDT_FWD_KERNEL=staged selects the other.
-    const char *force = getenv("MDT_FWD_KERNEL");
-    const bool direct = !(force && force[0] == 's') || !std::is_same<TIN, float>::value;
-    if (!direct) {
-        // channels per workgroup: enough workgroups to fill the chip, but amortise the table build
-        int cpw = (int)(((long long)N * C + 4095) / 4096);
-        if (cpw < 1) cpw = 1;
-        if (cpw > C) cpw = C;
-        const int gy = (C + cpw - 1) / cpw;
-        if (gy <= 65535) {
-            const size_t lds = (size_t)FWDS_BOX_FLOATS * sizeof(float) + tab_bytes;
-            (void)hipGetLastError();
-            hipLaunchKernelGGL(crop_fwd_staged_kernel<DIM>, dim3((unsigned)N, (unsigned)gy), dim3(FWDS_THREADS), lds, s,
-                               reinterpret_cast<const float *>(image), boxes, box_ind, B, H, W, D, ch, cw, cd, C, cpw, crops);
-            return check_launch();
-        }
-    }
-    if (fwd_use_wave_kernel(DIM) && (C + FW_WAVES - 1) / FW_WAVES <= 65535 && (long long)ch * cw * cd <= 0x3fffffff &&
-        (reinterpret_cast<uintptr_t>(image) & 15) == 0) {       // (its 4-element loads need the map 16-byte aligned)
-        (void)hipGetLastError();
-        const int cpw = fwd_wave_cpw(ch * cw * cd, C, N);
-        hipLaunchKernelGGL((crop_fwd_wave_kernel<DIM, TIN>), dim3((unsigned)N, (unsigned)((C + FW_WAVES * cpw - 1) / (FW_WAVES * cpw))), dim3(FW_THREADS),
-                           fwd_wave_lds(ch, cw, cd), s, image, boxes, box_ind, B, H, W, D, ch, cw, cd, C, cpw, crops);
-        return check_launch();
+    // 3D: the channel-quad form (roi_align_fwd.hip, round 5); 2D and what is outside its budgets: the direct gather below.
+    // (History, profiles/: a round-1 LDS-staged form lost to the direct gather -- 58 vs 35 us at N = 600 (7,7,3); round 4's wave-staged
+    // form reached 41 us at N = 240 (14,14,5) against 57 us direct; both are gone from the product library.)
+    if (DIM == 3) {
+        PyramidMaps one;
+        one.n_levels = 1; one.image[0] = image; one.H[0] = H; one.W[0] = W; one.D[0] = D;
+        const int rq = launch_fwd_cq<TIN>(one, boxes, box_ind, nullptr, N, B, ch, cw, cd, C, crops, s);
+        if (rq != MDT_ERR_UNSUPPORTED) return rq;
     }
     const long long slabs = (per_roi + FWD_SLAB - 1) / FWD_SLAB;
     if (slabs > 65535) return MDT_ERR_UNSUPPORTED;
@@ -1335,15 +983,11 @@ int launch_fwd_pyramid(int n_levels, const void *const *images, const int *H, co
     const size_t tab_bytes = (size_t)(ch + cw + cd) * sizeof(AxisEntry);
     const long long slabs = (per_roi + FWD_SLAB - 1) / FWD_SLAB;
     if (tab_bytes > 24 * 1024 || slabs > 65535) return MDT_ERR_UNSUPPORTED;
-    (void)hipGetLastError();
-    bool aligned = true;
-    for (int l = 0; l < n_levels; ++l) aligned = aligned && (reinterpret_cast<uintptr_t>(images[l]) & 15) == 0;
-    if (fwd_use_wave_kernel(DIM) && aligned && (C + FW_WAVES - 1) / FW_WAVES <= 65535 && (long long)ch * cw * cd <= 0x3fffffff) {
-        const int cpw = fwd_wave_cpw(ch * cw * cd, C, N);
-        hipLaunchKernelGGL((crop_fwd_wave_pyramid_kernel<DIM, TIN>), dim3((unsigned)N, (unsigned)((C + FW_WAVES * cpw - 1) / (FW_WAVES * cpw))), dim3(FW_THREADS),
-                           fwd_wave_lds(ch, cw, cd), s, maps, boxes, box_ind, level, B, ch, cw, cd, C, cpw, crops);
-        return check_launch();
+    if (DIM == 3) {
+        const int rq = launch_fwd_cq<TIN>(maps, boxes, box_ind, level, N, B, ch, cw, cd, C, crops, s);
+        if (rq != MDT_ERR_UNSUPPORTED) return rq;
     }
+    (void)hipGetLastError();
     hipLaunchKernelGGL((crop_fwd_pyramid_kernel<DIM, TIN>), dim3((unsigned)N, (unsigned)slabs), dim3(FWD_THREADS), tab_bytes, s,
                        maps, boxes, box_ind, level, B, ch, cw, cd, C, crops);
     return check_launch();

@@ -57,6 +57,41 @@ __device__ __forceinline__ float axis_weight(const AxisEntry &e, int idx)
     return w;
 }
 
+// input element of the forward kernels: fp32, or bf16 (raw 16-bit pattern, widened exactly to fp32 on load -- the interpolation itself is
+// always fp32; used by the autocast inference path, where it halves the gathered bytes), or uint8 (round 4: the GT masks of a training
+// batch travel and stay as uint8; the mask-target crop of detection_target_layer, mrcnn.py:551-563, reads them as they are)
+struct bf16raw { unsigned short v; };
+struct u8raw { unsigned char v; };
+__device__ __forceinline__ float ld(const float *p, long long i) { return p[i]; }
+__device__ __forceinline__ float ld(const bf16raw *p, long long i) { return __uint_as_float(((unsigned int)p[i].v) << 16); }
+__device__ __forceinline__ float ld(const u8raw *p, long long i) { return (float)p[i].v; }
+// four consecutive elements (16 / 8 / 4 bytes), widened exactly
+__device__ __forceinline__ void ld4(const float *p, long long i, float o[4]) { const v4f q = *reinterpret_cast<const v4f *>(p + i); o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; }
+__device__ __forceinline__ void ld4(const bf16raw *p, long long i, float o[4])
+{
+    const uint2 q = *reinterpret_cast<const uint2 *>(p + i);
+    o[0] = __uint_as_float(q.x << 16); o[1] = __uint_as_float(q.x & 0xffff0000u); o[2] = __uint_as_float(q.y << 16); o[3] = __uint_as_float(q.y & 0xffff0000u);
+}
+__device__ __forceinline__ void ld4(const u8raw *p, long long i, float o[4])
+{
+    const unsigned int q = *reinterpret_cast<const unsigned int *>(p + i);
+    o[0] = (float)(q & 255u); o[1] = (float)((q >> 8) & 255u); o[2] = (float)((q >> 16) & 255u); o[3] = (float)(q >> 24);
+}
+
+// the maps of a launch: one level, or all pyramid levels (mrcnn.py:373-457 pools every RoI on exactly one level)
+constexpr int PYR_MAX_LEVELS = 5;
+struct PyramidMaps {
+    const void *image[PYR_MAX_LEVELS];
+    int H[PYR_MAX_LEVELS], W[PYR_MAX_LEVELS], D[PYR_MAX_LEVELS];
+    int n_levels;
+};
+
+// roi_align_fwd.hip: 3D forward, channel-quad form (round 5).  MDT_ERR_UNSUPPORTED: outside its budgets -> the caller falls back to the
+// direct kernel of roi_align.hip.  `level` may be null (every RoI on level 0).
+template <typename TIN>
+int launch_fwd_cq(const PyramidMaps &maps, const float *boxes, const int *box_ind, const int *level, int N, int B,
+                  int ch, int cw, int cd, int C, float *crops, hipStream_t s);
+
 inline int check_launch()
 {
     const hipError_t e = hipGetLastError();

@@ -79,6 +79,9 @@ class FlatAdam(torch.optim.Adam):
             for p in plist:
                 cmap[id(p)] = i
         self._cond = (net, cmap, len(spec))
+        # the tensor exists from now on (the first step's forward runs BEFORE the lazy `_build`): ones = "everything has a gradient"
+        self._cond_buf = torch.ones(len(spec), dtype=torch.float32, device=next(net.parameters()).device)
+        net.set_grad_cond_buffer(self._cond_buf)
         self._flat = None
         return self
 
@@ -101,11 +104,14 @@ class FlatAdam(torch.optim.Adam):
             fgrad = gs.flat if gs.n_extra == 0 else gs.flat[:n]
             gs.defer_div = True         # this optimizer divides by the world size inside its launch
             cond_t = gs.extra[:n_cond] if n_cond else None
+            if cond_t is not None and cond_t.data_ptr() != self._cond_buf.data_ptr():
+                cond_t.copy_(self._cond_buf)                 # what the step has already written (the first forward precedes this build)
         else:
             fgrad = torch.zeros(n, dtype=torch.float32, device=dev)
-            cond_t = torch.ones(n_cond, dtype=torch.float32, device=dev) if n_cond else None
+            cond_t = self._cond_buf if n_cond else None
         if self._cond is not None:
             self._cond[0].set_grad_cond_buffer(cond_t)      # the step writes its counts straight into this tensor
+            self._cond_buf = cond_t
         fparam = torch.empty(n, dtype=torch.float32, device=dev)
         fm = torch.zeros(n, dtype=torch.float32, device=dev)
         fv = torch.zeros(n, dtype=torch.float32, device=dev)

@@ -166,6 +166,7 @@ def test_mrcnn_four_steps_one_without_positives_equal_torch_adam_bit_for_bit(cud
             cond_of[id(p)] = i
     names = [n for n, _ in net_a.named_parameters()]
     skipped_in_step2 = None
+    n_updates = {}
     for it, batch in enumerate((full, empty, full, full)):
         torch.manual_seed(10 + it)
         res = net_a.train_forward(batch, monitor=False)
@@ -173,7 +174,11 @@ def test_mrcnn_four_steps_one_without_positives_equal_torch_adam_bit_for_bit(cud
         res["torch_loss"].backward()
         cond = net_a._grad_cond.detach().cpu().tolist()
         n_valid, n_pos = (int(v) for v in res["sample_counts"])
-        assert (n_pos > 0) == (it != 1) and cond[3] == n_pos and cond[2] == n_valid
+        assert cond[3] == n_pos and cond[2] == n_valid
+        if it == 0:
+            assert n_pos > 0            # (later full-batch steps may lose their positives again: the weights have moved)
+        if it == 1:
+            assert n_pos == 0
         absent = []
         for (n, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
             have = pa.grad is not None and (id(pa) not in cond_of or cond[cond_of[id(pa)]] > 0)
@@ -182,6 +187,9 @@ def test_mrcnn_four_steps_one_without_positives_equal_torch_adam_bit_for_bit(cud
                 absent.append(n)
         if it == 1:
             skipped_in_step2 = set(absent)
+        for n in names:
+            if n not in absent:
+                n_updates[n] = n_updates.get(n, 0) + 1
         before = [p.detach().clone() for p in net_a.parameters()]
         oa.step()
         ob.step()
@@ -194,7 +202,8 @@ def test_mrcnn_four_steps_one_without_positives_equal_torch_adam_bit_for_bit(cud
     sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
     for k, n in enumerate(names):
         if k in sb:
-            assert float(sa[k]["step"]) == float(sb[k]["step"]) == (3.0 if n in skipped_in_step2 else 4.0), n
+            assert float(sa[k]["step"]) == float(sb[k]["step"]) == float(n_updates[n]), n
+            assert float(sa[k]["step"]) <= (3.0 if n in skipped_in_step2 else 4.0)
             assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"]), n
         else:
             assert float(sa[k]["step"]) == 0.0, n           # torch keeps no state for a parameter that never had a gradient

@@ -1,6 +1,8 @@
-"""RoIAlign-3D forward at the reference's inference / training call sizes, event-timed through the Python boundary: the wave-staged
-kernel (round 4, default) against the direct kernel (MDT_FWD_KERNEL=direct, read once per process), fp32 and bf16 maps, bit-compared with
-each other.  One JSON line per case.  usage: [MDT_FWD_KERNEL=direct] python tools/fwd_bench.py"""
+"""RoIAlign-3D forward at the reference's inference / training call sizes, event-timed through the Python boundary (round 5: the
+channel-quad kernel of csrc/roi_align_fwd.hip; the round-4 figures of the wave-staged and direct kernels are in profiles/r04/), fp32 and bf16
+maps.  One JSON line per case.  Algorithmic bytes as SURVEY.md 8(d) defines them for the forward: 4 N C P written + every TOUCHED input
+voxel once (4 C x the voxel box the RoI's samples reach, floor .. ceil per axis) + 28 N; `out_only_frac` is the output bytes alone against
+8 TB/s (what VERDICT r4 quoted).  usage: python tools/fwd_bench.py"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +11,7 @@ from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
 from medicaldetectiontoolkit_amd.utils.synthetic_data import random_boxes_3d, trainlike_rois_3d
 
 dev = torch.device("cuda:0")
-kern = os.environ.get("MDT_FWD_KERNEL", "wave")
+kern = "cq"
 rng = np.random.default_rng(0)
 torch.manual_seed(0)
 B, C = 8, 36
@@ -29,6 +31,24 @@ def time_op(fn, n=50):
     return float(np.mean(t)), float(t[len(t) // 2])
 
 
+def touched_voxels(boxes, shape, crop):
+    """per RoI: product over the axes of (max ceil - min floor + 1) of its sample coordinates (crop_and_resize_kernel.cu:51-75)"""
+    tot = 0
+    for bx in np.asarray(boxes, dtype=np.float64):
+        n = 1
+        for a, (lo, hi) in enumerate(((0, 2), (1, 3), (4, 5))):
+            L, Pn = shape[a], crop[a]
+            if Pn > 1:
+                sc = (bx[hi] - bx[lo]) * L / Pn
+                t = bx[lo] * L + np.arange(Pn) * sc + sc / 2 - 0.5
+            else:
+                t = np.array([0.5 * (bx[lo] + bx[hi]) * L])
+            t = np.clip(t, 0, L - 1)
+            n *= int(np.ceil(t).max() - np.floor(t).min() + 1)
+        tot += n
+    return tot
+
+
 cases = [("N240_14x14x5_P2_survey_boxes", P2, random_boxes_3d(rng, 240), rng.integers(0, B, 240), (14, 14, 5)),
          ("N600_7x7x3_P2_survey_boxes", P2, random_boxes_3d(rng, 600), rng.integers(0, B, 600), (7, 7, 3)),
          ("N4096_7x7x3_P2_survey_boxes", P2, random_boxes_3d(rng, 4096), rng.integers(0, B, 4096), (7, 7, 3)),
@@ -40,7 +60,10 @@ for tag, img, boxes, ind, crop in cases:
         im = img if dt == "f32" else img.bfloat16()
         out = _roi_align_impl.crop_forward(im, bx, bi, crop)
         mean, med = time_op(lambda: _roi_align_impl.crop_forward(im, bx, bi, crop))
-        byts = 4.0 * out.numel() + 28 * len(boxes)
+        esz = 4 if dt == "f32" else 2
+        tv = touched_voxels(boxes, tuple(img.shape[2:]), crop)
+        byts = 4.0 * out.numel() + esz * C * tv + 28 * len(boxes)
         print(json.dumps({"case": tag, "map": dt, "kernel": kern, "avg_us": round(mean, 2), "median_us": round(med, 2), "out_MB": round(4e-6 * out.numel(), 2),
+                          "touched_input_MB": round(esz * C * tv / 1e6, 2), "alg_MB": round(byts / 1e6, 2),
                           "GBps": round(byts / mean / 1e3, 1), "frac_of_8TBps": round(byts / (mean * 1e-6) / 8e12, 4),
-                          "checksum": float(out.double().sum())}), flush=True)
+                          "out_only_frac": round(4.0 * out.numel() / (mean * 1e-6) / 8e12, 4), "checksum": float(out.double().sum())}), flush=True)
