@@ -420,11 +420,13 @@ def graph_preflight_main(args):
     print("GRAPH_LEGS " + json.dumps(rec), flush=True)
 
 
-def exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph):
+def exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph, deferred=True):
     """exec.py:67-79 as the reference runs it: `batch = next(batch_gen)` (host numpy), `results = net.train_forward(batch)`, zero_grad,
     backward, step, then the consumers of results_dict (`logger_string` logged, `boxes` appended for the training metrics,
     `monitor_values` plotted) -- with the mask head over the detections on (mrcnn.py:1046-1048).  The batch stream goes through
-    training.DevicePrefetcher; the read-out is one packed device->host copy per step (1 sync per step)."""
+    training.DevicePrefetcher; the read-out is one packed device->host copy per step.  deferred=True (round 5): that copy is asynchronous and
+    the entries of step i are consumed while step i + 1 is already queued (monitor="deferred": exec.py's log line / box list arrive one batch
+    late, no host sync in the step); deferred=False: the synchronous read-out of round 4 (1 sync per step)."""
     from medicaldetectiontoolkit_amd import training
     from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch
     n = max(3, min(args.steps, 8))
@@ -433,13 +435,15 @@ def exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph):
     prev = getattr(cf, "run_detection_mask_head_in_training", False)
     cf.run_detection_mask_head_in_training = True
     try:
+        mode = "deferred" if deferred else True
         if use_graph:
-            xstep = training.GraphedTrainStep(net, opt, gmax=args.gmax, monitor=True, with_masks=True)
+            xstep = training.GraphedTrainStep(net, opt, gmax=args.gmax, monitor=mode, with_masks=True)
         else:
             def xstep(b):
-                return training.train_step(net, opt, b, monitor=True)
+                return training.train_step(net, opt, b, monitor=mode)
         pf = training.DevicePrefetcher(seq, dev)
         consumed = 0
+        last_log = None
         for _ in range(2):                       # capture / warm-up
             res = xstep(next(pf))
         torch.cuda.synchronize()
@@ -454,7 +458,9 @@ def exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph):
             if b is None:
                 break
             res = xstep(b)
-            consumed += len(res["logger_string"]) + len(res["boxes"]) + len(res["monitor_values"])     # what exec.py:76-79 reads every batch
+            if "logger_string" in res:       # (deferred: absent on the very first call only)
+                consumed += len(res["logger_string"]) + len(res["boxes"]) + len(res["monitor_values"])     # what exec.py:76-79 reads every batch
+                last_log = res["logger_string"]
         torch.cuda.synchronize()
         dt = time.time() - t0
     finally:
@@ -465,9 +471,11 @@ def exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph):
         host_ms = {k: round(v / c, 2) for k, v in xstep.host_ms.items()}
         host_ms["wait_for_next_batch"] = round(t_wait / c * 1e3, 2)
     return {"value": round(args.batch * n / dt, 3), "unit": "patches/s", "steps": n, "ms_per_step": round(dt / n * 1e3, 2),
-            "device_to_host_syncs_per_step": 1, "graph": bool(use_graph), "host_ms_per_step": host_ms, "last_logger_string": res["logger_string"],
-            "note": "host numpy batches (training.DevicePrefetcher: upload of batch i+1 behind step i) + monitoring read-out every step (one packed D2H) "
-                    "+ mask head over the detections (mrcnn.py:1046-1048) + box lists built on the host"}
+            "device_to_host_syncs_per_step": 0 if deferred else 1, "readout": "deferred by one step (asynchronous copy)" if deferred else "synchronous",
+            "graph": bool(use_graph), "host_ms_per_step": host_ms, "last_logger_string": last_log,
+            "note": "host numpy batches (training.DevicePrefetcher: upload of batch i+1 behind step i) + monitoring read-out every step (one packed D2H"
+                    + (", asynchronous: the entries of step i are consumed after step i+1 was queued" if deferred else "") +
+                    ") + mask head over the detections (mrcnn.py:1046-1048) + box lists built on the host"}
 
 
 def secondary_configs(timeout_s=240):
@@ -598,6 +606,7 @@ def main():
     ap.add_argument("--sparse-rpn-loss", type=int, default=1, help="1 (default): the RPN losses differentiate through the 48 sampled anchors only (models/mrcnn.rpn_at_anchors; the dense RPN forward carries no graph); 0: through the dense outputs like the reference (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
     ap.add_argument("--pool-cl", type=int, default=1, help="1 (default): channels-last max pooling kernel of the stem (csrc/pool.hip); 0: torch (A/B)")
+    ap.add_argument("--pin-cores", type=int, default=1, help="N > 1: 1 (default) pins every rank to its own slice of the cores of its GPU's NUMA node (utils/affinity.py); 0: only caps the intra-op threads")
     ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
     ap.add_argument("--channels-last", type=int, default=1)
     ap.add_argument("--host-batches", action="store_true", help="hand numpy batches to train_forward (PCIe-inclusive rate)")
@@ -630,8 +639,14 @@ def main():
     local_dev = local_rank % n_dev      # == local_rank whenever there is one GPU per rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:   # N processes share the host: do not let each spin up one intra-op thread per core
-        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    affinity_rec = None
+    if world > 1:   # N processes share the host: each rank gets a disjoint slice of the cores of its GPU's NUMA node (utils/affinity.py)
+        from medicaldetectiontoolkit_amd.utils import affinity
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if args.pin_cores:
+            affinity_rec = affinity.pin_rank(local_rank, lw, [r % n_dev for r in range(lw)])
+        else:
+            torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -850,6 +865,7 @@ def main():
                 exec_eq = exec_equivalent_leg(net, opt, cf, patch, args, dev, False)
             else:
                 exec_eq = exec_equivalent_leg(net, opt, cf, patch, args, dev, False)
+                exec_eq["synchronous_readout_form"] = exec_equivalent_leg(net, opt, cf, patch, args, dev, False, deferred=False)
                 g_eq = (child_legs or {}).get("exec_equivalent_graphed")
             if g_eq and "value" in g_eq:
                 exec_eq = dict(g_eq, eager_form=exec_eq) if g_eq["value"] >= exec_eq["value"] else dict(exec_eq, graphed_form=g_eq)
@@ -872,7 +888,8 @@ def main():
         dist.all_gather_object(devices, "rank %d: cuda:%d %s" % (rank, local_dev, torch.cuda.get_device_name(dev)))
     dist_rec = {"world": world, "backend": (dist.get_backend() if world > 1 else None), "devices": devices,
                 "param_checksum": float(cmin.item()), "params_identical_across_ranks": bool(cmin.item() == cmax.item()),
-                "grad_buckets": (len(sync.bucket_range) if sync is not None and sync.flat is not None else None)}
+                "grad_buckets": (len(sync.bucket_range) if sync is not None and sync.flat is not None else None),
+                "rank0_core_affinity": affinity_rec}
 
     if rank == 0:
         roofline = None if args.no_roofline else roialign_bwd_roofline(cf, args.batch, dev, prof, prof48)

@@ -903,6 +903,9 @@ class net(nn.Module):
     def train_forward(self, batch, is_validation=False, monitor=True):
         """mrcnn.py:853-967.  batch: the reference's batch dict (numpy): 'data', 'roi_labels', 'bb_target', 'roi_masks'.
         monitor=False skips the read-out and the python box lists (the loss terms are unchanged).
+        monitor="deferred": the read-out entries ('boxes', 'monitor_values', 'logger_string', ...) returned are those of the PREVIOUS
+        call (`results["monitor_of_previous_step"] = True`; absent on the first call) -- the packed buffer travels with an asynchronous
+        copy and nothing in the step waits for the GPU (utils.model_utils.DeferredReadout); `flush_deferred_monitor()` hands out the last one.
         The mask head over the DETECTIONS (mrcnn.py:1046-1048) only feeds the validation read-out (return_masks, :949); in a training
         step its result is dropped by the reference and it is not run here, unless cf.run_detection_mask_head_in_training asks for the
         reference's exact work (bench.py `exec_equivalent`)."""
@@ -912,10 +915,28 @@ class net(nn.Module):
         out = self.train_forward_device(d["img"], d["gt"], d["masks"], with_masks=with_masks)
         # the five terms of mrcnn.py:946 as device scalars (no read-out here): what the assembled-step parity test compares
         results_dict = {"torch_loss": out["loss"], "loss_terms": out["terms"], "sample_counts": out["sample_counts"]}
-        if monitor:
+        if monitor == "deferred":
+            if getattr(self, "_deferred", None) is None:
+                self._deferred = mutils.DeferredReadout()
+            prev = self._deferred.push(self.monitor_pack(out), (batch, tuple(d["img"].shape), is_validation))
+            if prev is not None:
+                results_dict.update(self._resolve_deferred(prev))
+        elif monitor:
             results_dict.update(self.monitor_results(self.monitor_pack(out), batch, tuple(d["img"].shape), is_validation,
                                                      detection_masks=out["mon"]["detection_masks"]))
         return results_dict
+
+    def _resolve_deferred(self, entry):
+        packed, (batch, img_shape, is_validation) = mutils.DeferredReadout.resolve(entry)
+        res = self.monitor_results(packed, batch, img_shape, is_validation, detection_masks=None)
+        res["monitor_of_previous_step"] = True
+        return res
+
+    def flush_deferred_monitor(self):
+        """read-out entries of the LAST train_forward(monitor="deferred") call, or None"""
+        d = getattr(self, "_deferred", None)
+        entry = d.flush() if d is not None else None
+        return self._resolve_deferred(entry) if entry is not None else None
 
     def test_forward(self, batch, return_masks=True):
         """mrcnn.py:969-985."""

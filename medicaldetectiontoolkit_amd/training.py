@@ -437,7 +437,8 @@ class GraphedTrainStep(object):
         if isinstance(optimizer, FlatAdam) and optimizer._grad_sync is not grad_sync:
             raise ValueError("GraphedTrainStep: optimizer and step disagree about the grad_sync")
         self.net, self.opt, self.sync = net, optimizer, grad_sync
-        self.gmax, self.monitor, self.with_masks, self.warmup = int(gmax), bool(monitor), bool(with_masks), int(warmup)
+        self.gmax, self.monitor, self.with_masks, self.warmup = int(gmax), (monitor if monitor == "deferred" else bool(monitor)), bool(with_masks), int(warmup)
+        self._deferred = None
         self.max_masks = max_masks
         self.graph = None
         self.static = None
@@ -594,7 +595,17 @@ class GraphedTrainStep(object):
         out = self._out
         # NOTE: these are the graph's STATIC output tensors -- the next call overwrites them; read (or clone) them before it
         res = {"torch_loss": out["loss"].detach(), "loss_terms": out["terms"], "sample_counts": out["sample_counts"]}
-        if self.monitor:
+        if self.monitor == "deferred":             # step i's read-out is handed out by call i + 1: no sync, the host never waits for the GPU
+            from .utils import model_utils as mu
+            if self._deferred is None:
+                self._deferred = mu.DeferredReadout()
+            prev = self._deferred.push(self._packed, (batch, tuple(self.static["img"].shape)))
+            if prev is not None:
+                packed, (pbatch, pshape) = mu.DeferredReadout.resolve(prev)
+                r = self.net.monitor_results(packed, pbatch, pshape, False, detection_masks=None)
+                r["monitor_of_previous_step"] = True
+                res.update(r)
+        elif self.monitor:
             host = self._packed[0].detach().cpu()                 # the ONE device->host copy (and the one sync) of the step
             t4 = time.perf_counter()
             res.update(self.net.monitor_results((host.numpy(), self._packed[1]), batch, tuple(self.static["img"].shape), False,
@@ -609,6 +620,21 @@ class GraphedTrainStep(object):
             hm["collective_adam"] = hm.get("collective_adam", 0.0) + (t3 - t2) * 1e3
             hm["calls"] = hm.get("calls", 0) + 1
         return res
+
+
+def flush_deferred_monitor(step_or_net):
+    """the read-out entries of the LAST step of a monitor="deferred" run (train_step: pass the net; GraphedTrainStep: pass the step)"""
+    if isinstance(step_or_net, GraphedTrainStep):
+        d = step_or_net._deferred
+        entry = d.flush() if d is not None else None
+        if entry is None:
+            return None
+        from .utils import model_utils as mu
+        packed, (pbatch, pshape) = mu.DeferredReadout.resolve(entry)
+        r = step_or_net.net.monitor_results(packed, pbatch, pshape, False, detection_masks=None)
+        r["monitor_of_previous_step"] = True
+        return r
+    return step_or_net.flush_deferred_monitor()
 
 
 class DevicePrefetcher(object):

@@ -249,6 +249,45 @@ def pack_for_readout(items):
     return torch.cat(flat), layout
 
 
+class DeferredReadout(object):
+    """The monitoring read-out one step LATE: the packed device buffer of step i travels to a pinned host buffer with an asynchronous copy
+    (no sync in step i), and is turned into the reference's results entries when step i + 1 asks -- by then the copy has long finished, so
+    the host never waits for the GPU and the GPU never idles while the host builds box lists.  exec.py:76-79 logs / collects the same
+    values, one batch later.  Two pinned buffers alternate (step i + 1's copy must not land in the buffer step i's values are read from)."""
+
+    def __init__(self):
+        self.bufs = [None, None]
+        self.k = 0
+        self.pending = None          # (event, host tensor, layout, context)
+
+    def push(self, packed, context):
+        """enqueue the copy of `packed` = (device int32 buffer, layout); returns what was pending before (or None)"""
+        buf, layout = packed
+        prev = self.pending
+        host = self.bufs[self.k]
+        if host is None or host.numel() < buf.numel():
+            host = self.bufs[self.k] = torch.empty(int(buf.numel()), dtype=torch.int32).pin_memory()
+        view = host[:buf.numel()]
+        view.copy_(buf.detach(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (ev, view, layout, context)
+        self.k ^= 1
+        return prev
+
+    @staticmethod
+    def resolve(entry):
+        """(numpy view of the arrived buffer, layout), context -- waits for the copy's event (a no-op one step later)"""
+        ev, view, layout, context = entry
+        ev.synchronize()
+        return (view.numpy(), layout), context
+
+    def flush(self):
+        """the last step's entry (end of an epoch)"""
+        prev, self.pending = self.pending, None
+        return prev
+
+
 def unpack_readout(packed):
     """host side of pack_for_readout: {name: numpy array}; `packed[0]` may be the device buffer (copied here: the one sync of the
     read-out) or a host tensor / numpy array that was already copied"""

@@ -334,3 +334,26 @@ def test_rpn_losses_through_sampled_anchors_equal_the_dense_graph_losses():
     for a, b in zip(ga, gb):
         assert float((a - b).abs().max()) <= 1e-12 * max(1.0, float(a.abs().max()))
     assert any(float(g.abs().max()) > 0 for g in ga[:4])
+
+
+def test_rank_core_plan_is_disjoint_and_numa_local():
+    """utils/affinity.plan: ranks sharing a NUMA node split its cores evenly; unknown topology -> even split of the allowed cores; the slices
+    of different ranks never overlap; more ranks than cores degrade to sharing instead of an empty set"""
+    from medicaldetectiontoolkit_amd.utils import affinity
+    assert affinity.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(128))
+    nodes = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    slices = [affinity.plan(r, 8, allowed, numa, nodes) for r in range(8)]
+    assert all(len(s) == 16 for s in slices)
+    assert all(set(s) <= set(nodes[numa[r]]) for r, s in enumerate(slices))
+    assert len(set().union(*map(set, slices))) == 128
+    # topology not exposed (numa_node = -1 in a container): even split
+    slices = [affinity.plan(r, 4, allowed, [None] * 4, nodes) for r in range(4)]
+    assert [len(s) for s in slices] == [32] * 4 and len(set().union(*map(set, slices))) == 128
+    # a restricted cpuset (cgroup): only allowed cores are handed out
+    slices = [affinity.plan(r, 2, [4, 5, 6, 7], [0, 0], nodes) for r in range(2)]
+    assert slices == [[4, 5], [6, 7]]
+    assert affinity.plan(5, 8, [0, 1], None, None) == [1]
+    rec = affinity.pin_rank(0, 1, [0], set_torch_threads=False)
+    assert rec["pinned"] and rec["cores"] >= 1

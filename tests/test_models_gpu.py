@@ -351,3 +351,34 @@ def test_train_py_exec_loop_graphed_then_resumed_eager(cuda, tmp_path):
     assert "resumed to checkpoint at epoch 2" in r2.stdout
     lines = [l for l in r2.stdout.splitlines() if l.startswith("tr. batch")]
     assert len(lines) == 3 and all("(ep. 2)" in l for l in lines), r2.stdout[-800:]
+
+
+def test_deferred_monitor_readout_equals_synchronous_one_step_late(cuda):
+    """train_forward(monitor="deferred") hands out, at call i + 1, exactly the read-out entries the synchronous monitor=True form returns
+    at call i (exec.py:76-79 consumes them one batch later; no host sync in the step); flush_deferred_monitor() delivers the last one"""
+    patch, B = [64, 64, 32], 2
+    cf = Configs(dim=3, model="mrcnn", patch_size=patch, batch_size=B)
+    torch.manual_seed(0)
+    net = mrcnn.net(cf, device=cuda)
+    batches = [make_batch(patch, B, seed=s) for s in (3, 4, 5)]
+    sync = []
+    for i, b in enumerate(batches):
+        torch.manual_seed(50 + i)
+        sync.append(net.train_forward(b, monitor=True))
+    got = []
+    for i, b in enumerate(batches):
+        torch.manual_seed(50 + i)
+        r = net.train_forward(b, monitor="deferred")
+        assert ("logger_string" in r) == (i > 0)
+        if i > 0:
+            assert r["monitor_of_previous_step"]
+            got.append(r)
+    got.append(net.flush_deferred_monitor())
+    assert net.flush_deferred_monitor() is None
+    for s, g in zip(sync, got):
+        assert s["logger_string"] == g["logger_string"] and s["monitor_values"] == g["monitor_values"]
+        assert len(s["boxes"]) == len(g["boxes"])
+        for bs, bg in zip(s["boxes"], g["boxes"]):
+            assert [x["box_type"] for x in bs] == [x["box_type"] for x in bg]
+            for x, y in zip(bs, bg):
+                assert np.array_equal(np.asarray(x["box_coords"]), np.asarray(y["box_coords"]))
