@@ -90,20 +90,15 @@ int mdt_crop_and_resize_2d_forward_u8(
  *   crop_and_resize_gpu.c:61): every byte of grads_image is written exactly once, without atomics.
  * grads [num_boxes, depth, ch, cw, cd]; grads_image [batch, depth, H, W, D].
  *
- * Default form: ONE launch, no workspace (csrc/roi_align_bwd.hip).  Workgroups of a "zero" role stream 16-byte zero
- * stores over everything outside the index bounding boxes of the RoIs ("territory", a bitmap every workgroup
- * rebuilds from `boxes`); one workgroup per (batch element, channel) of a "scatter" role computes the territory
- * from LDS: per-axis interpolation as separable streaming passes into compact per-RoI blocks, then one ordered sum
- * per voxel over the RoIs covering it.  Deterministic run to run; sums are reassociated relative to the
- * reference's flat 8-corner scatter, so values agree to fp32 rounding (bar: 1e-4).
- * Dispatch: the single-launch form runs for num_boxes <= 128 and batch * depth <= 1024 volumes on shapes within its LDS
- * budgets; more RoIs, more (batch element, channel) volumes (the 2D models: 20 x 192 small maps) or shapes beyond the
- * budgets (pool extents > 64, very large maps) run the two-kernel form below; pool extents beyond that form's budget
- * fall back to the _ordered kernel.
- * workspace: mdt_crop_and_resize_backward_workspace_bytes(...) -- the query has no batch argument, so it answers 256
- * bytes (unused) only when the single-launch form is certain (dim == 3, depth <= 128, num_boxes <= 128, shape
- * supported) and the two-kernel size otherwise.  A call that would prefer the two-kernel form but was given less than
- * its workspace still runs (single-launch form, slower), it never fails for that reason.
+ * ONE launch, no workspace, no atomics (csrc/roi_align_bwd_v3.hip): workgroups of a "zero" role stream 16-byte zero
+ * stores over everything outside the index bounding boxes of the RoIs (a bitmap every workgroup rebuilds from `boxes`); one
+ * workgroup per (batch element, channel) of a "scatter" role computes the rest from LDS as wave-uniform separable passes and one
+ * ordered sum per voxel over the RoIs covering it.  Deterministic run to run; sums are reassociated relative to the reference's
+ * flat 8-corner scatter, so values agree to fp32 rounding (bar: 1e-4).  2D maps are its W = 1 case.
+ * Beyond its budgets (more than 128 RoIs, pool extents or maps beyond its LDS plan) the call runs the exact-order kernel
+ * (mdt_crop_and_resize_*_backward_ordered below: any shape, bit-exact against the sequential oracle, slower).
+ * `workspace` is not used any more (round 5: the two-kernel form that needed one is A/B history in libmdt_hip_ab.so); the argument and
+ * the query (which answers a token 256) stay for ABI stability -- NULL / 0 is fine.
  */
 size_t mdt_crop_and_resize_backward_workspace_bytes(int dim, int num_boxes, int depth,
                                                    int image_height, int image_width, int image_zdepth,
@@ -114,22 +109,6 @@ int mdt_crop_and_resize_3d_backward(
     int crop_height, int crop_width, int crop_zdepth, int depth,
     float *grads_image, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Two-kernel separable form (round-1 default, kept as A/B baseline and fallback): kernel 1 = per-(RoI, channel)
- * expansion into compact blocks in `workspace` running beside a zero-fill role; kernel 2 patches the touched voxels.
- * workspace: mdt_crop_and_resize_backward_twophase_workspace_bytes(...), 16-byte aligned.  Same numerics contract. */
-size_t mdt_crop_and_resize_backward_twophase_workspace_bytes(int dim, int num_boxes, int depth,
-                                                            int image_height, int image_width, int image_zdepth,
-                                                            int crop_height, int crop_width, int crop_zdepth);
-int mdt_crop_and_resize_3d_backward_twophase(
-    const float *grads, const float *boxes, const int *box_ind,
-    int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
-    int crop_height, int crop_width, int crop_zdepth, int depth,
-    float *grads_image, void *workspace, size_t workspace_bytes, void *stream);
-int mdt_crop_and_resize_2d_backward_twophase(
-    const float *grads, const float *boxes, const int *box_ind,
-    int num_boxes, int batch, int image_height, int image_width,
-    int crop_height, int crop_width, int depth,
-    float *grads_image, void *workspace, size_t workspace_bytes, void *stream);
 
 /* All pyramid levels in ONE launch: replaces the per-level loop of mrcnn.py:373-457 (pyramid_roi_align: level rule :403,
  * one CropAndResizeFunction call per level :431-437, torch.cat + sort back :440-455).
@@ -151,10 +130,6 @@ int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, co
                                    const int *D, int crop_height, int crop_width, int crop_zdepth,
                                    float *const *grads_images, void *stream);
 
-/* Tuning hook of the default backward (tools/bwd_stage_probe.py, tools/bwd_trace_probe.py): when set to a device buffer of
- * >= 64 + 4 * grid int64 entries the kernel records per-stage / per-workgroup wall-clock stamps there; NULL (default)
- * turns it off.  Not part of the reference's interface. */
-void mdt_debug_bwd_timestamps(long long *dev_buf);
 /* Same for the round-3 gather-form backward (csrc/roi_align_bwd_v3.hip; tools/bwd3_probe.py): dev_buf >= 16 int64 or NULL;
  * dbg bit0 / bit1 make the scatter / zero role return at once (role-by-role timing); wg = traced scatter workgroup. */
 void mdt_debug_bwd3(long long *dev_buf, int dbg, int wg);
@@ -171,13 +146,6 @@ int mdt_crop_and_resize_3d_backward_ordered(
     int crop_height, int crop_width, int crop_zdepth, int depth,
     float *grads_image, void *stream);
 
-/* A/B variant: vectorised zero-fill kernel followed by an fp32 global-atomic scatter
- * (the reference's algorithm, order-nondeterministic). */
-int mdt_crop_and_resize_3d_backward_atomic(
-    const float *grads, const float *boxes, const int *box_ind,
-    int num_boxes, int batch, int image_height, int image_width, int image_zdepth,
-    int crop_height, int crop_width, int crop_zdepth, int depth,
-    float *grads_image, void *stream);
 
 /* 2D twins: cuda_functions/roi_align_2D/roi_align/src/cuda/crop_and_resize_kernel.h
  * (kernels crop_and_resize_kernel.cu:11-99, 102-194; glue crop_and_resize_gpu.c:7-67).

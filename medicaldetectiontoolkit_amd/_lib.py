@@ -27,12 +27,8 @@ _SIGNATURES = {
     "mdt_crop_and_resize_2d_forward_u8": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
     "mdt_crop_and_resize_backward_workspace_bytes": (c_size_t, [c_int] * 9),
     "mdt_crop_and_resize_3d_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "mdt_crop_and_resize_backward_twophase_workspace_bytes": (c_size_t, [c_int] * 9),
-    "mdt_crop_and_resize_3d_backward_twophase": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "mdt_crop_and_resize_2d_backward_twophase": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_pyramid_roi_align_forward": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mdt_pyramid_roi_align_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "mdt_debug_bwd_timestamps": (None, [c_void_p]),
     "mdt_debug_bwd3": (None, [c_void_p, c_int, c_int]),
     "mdt_debug_fwd_stamps": (None, [c_void_p]),
     "mdt_upsample2x_yx_cl_forward": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_longlong, c_void_p]),
@@ -55,7 +51,6 @@ _SIGNATURES = {
     "mdt_conv1x1_wgrad_workspace_bytes": (c_size_t, [ctypes.c_longlong, c_int, c_int]),
     "mdt_conv1x1_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mdt_crop_and_resize_3d_backward_ordered": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
-    "mdt_crop_and_resize_3d_backward_atomic": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
     "mdt_crop_and_resize_2d_forward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p, c_void_p]),
     "mdt_crop_and_resize_2d_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_crop_and_resize_2d_backward_ordered": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p]),
@@ -88,6 +83,35 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+# libmdt_hip_ab.so (include/mdt_hip_ab.h): superseded kernel generations, A/B baselines and test subjects ONLY -- nothing under
+# medicaldetectiontoolkit_amd/ calls ab_lib() on its own; tests and tools ask for these modes explicitly
+AB_LIB_PATH = os.path.join(_HERE, "libmdt_hip_ab.so")
+_AB_SIGNATURES = {
+    "mdt_crop_and_resize_backward_twophase_workspace_bytes": (c_size_t, [c_int] * 9),
+    "mdt_crop_and_resize_3d_backward_twophase": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_crop_and_resize_2d_backward_twophase": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdt_debug_bwd_timestamps": (None, [c_void_p]),
+    "mdt_crop_and_resize_3d_backward_atomic": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
+    "mdt_ab_crop_and_resize_backward_territory": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
+}
+_ab_lib = None
+
+
+def ab_lib():
+    """the A/B library (tests / tools); raises if it was not built"""
+    global _ab_lib
+    if _ab_lib is None:
+        if not os.path.exists(AB_LIB_PATH):
+            raise RuntimeError("libmdt_hip_ab.so not found at %s -- make -C medicaldetectiontoolkit_amd/csrc" % AB_LIB_PATH)
+        lib()           # (torch's HIP runtime first, see lib())
+        handle = ctypes.CDLL(AB_LIB_PATH)
+        for name, (res, args) in _AB_SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _ab_lib = handle
+    return _ab_lib
 
 
 def lib():

@@ -41,7 +41,7 @@
 //   * Small volumes (P4/P5, 2D maps): no zero role, the scatter workgroup also zero-fills the rest of its volume.
 //
 // HBM-bound, no MFMA.  Algorithmic bytes per launch: 4*B*C*V (grads_image once) + 4*N*C*P (grads once) + 28*N.
-#include "roi_align_common.h"
+#include "roi_align_ab_common.h"
 
 using namespace mdt_ra;
 

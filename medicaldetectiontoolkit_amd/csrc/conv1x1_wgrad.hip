@@ -197,9 +197,8 @@ bool make_plan(long long V, int Cout, int Cin, Plan &p)
     p.mt = mt; p.nt = nt;
     p.groups_m = (tm + mt - 1) / mt;
     p.groups_n = (tn + nt - 1) / nt;
-    // workgroups per CU (MDT_WGRAD_WGS_PER_CU overrides), never more than one block per wave would justify
-    static const int forced = [] { const char *e = getenv("MDT_WGRAD_WGS_PER_CU"); return e ? atoi(e) : 0; }();
-    const int per_cu = forced > 0 ? forced : (mt * nt == 1 ? 4 : 2);      // measured: 18 -> 18 59 vs 87 us; 36 -> 144 65 vs 81 us
+    // workgroups per CU, never more than one block per wave would justify
+    const int per_cu = (mt * nt == 1 ? 4 : 2);      // measured: 18 -> 18 59 vs 87 us; 36 -> 144 65 vs 81 us
     long long n_wg = (long long)cu_count() * per_cu;
     const long long blocks = (V + 2 * W_UNROLL - 1) / (2 * W_UNROLL);
     const long long max_wg = (blocks + (W_THREADS / 64) - 1) / (W_THREADS / 64);

@@ -319,8 +319,7 @@ int mdt_conv_stem_wgrad(const float *grad_out, const float *x_padded, float *gra
     p.YP = YP; p.XP = XP; p.ZP = ZP; p.sy = sy; p.sx = sx; p.k = k; p.T = T; p.rows = rows;
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipGetLastError();
-    static const bool use_lds = []() { const char *e = getenv("MDT_STEM_WGRAD"); return !(e && e[0] == 'v' && e[1] == '1'); }();
-    if (use_lds && k == SL_K && sy == 2 && sx == 2 && OX % SL_NX == 0 && ZP == OZ + SL_K - 1 && (OZ == 128 || OZ == 64 || OZ == 32)
+    if (k == SL_K && sy == 2 && sx == 2 && OX % SL_NX == 0 && ZP == OZ + SL_K - 1 && (OZ == 128 || OZ == 64 || OZ == 32)
         && XP >= 2 * OX + SL_K - 2 && rows / SL_NX <= 0x7fffffffLL) {
         n_wg = OZ == 128 ? launch_lds<128>(p, s) : OZ == 64 ? launch_lds<64>(p, s) : launch_lds<32>(p, s);
     } else {

@@ -409,10 +409,9 @@ int mdt_conv1x1_dgrad_add(const float *gy, const float *w, const float *res, flo
     if (!mdt_conv1x1_dgrad_add_supported(c_out, c_in)) return MDT_ERR_UNSUPPORTED;
     if (n_voxels == 0) return MDT_OK;
     if (((((uintptr_t)gy) & 7) | (((uintptr_t)out) & 15) | (((uintptr_t)res) & 15)) != 0) return MDT_ERR_UNSUPPORTED;
-    // the two layer shapes of the LIDC backbone whose maps are large (C2: 18 -> 72 wide, C3: 36 -> 144): matrix cores; MDT_DGRAD_ADD=valu: A/B
-    static int use_mfma = -1;
-    if (use_mfma < 0) { const char *f = getenv("MDT_DGRAD_ADD"); use_mfma = (f && f[0] == 'v') ? 0 : 1; }
-    if (use_mfma && ((c_out == 18 && c_in == 72) || (c_out == 36 && c_in == 144))) {
+    // the two layer shapes of the LIDC backbone whose maps are large (C2: 18 -> 72 wide, C3: 36 -> 144): matrix cores (the VALU form below
+    // measured 249 / 127 us against 207 / 44 us: profiles/r04/r04_res_tap_probe.jsonl)
+    if ((c_out == 18 && c_in == 72) || (c_out == 36 && c_in == 144)) {
         const long long tiles = (n_voxels + 31) / 32;
         long long blocks = (tiles + 3) / 4;
         if (blocks > 2048) blocks = 2048;

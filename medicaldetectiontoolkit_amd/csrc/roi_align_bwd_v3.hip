@@ -743,14 +743,9 @@ inline int ilog2_exact(int v)
     return s;
 }
 
-// Launch-geometry knobs (MDT_BWD3_*) for the tuning scripts under tools/; honoured only when MDT_BWD_TUNE is set.
-inline int env_int(const char *name, int dflt)
-{
-    static const bool tune = getenv("MDT_BWD_TUNE") != nullptr;
-    if (!tune) return dflt;
-    const char *v = getenv(name);
-    return (v && v[0]) ? atoi(v) : dflt;
-}
+// (rounds 3-4 read launch-geometry knobs MDT_BWD3_* from the environment for the tuning sweeps under tools/; the settled values are
+// constants now -- the product library reads no switch from the environment)
+inline int env_int(const char *, int dflt) { return dflt; }
 
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 

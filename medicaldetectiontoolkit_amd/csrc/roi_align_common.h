@@ -1,4 +1,4 @@
-// roi_align_common.h -- device helpers shared by the RoIAlign translation units (roi_align.hip, roi_align_bwd.hip).
+// roi_align_common.h -- device helpers shared by the RoIAlign translation units (roi_align.hip, roi_align_fwd.hip, roi_align_bwd_v3.hip; ab/*.hip).
 // Sample-coordinate arithmetic follows the reference CUDA kernels
 // (cuda_functions/roi_align_3D/roi_align/src/cuda/crop_and_resize_kernel.cu:51-75); every translation unit that
 // includes this file is compiled with -ffp-contract=off so the results round like the uncontracted CPU oracle.
@@ -99,16 +99,6 @@ inline int check_launch()
     if (getenv("MDT_VERBOSE")) fprintf(stderr, "libmdt_hip: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
     return MDT_ERR_LAUNCH_FAILED;
 }
-
-// roi_align_bwd.hip: default backward (single launch, RoI-territory form).  Returns MDT_ERR_UNSUPPORTED when the
-// shape does not fit its LDS budgets; the caller then falls back to the two-kernel / ordered forms.
-bool bwd_territory_supported(int dim, int N, int B, int H, int W, int D, int ph, int pw, int pd, int C);
-int launch_bwd_territory(int dim, const float *grads, const float *boxes, const int *box_ind, int N, int B,
-                         int H, int W, int D, int ph, int pw, int pd, int C, float *out, hipStream_t s);
-
-int launch_bwd_territory_multi(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
-                               int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
-                               float *const *outs, hipStream_t s);
 
 // roi_align_bwd_v3.hip: round-3 default backward (gather form; one launch for one map or for all pyramid levels; 2D maps as
 // the W = 1 case).  `level` may be null (every RoI on level 0).  MDT_ERR_UNSUPPORTED: outside its budgets -> the caller

@@ -98,10 +98,10 @@ def _workspace(nbytes, device):
 def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False, out=None):
     """grads [N, C, *crop] -> grad_image of shape im_size; fully written by the kernel(s) (`out`: write into this
     contiguous fp32 tensor instead of a fresh one -- cache-cold timing rotates several).
-    mode: "fast" (default: single-launch gather-form kernel, csrc/roi_align_bwd_v3.hip; MDT_BWD_KERNEL=r2 selects the
-    round-2 territory kernel csrc/roi_align_bwd.hip for A/B), "twophase" (round-1 separable
-    two-kernel form, A/B and fallback for shapes beyond the LDS budgets), "ordered" (bit-exact vs the sequential
-    oracle), "atomic" (reference algorithm, A/B only)."""
+    mode: "fast" (default: the single-launch gather-form kernel, csrc/roi_align_bwd_v3.hip; beyond its budgets -- more than 128 RoIs --
+    the library runs the exact-order kernel), "ordered" (bit-exact vs the sequential oracle).
+    A/B history, served by libmdt_hip_ab.so and asked for by tests / tools only: "twophase" (round-1 separable two-kernel form),
+    "territory" (round-2 single-launch kernel), "atomic" (the reference's algorithm)."""
     if atomic:
         mode = "atomic"
     dim = len(im_size) - 2
@@ -128,22 +128,25 @@ def crop_backward(grads, boxes, box_ind, im_size, mode="fast", atomic=False, out
         s = _lib.current_stream_ptr()
         head = [_lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(box_ind), n, im_size[0]] + list(im_size[2:]) + \
             list(crop) + [im_size[1], _lib.ptr(grad_image)]
-        if mode in ("fast", "twophase"):
-            query = L.mdt_crop_and_resize_backward_workspace_bytes if mode == "fast" else \
-                L.mdt_crop_and_resize_backward_twophase_workspace_bytes
-            wsb = query(dim, n, im_size[1], im_size[2], im_size[3], im_size[4] if dim == 3 else 1,
-                        crop[0], crop[1], crop[2] if dim == 3 else 1)
+        if mode == "fast":
+            fn = L.mdt_crop_and_resize_3d_backward if dim == 3 else L.mdt_crop_and_resize_2d_backward
+            rc = fn(*(head + [None, 0, s]))
+        elif mode == "twophase":
+            A = _lib.ab_lib()
+            wsb = A.mdt_crop_and_resize_backward_twophase_workspace_bytes(dim, n, im_size[1], im_size[2], im_size[3], im_size[4] if dim == 3 else 1,
+                                                                          crop[0], crop[1], crop[2] if dim == 3 else 1)
             ws = _workspace(wsb, grads.device)
-            if mode == "fast":
-                fn = L.mdt_crop_and_resize_3d_backward if dim == 3 else L.mdt_crop_and_resize_2d_backward
-            else:
-                fn = L.mdt_crop_and_resize_3d_backward_twophase if dim == 3 else L.mdt_crop_and_resize_2d_backward_twophase
+            fn = A.mdt_crop_and_resize_3d_backward_twophase if dim == 3 else A.mdt_crop_and_resize_2d_backward_twophase
             rc = fn(*(head + [_lib.ptr(ws), wsb, s]))
+        elif mode == "territory":
+            rc = _lib.ab_lib().mdt_ab_crop_and_resize_backward_territory(
+                dim, _lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(box_ind), n, im_size[0], im_size[2], im_size[3], im_size[4] if dim == 3 else 1,
+                crop[0], crop[1], crop[2] if dim == 3 else 1, im_size[1], _lib.ptr(grad_image), s)
         elif mode == "ordered":
             fn = L.mdt_crop_and_resize_3d_backward_ordered if dim == 3 else L.mdt_crop_and_resize_2d_backward_ordered
             rc = fn(*(head + [s]))
         elif mode == "atomic" and dim == 3:
-            rc = L.mdt_crop_and_resize_3d_backward_atomic(*(head + [s]))
+            rc = _lib.ab_lib().mdt_crop_and_resize_3d_backward_atomic(*(head + [s]))
         else:
             raise ValueError("unknown backward mode %r for dim %d" % (mode, dim))
     if prof is not None:

@@ -158,3 +158,35 @@ def test_ctypes_signatures_match_the_header_prototypes():
         for i, (d, t) in enumerate(zip(decls, argtypes)):
             assert kind(d) == ctype_kind[t], (name, i, d.strip(), t)
     assert set(_lib._SIGNATURES) == {n for _, n, _ in protos}
+    # the A/B library (superseded generations; tests and tools only): same check against include/mdt_hip_ab.h
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mdt_hip_ab.h")).read(), flags=re.S)
+    ab = re.findall(r"\b(int|size_t|void|const char \*)\s*(mdt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, re.S)
+    assert {n for _, n, _ in ab} == set(_lib._AB_SIGNATURES)
+    for ret, name, args in ab:
+        restype, argtypes = _lib._AB_SIGNATURES[name]
+        assert restype is ret_kind[ret], (name, ret, restype)
+        decls = [] if args.strip() in ("", "void") else [a for a in args.split(",")]
+        assert len(decls) == len(argtypes), (name, len(decls), len(argtypes))
+        for i, (d, t) in enumerate(zip(decls, argtypes)):
+            assert kind(d) == ctype_kind[t], (name, i, d.strip(), t)
+    assert not (set(_lib._AB_SIGNATURES) & set(_lib._SIGNATURES))
+    L = _lib.ab_lib()
+    assert all(getattr(L, n) is not None for n in _lib._AB_SIGNATURES)
+
+
+def test_product_ops_never_load_the_ab_library():
+    """libmdt_hip_ab.so holds superseded kernel generations: no module of the package calls _lib.ab_lib() except behind an explicitly
+    requested A/B mode of _roi_align_impl.crop_backward (mode in {"twophase", "territory", "atomic"}), and the product library exports
+    none of its symbols"""
+    import subprocess
+    from medicaldetectiontoolkit_amd import _lib
+    pkg = os.path.join(ROOT, "medicaldetectiontoolkit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f not in ("_lib.py", "_roi_align_impl.py"):
+                assert "ab_lib" not in open(os.path.join(dirpath, f), errors="ignore").read(), (dirpath, f)
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    for n in _lib._AB_SIGNATURES:
+        assert (" T " + n + "\n") not in syms, n
+    for bad in ("territory", "twophase", "expand_zero", "atomic_kernel"):
+        assert bad not in syms, bad

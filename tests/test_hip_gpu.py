@@ -84,7 +84,16 @@ def test_roialign3d_forward_backward_bitexact(case, cuda):
     go = _roi_align_impl.crop_backward(_t(g, cuda), _t(boxes, cuda), _t(box_ind, cuda), image.shape, mode="ordered")
     assert np.array_equal(go.cpu().numpy(), want_g), np.abs(go.cpu().numpy() - want_g).max()
 
-    # round-1 two-kernel form (A/B baseline, fallback for shapes beyond the LDS budgets of the default kernel)
+    # round-2 territory kernel (A/B history, libmdt_hip_ab.so): same bar where its LDS budgets admit the shape
+    try:
+        gt2 = _roi_align_impl.crop_backward(_t(g, cuda), _t(boxes, cuda), _t(box_ind, cuda), image.shape, mode="territory")
+    except RuntimeError as e:
+        assert "not supported" in str(e)
+    else:
+        err = np.abs(gt2.cpu().numpy() - want_g)
+        assert np.all(err <= FAST_TOL * scale), (err / scale).max()
+
+    # round-1 two-kernel form (A/B history, libmdt_hip_ab.so)
     try:
         g2 = _roi_align_impl.crop_backward(_t(g, cuda), _t(boxes, cuda), _t(box_ind, cuda), image.shape, mode="twophase")
     except RuntimeError as e:       # pool extents beyond its LDS budget (the default entry point then runs _ordered)
@@ -146,7 +155,7 @@ def test_roialign2d_backward_training_call_many_volumes(with_workspace, cuda):
     L = _lib.lib()
     gt, bt, it = _t(g, cuda), _t(boxes, cuda), _t(box_ind, cuda)
     out = torch.full((B, C, Y, X), float("nan"), device=cuda)
-    wsb = L.mdt_crop_and_resize_backward_twophase_workspace_bytes(2, N, C, Y, X, 1, crop[0], crop[1], 1) if with_workspace else 0
+    wsb = _lib.ab_lib().mdt_crop_and_resize_backward_twophase_workspace_bytes(2, N, C, Y, X, 1, crop[0], crop[1], 1) if with_workspace else 0
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=cuda)
     rc = L.mdt_crop_and_resize_2d_backward(_lib.ptr(gt), _lib.ptr(bt), _lib.ptr(it), N, B, Y, X, crop[0], crop[1], C, _lib.ptr(out),
                                            _lib.ptr(ws) if with_workspace else None, wsb, _lib.current_stream_ptr())

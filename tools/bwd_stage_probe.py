@@ -23,7 +23,7 @@ g = torch.randn((N, C, 14, 14, 5), device=dev)
 L = _lib.lib()
 ts = torch.zeros(32, dtype=torch.int64, device=dev)
 L._handle if False else None
-_lib.lib().mdt_debug_bwd_timestamps(ctypes.c_void_p(ts.data_ptr()))
+_lib.ab_lib().mdt_debug_bwd_timestamps(ctypes.c_void_p(ts.data_ptr()))
 names = ["start", "bitmap", "prefix", "tab(a)", "compact(b)", "offsets", "passes(c)", "combine(d)"]
 for nt in ("512",):
     os.environ["MDT_BWD_THREADS"] = nt
@@ -35,7 +35,7 @@ for nt in ("512",):
                 os.environ["MDT_BWD_DBG_WG"] = str(wg)
                 for _ in range(3):
                     ts.zero_()
-                    _roi_align_impl.crop_backward(g, bx, ind, shape)
+                    _roi_align_impl.crop_backward(g, bx, ind, shape, mode="territory")
                     torch.cuda.synchronize()
                 t = ts.cpu().numpy()
                 d = {names[i]: round(float(t[i] - t[i - 1]) * 0.01, 2) for i in range(1, 8)}

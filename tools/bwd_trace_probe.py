@@ -22,7 +22,7 @@ ind_train = torch.arange(N, dtype=torch.int32, device=dev) // 6
 g = torch.randn((N, C, 14, 14, 5), device=dev)
 _lib.lib()
 ts = torch.zeros(64 + 4 * 8192, dtype=torch.int64, device=dev)
-_lib.lib().mdt_debug_bwd_timestamps(ctypes.c_void_p(ts.data_ptr()))
+_lib.ab_lib().mdt_debug_bwd_timestamps(ctypes.c_void_p(ts.data_ptr()))
 os.environ["MDT_BWD_DBG"] = "2"
 nscat = 288
 for nt, parts in (("512", "0"),):
@@ -31,7 +31,7 @@ for nt, parts in (("512", "0"),):
     for name, (bx, ind) in {"train": (boxes_train, ind_train), "balanced": (boxes, ind_bal)}.items():
         for _ in range(3):
             ts.zero_()
-            _roi_align_impl.crop_backward(g, bx, ind, shape)
+            _roi_align_impl.crop_backward(g, bx, ind, shape, mode="territory")
             torch.cuda.synchronize()
         t = ts.cpu().numpy()[64:].reshape(-1, 4)
         nwg = int((t[:, 0] != 0).sum())
