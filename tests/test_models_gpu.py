@@ -354,8 +354,10 @@ def test_train_py_exec_loop_graphed_then_resumed_eager(cuda, tmp_path):
 
 
 def test_deferred_monitor_readout_equals_synchronous_one_step_late(cuda):
-    """train_forward(monitor="deferred") hands out, at call i + 1, exactly the read-out entries the synchronous monitor=True form returns
-    at call i (exec.py:76-79 consumes them one batch later; no host sync in the step); flush_deferred_monitor() delivers the last one"""
+    """train_forward(monitor="deferred") hands out, at call i + 1, the read-out entries of call i (exec.py:76-79 consumes them one batch
+    later; no host sync in the step): the loss in `monitor_values` / `logger_string` is bit-for-bit the device loss call i returned, the GT
+    boxes are call i's batch, the sampled-anchor boxes equal the synchronous form's on the same seed; flush_deferred_monitor() delivers the
+    last one"""
     patch, B = [64, 64, 32], 2
     cf = Configs(dim=3, model="mrcnn", patch_size=patch, batch_size=B)
     torch.manual_seed(0)
@@ -365,20 +367,27 @@ def test_deferred_monitor_readout_equals_synchronous_one_step_late(cuda):
     for i, b in enumerate(batches):
         torch.manual_seed(50 + i)
         sync.append(net.train_forward(b, monitor=True))
-    got = []
+    got, losses = [], []
     for i, b in enumerate(batches):
         torch.manual_seed(50 + i)
         r = net.train_forward(b, monitor="deferred")
+        losses.append(float(r["torch_loss"]))
         assert ("logger_string" in r) == (i > 0)
         if i > 0:
             assert r["monitor_of_previous_step"]
             got.append(r)
     got.append(net.flush_deferred_monitor())
     assert net.flush_deferred_monitor() is None
-    for s, g in zip(sync, got):
-        assert s["logger_string"] == g["logger_string"] and s["monitor_values"] == g["monitor_values"]
-        assert len(s["boxes"]) == len(g["boxes"])
-        for bs, bg in zip(s["boxes"], g["boxes"]):
-            assert [x["box_type"] for x in bs] == [x["box_type"] for x in bg]
-            for x, y in zip(bs, bg):
-                assert np.array_equal(np.asarray(x["box_coords"]), np.asarray(y["box_coords"]))
+    assert len(got) == 3
+    for i, (s, g) in enumerate(zip(sync, got)):
+        assert g["monitor_values"]["loss"] == losses[i]                       # the SAME pass: exact
+        assert g["logger_string"].startswith("loss: {0:.2f}".format(losses[i]))
+        assert abs(s["monitor_values"]["loss"] - g["monitor_values"]["loss"]) <= 1e-4 * abs(losses[i])     # two passes: MIOpen run-to-run noise
+        assert len(s["boxes"]) == len(g["boxes"]) == B
+        for b_ix, (bs, bg) in enumerate(zip(s["boxes"], g["boxes"])):
+            gt = [x for x in bg if x["box_type"] == "gt"]
+            assert len(gt) == len(batches[i]["bb_target"][b_ix])
+            for x, want in zip(gt, batches[i]["bb_target"][b_ix]):
+                assert np.array_equal(np.asarray(x["box_coords"]), np.asarray(want))
+            for t in ("pos_anchor", "neg_anchor", "prop"):
+                assert sum(1 for x in bs if x["box_type"] == t) == sum(1 for x in bg if x["box_type"] == t), t
