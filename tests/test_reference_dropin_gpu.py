@@ -261,8 +261,11 @@ def test_reference_adam_leaves_the_same_parameters_alone_as_flat_adam_in_a_step_
     for it in range(3):
         assert untouched["ref"][it] == untouched["mine"][it], (it, sorted(untouched["ref"][it] ^ untouched["mine"][it]))
     heads = {n for n, _ in rnet.named_parameters() if n.startswith("mask.") or n.startswith("classifier.linear_bbox") or n.startswith("rpn.conv_bbox")}
-    assert heads and heads <= untouched["ref"][1] and not (heads & untouched["ref"][0]) and not (heads & untouched["ref"][2])
+    # step 1 (positives exist) moves the heads, the empty step 2 leaves them alone (step 3 may or may not find positives again: the weights
+    # have moved -- whatever it does, reference and FlatAdam did the same, asserted above)
+    assert heads and heads <= untouched["ref"][1] and not (heads & untouched["ref"][0])
     rs, ms = ropt.state_dict()["state"], mopt.state_dict()["state"]
-    for k, (n, _) in enumerate(rnet.named_parameters()):
+    names = [n for n, _ in rnet.named_parameters()]
+    for k, n in enumerate(names):
         assert float(ms[k]["step"]) == (float(rs[k]["step"]) if k in rs else 0.0), n
-    assert {float(v["step"]) for v in rs.values()} == {2.0, 3.0}
+    assert max(float(rs[k]["step"]) for k, n in enumerate(names) if n in heads) < 3.0 == max(float(v["step"]) for v in rs.values())
