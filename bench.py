@@ -923,7 +923,7 @@ def main():
                                         "built and nothing is copied to the host; (2) the mask head over the DETECTIONS (mrcnn.py:1046-1048, :946-964) is not run -- "
                                         "no loss term or gradient depends on it, the reference computes it in every training step and only its validation pass reads it.  "
                                         "`exec_equivalent` is the step with both, fed host numpy batches: the figure to quote for SURVEY 8(d) M1 as exec.py runs it.  "
-                                        if args.model == "mrcnn" else "train_forward(monitor=False): the per-batch read-out of exec.py:76-79 is not built.  ") +
+                                        if args.model == "mrcnn" else "train_forward(monitor=False): the per-batch read-out of exec.py:76-79 is not built.  ")
                                      + ("The timed batches are random-GT batches on random-init weights: see `timed_batches` for how full the RoI heads were, "
                                         "`heads_full_step` for the same step with full RoI heads.  " if args.model == "mrcnn" else "") + "RPN losses back-propagated "
                                      + ("through the sampled anchors only (same gradients as the dense graph, which is timed as dense_rpn_graph_step)"

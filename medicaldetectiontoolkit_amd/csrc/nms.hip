@@ -69,18 +69,20 @@ constexpr int MASK_WAVES = 4;
 template <int STRIDE>
 __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(
     const float *__restrict__ dets, int n, float thresh, int rule, int fill_lower, int block_major,
-    u64 *__restrict__ mask)
+    u64 *__restrict__ mask, int row_block0, const int *__restrict__ done, long long mask_stride_bytes)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int col_blocks = (n + 63) / 64;
     const int col_start = blockIdx.x * MASK_WAVES + wave;
-    const int row_start = blockIdx.y;
+    const int row_start = row_block0 + blockIdx.y;          // (lazy form: the launch covers the row blocks [row_block0, row_block0 + gridDim.y))
     if (col_start >= col_blocks) return;
+    if (done != nullptr && done[(mask_stride_bytes >> 2) * blockIdx.z] != 0) return;    // this problem's scan already has its max_keep boxes
     dets += (long long)blockIdx.z * n * STRIDE;
     // block_major (internal workspace): word of row 64*R + l for column block Cb sits at
     // ((R * col_blocks + Cb) * 64 + l): a wave reads/writes 512 contiguous bytes.
-    mask += (long long)blockIdx.z * (block_major ? (long long)col_blocks * col_blocks * 64 : (long long)n * col_blocks);
+    if (mask_stride_bytes > 0) mask = reinterpret_cast<u64 *>(reinterpret_cast<char *>(mask) + (long long)blockIdx.z * mask_stride_bytes);
+    else mask += (long long)blockIdx.z * (block_major ? (long long)col_blocks * col_blocks * 64 : (long long)n * col_blocks);
 
     const int row_idx = row_start * 64 + lane;
     // fill_lower: 0 = leave the blocks below the diagonal untouched, 1 = write them as zero, 2 = compute them like the
@@ -153,9 +155,13 @@ __device__ __forceinline__ ScanRow scan_load(const u64 *__restrict__ mask, int k
     return r;
 }
 
+// Lazy form (kb, ke, state != null): the scan covers the row blocks [kb, ke) only and keeps its state -- `removed` bitmap, number kept, a
+// done flag -- in global memory between launches: the RPN wants the first 75 boxes of 6000 (mrcnn.py:348), which the scan usually has
+// after a few hundred rows, so the mask is built and scanned in growing chunks and the later launches return at once.
+// state (ints): [0] done, [1] nkept, [2..3] pad, then col_blocks u64 of `removed`.
 __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
     const u64 *__restrict__ mask, int n, int max_keep,
-    long long *__restrict__ keep, int keep_stride, int *__restrict__ num_out)
+    long long *__restrict__ keep, int keep_stride, int *__restrict__ num_out, int kb, int ke, int *__restrict__ state, long long ws_stride_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     u64 *remv = reinterpret_cast<u64 *>(smem_raw);
@@ -166,21 +172,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int col_blocks = (n + 63) / 64;
-    mask += (long long)blockIdx.x * col_blocks * col_blocks * 64;
+    if (state != nullptr) {
+        mask = reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(mask) + (long long)blockIdx.x * ws_stride_bytes);
+        state = reinterpret_cast<int *>(reinterpret_cast<char *>(state) + (long long)blockIdx.x * ws_stride_bytes);
+        if (kb > 0 && state[0] != 0) return;           // finished in an earlier chunk
+    } else {
+        mask += (long long)blockIdx.x * col_blocks * col_blocks * 64;
+        kb = 0; ke = col_blocks;
+    }
     keep += (long long)blockIdx.x * keep_stride;
     const int limit = (max_keep > 0) ? min(max_keep, keep_stride) : keep_stride;
-
-    for (int j = tid; j < col_blocks; j += SCAN_THREADS) remv[j] = 0ULL;
-    if (tid == 0) { s_kept = 0ULL; s_nkept = 0; }
-    ScanRow cur = scan_load(mask, 0, col_blocks, wave, lane);
-    __syncthreads();
+    u64 *g_remv = state ? reinterpret_cast<u64 *>(state + 4) : nullptr;
 
     int nkept = 0;
-    for (int k = 0; k < col_blocks; ++k) {
+    if (state != nullptr && kb > 0) {
+        for (int j = tid; j < col_blocks; j += SCAN_THREADS) remv[j] = g_remv[j];
+        nkept = state[1];
+    } else {
+        for (int j = tid; j < col_blocks; j += SCAN_THREADS) remv[j] = 0ULL;
+    }
+    if (tid == 0) { s_kept = 0ULL; s_nkept = nkept; }
+    ScanRow cur = scan_load(mask, kb, col_blocks, wave, lane);
+    __syncthreads();
+
+    bool full = false;
+    for (int k = kb; k < ke; ++k) {
         ScanRow nxt;
         // prefetch the next row block unless it is ALREADY fully removed (bits only ever get set, so it stays dead)
         bool want_next = false;
-        if (k + 1 < col_blocks) {
+        if (k + 1 < ke) {
             const int rows_next = min(n - (k + 1) * 64, 64);
             const u64 valid_next = (rows_next == 64) ? ~0ULL : ((1ULL << rows_next) - 1ULL);
             want_next = (~remv[k + 1] & valid_next) != 0ULL;
@@ -218,7 +238,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
         __syncthreads();
         const u64 kept = s_kept;
         nkept = s_nkept;
-        if (max_keep > 0 && nkept >= max_keep) break;
+        if (max_keep > 0 && nkept >= max_keep) { full = true; break; }
 
         const bool mine = (kept >> lane) & 1ULL;
 #pragma unroll
@@ -243,8 +263,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(
         cur = nxt;
     }
 
+    if (state != nullptr && !full && ke < col_blocks) {      // not finished: hand the state to the next chunk's launch
+        __syncthreads();
+        for (int j = tid; j < col_blocks; j += SCAN_THREADS) g_remv[j] = remv[j];
+        if (tid == 0) { state[0] = 0; state[1] = nkept; }
+        return;
+    }
     const int nout = min(nkept, limit);
-    if (tid == 0) num_out[blockIdx.x] = nout;
+    if (tid == 0) { num_out[blockIdx.x] = nout; if (state != nullptr) state[0] = 1; }
     for (int j = nout + tid; j < keep_stride; j += SCAN_THREADS) keep[j] = -1LL;
 }
 
@@ -258,15 +284,20 @@ inline int check_launch()
 
 template <int STRIDE>
 int launch_mask(const float *dets, int batch, int n, float thresh, int rule, int fill_lower, int block_major,
-                u64 *mask, hipStream_t s)
+                u64 *mask, hipStream_t s, int kb = 0, int ke = -1, const int *done = nullptr, long long stride_bytes = 0)
 {
     const int col_blocks = (n + 63) / 64;
     if (col_blocks > 65535 || batch > 65535) return MDT_ERR_UNSUPPORTED;
-    dim3 grid((col_blocks + MASK_WAVES - 1) / MASK_WAVES, col_blocks, batch);
+    if (ke < 0) ke = col_blocks;
+    dim3 grid((col_blocks + MASK_WAVES - 1) / MASK_WAVES, ke - kb, batch);
     (void)hipGetLastError(); hipLaunchKernelGGL(nms_mask_kernel<STRIDE>, grid, dim3(64 * MASK_WAVES), 0, s,
-                       dets, n, thresh, rule, fill_lower, block_major, mask);
+                       dets, n, thresh, rule, fill_lower, block_major, mask, kb, done, stride_bytes);
     return check_launch();
 }
+
+// lazy form: chunk boundaries in 64-row blocks (8 blocks = 512 rows first, then 4x as many, then the rest)
+constexpr int NMS_LAZY_MIN_BLOCKS = 24;          // below this many row blocks (n <= 1536) the single pass is as fast
+inline size_t nms_state_bytes(int n) { return ((size_t)((n + 63) / 64) * sizeof(u64) + 16 + 255) & ~(size_t)255; }
 
 template <int STRIDE>
 int nms_impl(const float *dets, int batch, int n, float thresh, int rule, int max_keep,
@@ -288,15 +319,32 @@ int nms_impl(const float *dets, int batch, int n, float thresh, int rule, int ma
     const size_t lds = (size_t)col_blocks * sizeof(u64);
     if (lds > 128 * 1024) return MDT_ERR_UNSUPPORTED;  // n <= 1,048,576
     u64 *mask = reinterpret_cast<u64 *>(ws);
-    int rc = launch_mask<STRIDE>(dets, batch, n, thresh, rule, 0, 1, mask, s);
-    if (rc != MDT_OK) return rc;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(nms_scan_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MDT_ERR_LAUNCH_FAILED;
     }
+    if (max_keep > 0 && max_keep * 8 < n && col_blocks >= NMS_LAZY_MIN_BLOCKS) {
+        // the caller wants few boxes of many (RPN: 75 of 6000): mask + scan in growing chunks, later launches return at once when done
+        const long long stride = (long long)mdt_nms_workspace_bytes(n);
+        int *state = reinterpret_cast<int *>(reinterpret_cast<char *>(ws) + (stride - (long long)nms_state_bytes(n)));
+        int kb = 0;
+        for (int chunk = 0; kb < col_blocks; ++chunk) {
+            int ke = (chunk == 0) ? 8 : (chunk == 1 ? 40 : col_blocks);
+            if (ke > col_blocks || col_blocks - ke < 8) ke = col_blocks;
+            const int rc = launch_mask<STRIDE>(dets, batch, n, thresh, rule, 0, 1, mask, s, kb, ke, kb > 0 ? state : nullptr, stride);
+            if (rc != MDT_OK) return rc;
+            (void)hipGetLastError(); hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), lds, s,
+                               mask, n, max_keep, keep, keep_stride, num_out, kb, ke, state, stride);
+            if (check_launch() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
+            kb = ke;
+        }
+        return MDT_OK;
+    }
+    int rc = launch_mask<STRIDE>(dets, batch, n, thresh, rule, 0, 1, mask, s);
+    if (rc != MDT_OK) return rc;
     (void)hipGetLastError(); hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), lds, s,
-                       mask, n, max_keep, keep, keep_stride, num_out);
+                       mask, n, max_keep, keep, keep_stride, num_out, 0, col_blocks, (int *)nullptr, 0LL);
     return check_launch();
 }
 
@@ -307,8 +355,8 @@ extern "C" {
 size_t mdt_nms_workspace_bytes(int n)
 {
     if (n <= 0) return 16;
-    const size_t col_blocks = ((size_t)n + 63) / 64;   // block-major mask: col_blocks^2 blocks of 64 words
-    return (col_blocks * col_blocks * 64 * sizeof(u64) + 255) & ~(size_t)255;
+    const size_t col_blocks = ((size_t)n + 63) / 64;   // block-major mask: col_blocks^2 blocks of 64 words, + the lazy scan's state
+    return ((col_blocks * col_blocks * 64 * sizeof(u64) + 255) & ~(size_t)255) + nms_state_bytes(n);
 }
 
 int mdt_nms_mask_3d(const float *dets_sorted, int n, float thresh, int rule, unsigned long long *mask, void *stream)
