@@ -120,7 +120,7 @@ def cpu_baseline(cf, anchors, seconds_budget=25.0):
 def cpu_baseline_reference(args, timeout_s=420):
     """`cpu_baseline.kind = "reference"`: the REFERENCE's own models/mrcnn.py `train_forward` + backward + torch.optim.Adam step
     (exec.py:39,68-74) on ONE full batch of the benchmarked configuration, on this box's host cores, in a child process
-    (oracle/ref_step_cpu.py: reference files from oracle/_ref/py, the CPU oracle behind the four CUDA-only cuda_functions imports)."""
+    (oracle/ref_step_cpu.py: reference files from oracle/_ref/ref_models.tar.gz, the CPU oracle behind the four CUDA-only cuda_functions imports)."""
     import subprocess
     # torch-CPU's 3D convolutions scale badly past a few dozen threads on these hosts (256 threads: 266 s for the step that takes 32 s on the 8
     # cores of the build container): the baseline is run at --cpu-threads (default 16), `cores` says so

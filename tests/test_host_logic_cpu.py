@@ -357,3 +357,29 @@ def test_rank_core_plan_is_disjoint_and_numa_local():
     assert affinity.plan(5, 8, [0, 1], None, None) == [1]
     rec = affinity.pin_rank(0, 1, [0], set_torch_threads=False)
     assert rec["pinned"] and rec["cores"] >= 1
+
+
+def test_bench_step_form_text_builds_for_both_models():
+    """bench.py's JSON line is assembled after minutes of GPU work: the one large string expression in it must at least evaluate (a stray
+    operator there once took the whole line down on the GPU box)"""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    ast.parse(src)
+    i = src.index('"step_form": (') + len('"step_form": ')
+    depth = 0
+    for j in range(i, len(src)):
+        if src[j] == "(":
+            depth += 1
+        elif src[j] == ")":
+            depth -= 1
+            if depth == 0:
+                break
+
+    class A(object):
+        model, sparse_rpn_loss = "mrcnn", 1
+    for model in ("mrcnn", "retina_unet"):
+        A.model = model
+        text = eval(src[i:j + 1], {"args": A})
+        assert isinstance(text, str) and "exec.py:68-74" in text
+        assert ("exec_equivalent" in text) == (model == "mrcnn")

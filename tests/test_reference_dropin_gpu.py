@@ -1,9 +1,10 @@
 """The reference's OWN model files, UNMODIFIED, on the MI355X with this repo's ops behind their import statements
 ("behind the existing models/{mrcnn,retina_unet}.py call sites"; VERDICT r4 "What's missing" 1).
 
-oracle/_ref/py/ holds verbatim copies of /root/reference/{models/{mrcnn,retina_unet,backbone}.py, utils/{model_utils,exp_utils}.py,
-plotting.py}, made by `make -C oracle _ref_py` (run by __graft_entry__.build() in the build container; git-ignored like the compiled
-reference objects, shipped to the GPU box with the snapshot).  Here
+oracle/_ref/ref_models.tar.gz holds /root/reference/{models/{mrcnn,retina_unet,backbone}.py, utils/{model_utils,exp_utils}.py,
+plotting.py}, packed where they lie by `make -C oracle _ref_py` (run by __graft_entry__.build() in the build container; git-ignored like
+the compiled reference objects, shipped to the GPU box with the snapshot; unpacked into a temporary directory by oracle/ref_models.py --
+no reference source file lives in this repository's tree).  Here
     medicaldetectiontoolkit_amd.install_dropin()
 registers this repo's `cuda_functions` package under the name the reference imports (models/mrcnn.py:24-27,
 models/retina_unet.py:26-27), the reference `net` classes are built with `.cuda()` REAL (every tensor of the step lives on the GPU,
@@ -17,7 +18,7 @@ tests/golden/make_step_golden.py:30-80: integer `/` on index tensors floor-divid
 tensor copies to the host as torch 0.4.1 did (`np.argwhere(cuda_tensor == -1)`, mrcnn.py:915 -- needed only here, where tensors really
 are CUDA tensors); and the default `shem_poolsize` of retina_unet.compute_class_loss is 1 instead of 20 for a deterministic sample (the
 golden was made that way).
-A missing oracle/_ref/py is a FAILURE, not a skip."""
+A missing archive is a FAILURE, not a skip."""
 import importlib.util
 import logging
 import os
@@ -31,7 +32,7 @@ from tests.golden import step_inputs as si
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_PY = os.path.join(ROOT, "oracle", "_ref", "py")
+REF_PY = None          # set by the `ref` fixture: the temporary directory the archive was unpacked into
 GOLD = np.load(os.path.join(ROOT, "tests", "golden", "step_reference.npz"), allow_pickle=False)
 _FILES = ("models/mrcnn.py", "models/retina_unet.py", "models/backbone.py", "utils/model_utils.py", "utils/exp_utils.py", "plotting.py")
 
@@ -83,11 +84,15 @@ class Recorder(object):
 
 @pytest.fixture(scope="module")
 def ref(cuda):
-    """the reference modules, imported from oracle/_ref/py with this repo's cuda_functions behind their imports"""
+    """the reference modules, imported from the unpacked oracle/_ref/ref_models.tar.gz with this repo's cuda_functions behind their imports"""
+    global REF_PY
+    from oracle import ref_models
+    try:
+        REF_PY = ref_models.unpack(prefer_archive=True)       # what ships to the GPU box, also when the checkout itself is present
+    except FileNotFoundError as e:
+        pytest.fail(str(e))
     missing = [f for f in _FILES if not os.path.exists(os.path.join(REF_PY, f))]
-    if missing:
-        pytest.fail("oracle/_ref/py is incomplete (%s): run `python -c 'import __graft_entry__ as g; g.build()'` in the build container "
-                    "(make -C oracle _ref_py); it ships to the GPU box with the snapshot" % ", ".join(missing))
+    assert not missing, missing
     import medicaldetectiontoolkit_amd as m
     from medicaldetectiontoolkit_amd import _lib, miopen_env
     miopen_env.setup()
