@@ -363,6 +363,7 @@ def test_bench_step_form_text_builds_for_both_models():
     """bench.py's JSON line is assembled after minutes of GPU work: the one large string expression in it must at least evaluate (a stray
     operator there once took the whole line down on the GPU box)"""
     import ast
+    import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "bench.py")).read()
     ast.parse(src)
