@@ -605,6 +605,7 @@ def main():
     ap.add_argument("--stride-tap", type=int, default=1, help="1 (default): a stage output is sub-sampled once for the two strided 1x1 layers of the next stage and the three gradients meet in one node (utils/fused_epilogue._StrideTap); 0: three autograd consumers (A/B)")
     ap.add_argument("--sparse-rpn-loss", type=int, default=1, help="1 (default): the RPN losses differentiate through the 48 sampled anchors only (models/mrcnn.rpn_at_anchors; the dense RPN forward carries no graph); 0: through the dense outputs like the reference (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
+    ap.add_argument("--roialign-cl", type=int, default=1, help="1 (default): the RoI heads pool the channels-last pyramid maps as they are (mdt_pyramid_roi_align_forward_cl); 0: one row-major copy of the pyramid per forward (A/B)")
     ap.add_argument("--pool-cl", type=int, default=1, help="1 (default): channels-last max pooling kernel of the stem (csrc/pool.hip); 0: torch (A/B)")
     ap.add_argument("--pin-cores", type=int, default=1, help="N > 1: 1 (default) pins every rank to its own slice of the cores of its GPU's NUMA node (utils/affinity.py); 0: only caps the intra-op threads")
     ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
@@ -673,6 +674,7 @@ def main():
     from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
     from medicaldetectiontoolkit_amd.models import mrcnn, retina_unet
     from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch, to_device
+    _roi_align_impl.ROI_ALIGN_CHANNELS_LAST = bool(args.roialign_cl)
     mrcnn.HEAD_AS_LINEAR = bool(args.head_as_linear)
     mrcnn.MERGE_RPN_HEADS = bool(args.merge_rpn_heads)
     mrcnn.SPARSE_RPN_LOSS = bool(args.sparse_rpn_loss)

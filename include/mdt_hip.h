@@ -125,6 +125,13 @@ int mdt_pyramid_roi_align_forward(int dim, int n_levels, const void *const *imag
                                   const int *D, const float *boxes, const int *batch_ix, const int *level, int num_boxes,
                                   int batch, int depth, int crop_height, int crop_width, int crop_zdepth, float *crops,
                                   void *stream);
+/* The forward on CHANNELS-LAST maps (round 5): images[l] is level l's map stored [batch, H[l], W[l], D[l], depth] (torch channels_last_3d: what the
+ * convolution path produces), fp32 (bf16 = 0) or bf16 (bf16 = 1); depth % 4 == 0; 3D only.  A corner voxel is `depth` contiguous values serving every
+ * channel: 16-byte loads straight from global memory, no row-major copy of the pyramid per forward.  crops [N, depth, ch, cw, cd] in the reference
+ * layout, bit-equal to mdt_pyramid_roi_align_forward on the same maps in row-major storage.  The backward stays in the reference layout. */
+int mdt_pyramid_roi_align_forward_cl(int n_levels, const void *const *images, int bf16, const int *H, const int *W, const int *D,
+                                     const float *boxes, const int *batch_ix, const int *level, int num_boxes, int batch, int depth,
+                                     int ch, int cw, int cd, float *crops, void *stream);
 int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix,
                                    const int *level, int num_boxes, int batch, int depth, const int *H, const int *W,
                                    const int *D, int crop_height, int crop_width, int crop_zdepth,

@@ -28,6 +28,7 @@ _SIGNATURES = {
     "mdt_crop_and_resize_backward_workspace_bytes": (c_size_t, [c_int] * 9),
     "mdt_crop_and_resize_3d_backward": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdt_pyramid_roi_align_forward": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "mdt_pyramid_roi_align_forward_cl": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mdt_pyramid_roi_align_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mdt_debug_bwd3": (None, [c_void_p, c_int, c_int]),
     "mdt_debug_fwd_stamps": (None, [c_void_p]),

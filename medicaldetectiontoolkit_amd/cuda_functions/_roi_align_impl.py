@@ -222,8 +222,27 @@ def _level_dims(shapes, dim):
     return H, W, D
 
 
-def pyramid_forward(maps, boxes, batch_ix, level, crop):
-    """maps: list of [B, C, *spatial_l] (all fp32 or all bf16, contiguous); one launch for all levels"""
+ROI_ALIGN_CHANNELS_LAST = True     # module switch (A/B): channels-last pyramid maps are pooled as they are (mdt_pyramid_roi_align_forward_cl)
+
+
+def channels_last_eligible(maps, dim):
+    """the maps can go to the channels-last forward as they are: 3D, every map dense in channels_last_3d storage (and not also row-major),
+    C % 4 == 0, all fp32 or all bf16"""
+    if not (ROI_ALIGN_CHANNELS_LAST and dim == 3 and len(maps) > 0):
+        return False
+    C = maps[0].size(1)
+    if C % 4 != 0 or C < 4:
+        return False
+    dt = maps[0].dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        return False
+    return all(m.dim() == 5 and m.dtype == dt and m.size(1) == C and m.is_contiguous(memory_format=torch.channels_last_3d) and not m.is_contiguous()
+               for m in maps)
+
+
+def pyramid_forward(maps, boxes, batch_ix, level, crop, channels_last=False):
+    """maps: list of [B, C, *spatial_l] (all fp32 or all bf16; contiguous, or -- channels_last=True -- dense channels_last_3d); one launch for
+    all levels"""
     dim = len(crop)
     L = _lib.lib()
     n, B, C = boxes.size(0), maps[0].size(0), maps[0].size(1)
@@ -231,6 +250,13 @@ def pyramid_forward(maps, boxes, batch_ix, level, crop):
     if n == 0 or C == 0:
         return crops
     H, W, D = _level_dims([m.shape for m in maps], dim)
+    if channels_last:
+        with torch.cuda.device(maps[0].device):
+            rc = L.mdt_pyramid_roi_align_forward_cl(len(maps), _ptr_array(maps), int(maps[0].dtype == torch.bfloat16), H, W, D,
+                                                    _lib.ptr(boxes), _lib.ptr(batch_ix), _lib.ptr(level), n, B, C,
+                                                    crop[0], crop[1], crop[2], _lib.ptr(crops), _lib.current_stream_ptr())
+        _lib.check(rc, "mdt_pyramid_roi_align_forward_cl")
+        return crops
     with torch.cuda.device(maps[0].device):
         rc = L.mdt_pyramid_roi_align_forward(dim, len(maps), _ptr_array(maps), int(maps[0].dtype == torch.bfloat16), H, W, D,
                                              _lib.ptr(boxes), _lib.ptr(batch_ix), _lib.ptr(level), n, B, C,
@@ -291,13 +317,14 @@ class _PyramidRoIAlign(Function):
         # inside Function.forward grad mode is always off, so there is nothing to test here: bf16 maps are always read by
         # the bf16-input kernel (exact widening, fp32 interpolation); backward returns fp32 maps cast to ctx.dtypes
         bf16 = all(m.dtype == torch.bfloat16 for m in maps)
-        maps_c = [m.contiguous() if (m.dtype == torch.float32 or bf16) else m.float().contiguous() for m in maps]
+        cl = channels_last_eligible(maps, dim)          # the conv path's own layout: pooled as it is, no row-major copy of the pyramid
+        maps_c = list(maps) if cl else [m.contiguous() if (m.dtype == torch.float32 or bf16) else m.float().contiguous() for m in maps]
         boxes = boxes.detach().to(device=maps_c[0].device, dtype=torch.float32).contiguous()
         batch_ix = batch_ix.detach().to(device=maps_c[0].device, dtype=torch.int32).contiguous()
         level = level.detach().to(device=maps_c[0].device, dtype=torch.int32).contiguous()
         if boxes.dim() != 2 or boxes.size(1) != 2 * dim:
             raise ValueError("boxes must be [N, %d], got %s" % (2 * dim, tuple(boxes.shape)))
-        crops = pyramid_forward(maps_c, boxes, batch_ix, level, crop)
+        crops = pyramid_forward(maps_c, boxes, batch_ix, level, crop, channels_last=cl)
         ctx.shapes = [tuple(m.shape) for m in maps_c]
         ctx.dtypes = [m.dtype for m in maps]
         ctx.save_for_backward(boxes, batch_ix, level)

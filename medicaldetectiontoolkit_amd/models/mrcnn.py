@@ -730,9 +730,15 @@ class net(nn.Module):
             img = img.contiguous(memory_format=self.memory_format)
         fpn_outs = self.fpn(img)
         rpn_feature_maps = [fpn_outs[i] for i in cf.pyramid_levels]
-        # the RoIAlign kernels read [B, C, spatial] row-major maps: convert a channels-last map ONCE per forward (every head
-        # call would otherwise re-copy all levels, and the heads' gradients would meet in mixed layouts)
-        self.mrcnn_feature_maps = [m.contiguous() for m in rpn_feature_maps]
+        # round 5: channels-last maps (what the convolution path produces) are pooled AS THEY ARE by mdt_pyramid_roi_align_forward_cl -- a
+        # corner voxel is 36 contiguous floats serving every channel; no row-major copy of the pyramid per forward, no copy back in the
+        # backward.  Otherwise the RoIAlign kernels read [B, C, spatial] row-major maps: convert ONCE per forward (every head call would
+        # re-copy all levels)
+        from ..cuda_functions import _roi_align_impl as _rai
+        if _rai.channels_last_eligible(rpn_feature_maps, cf.dim):
+            self.mrcnn_feature_maps = list(rpn_feature_maps)
+        else:
+            self.mrcnn_feature_maps = [m.contiguous() for m in rpn_feature_maps]
         self.rpn_feature_maps = rpn_feature_maps if is_training else None       # read by rpn_at_anchors, released after the RPN losses
         with torch.set_grad_enabled(rpn_graph and torch.is_grad_enabled()):
             layer_outputs = [self.rpn(p) for p in rpn_feature_maps]

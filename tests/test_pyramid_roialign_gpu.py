@@ -9,6 +9,7 @@ import torch
 
 from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl as impl
 from oracle import oracle
+from tests.helpers import random_boxes_3d
 
 pytestmark = pytest.mark.gpu
 
@@ -131,3 +132,39 @@ def test_pyramid_full_size_adjoint_and_single_level_equivalence(cuda):
         single = impl.crop_backward(g, boxes, ind, s)
         mag = impl.crop_backward(g.abs(), boxes, ind, s)
         assert torch.all((grads[l] - single).abs() <= 4e-6 * mag + 1e-30)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("crop", [(7, 7, 3), (14, 14, 5), (1, 1, 1)])
+def test_channels_last_pyramid_forward_equals_row_major_kernel(crop, dtype, cuda):
+    """mdt_pyramid_roi_align_forward_cl on channels_last_3d maps == mdt_pyramid_roi_align_forward on the same maps in row-major storage, bit
+    for bit (fp32 and bf16), incl. rows without a level / batch element; gradients flow to the channels-last maps like to row-major ones"""
+    from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl as rai
+    rng = np.random.default_rng(31)
+    g = torch.Generator(device=cuda).manual_seed(31)
+    B, C = 3, 36
+    shapes = [(B, C, 16, 16, 32), (B, C, 8, 8, 16), (B, C, 4, 4, 8), (B, C, 2, 2, 4)]
+    maps = [torch.randn(s, device=cuda, generator=g).to(dtype) for s in shapes]
+    maps_cl = [m.contiguous(memory_format=torch.channels_last_3d) for m in maps]
+    N = 90
+    boxes = torch.from_numpy(random_boxes_3d(rng, N, spill=True)).to(cuda)
+    bix = torch.from_numpy(rng.integers(-1, B + 1, size=N).astype(np.int32)).to(cuda)        # incl. out-of-range elements
+    lvl = torch.from_numpy(rng.integers(-1, 5, size=N).astype(np.int32)).to(cuda)            # incl. rows without a level
+    assert rai.channels_last_eligible(maps_cl, 3) and not rai.channels_last_eligible(maps, 3)
+    want = rai.pyramid_forward(maps, boxes, bix, lvl, crop)
+    got = rai.pyramid_forward(maps_cl, boxes, bix, lvl, crop, channels_last=True)
+    assert torch.equal(got, want)
+    if dtype == torch.float32:
+        a = [m.clone().requires_grad_(True) for m in maps]
+        b = [m.clone(memory_format=torch.preserve_format).requires_grad_(True) for m in maps_cl]
+        assert all(t.is_contiguous(memory_format=torch.channels_last_3d) and not t.is_contiguous() for t in b)
+        ok_rows = ((bix >= 0) & (bix < B) & (lvl >= 0) & (lvl < 4))
+        bx2, bi2, lv2 = boxes[ok_rows][:48], bix[ok_rows][:48], lvl[ok_rows][:48]
+        ya = rai.pyramid_crop_and_resize(a, bx2, bi2, lv2, crop)
+        yb = rai.pyramid_crop_and_resize(b, bx2, bi2, lv2, crop)
+        assert torch.equal(ya, yb)
+        w = torch.randn(ya.shape, device=cuda, generator=g)
+        (ya * w).sum().backward()
+        (yb * w).sum().backward()
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta.grad, tb.grad)
