@@ -355,10 +355,14 @@ __device__ __forceinline__ v4f ldq(const bf16raw *p, long long i)
     return v4f{__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
 }
 
+constexpr int CL_PASSES = 4;            // passes of ppb positions a workgroup gathers in LDS before it stores them channel by channel
+constexpr int CL_TILE_MAX = 8192;       // floats of the output tile (C x positions per chunk, +1 padding per channel row)
+
 template <typename TIN>
 __global__ __launch_bounds__(CQ_THREADS) void crop_fwd_cl_kernel(ClParams p)
 {
     __shared__ AxisEntry tab[CQ_TAB_MAX];
+    __shared__ float tile[CL_TILE_MAX];
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
     const float *bx = p.boxes + (long long)n * 6;
@@ -384,34 +388,50 @@ __global__ __launch_bounds__(CQ_THREADS) void crop_fwd_cl_kernel(ClParams p)
     }
     __syncthreads();
     const int pl = tid / Q, q = tid - pl * Q;
-    if (pl >= p.ppb) return;
     const float rcp_cd = 1.0f / (float)cd, rcp_cw = 1.0f / (float)cw;
-    const int npass = (P + p.ppb - 1) / p.ppb;
-    for (int ps = blockIdx.y; ps < npass; ps += p.nsplit) {
-        const int pos = ps * p.ppb + pl;
-        if (pos >= P) continue;
-        int z, x;
-        const int t = fast_divmod(pos, cd, rcp_cd, z);
-        const int y = fast_divmod(t, cw, rcp_cw, x);
-        const AxisEntry ey = tab[y], ex = tab[ch + x], ez = tab[ch + cw + z];
-        const int top = ey.lo, bottom = entry_hi(ey), left = ex.lo, right = entry_hi(ex), front = ez.lo, back = entry_hi(ez);
-        const long long rt_l = ((long long)top * W + left) * D, rt_r = ((long long)top * W + right) * D;
-        const long long rb_l = ((long long)bottom * W + left) * D, rb_r = ((long long)bottom * W + right) * D;
-        const int c4 = 4 * q;
-        const v4f tlf = ldq(image, (rt_l + front) * C + c4), trf = ldq(image, (rt_r + front) * C + c4);
-        const v4f blf = ldq(image, (rb_l + front) * C + c4), brf = ldq(image, (rb_r + front) * C + c4);
-        const v4f tlb = ldq(image, (rt_l + back) * C + c4), trb = ldq(image, (rt_r + back) * C + c4);
-        const v4f blb = ldq(image, (rb_l + back) * C + c4), brb = ldq(image, (rb_r + back) * C + c4);
-        const float lx = ex.lerp, ly = ey.lerp, lz = ez.lerp;
-        const v4f top_front = tlf + (trf - tlf) * lx;
-        const v4f bottom_front = blf + (brf - blf) * lx;
-        const v4f top_back = tlb + (trb - tlb) * lx;
-        const v4f bottom_back = blb + (brb - blb) * lx;
-        const v4f frontv = top_front + (bottom_front - top_front) * ly;
-        const v4f backv = top_back + (bottom_back - top_back) * ly;
-        const v4f res = frontv + (backv - frontv) * lz;
-        float *o = out + (long long)c4 * P + pos;
-        o[0] = res.x; o[P] = res.y; o[2LL * P] = res.z; o[3LL * P] = res.w;
+    const int chunk_pos = p.ppb * CL_PASSES;                 // positions per chunk
+    const int trow = chunk_pos + 1;                          // tile row stride (odd: the transposed writes spread over the banks)
+    const int nchunks = (P + chunk_pos - 1) / chunk_pos;
+    for (int ck = blockIdx.y; ck < nchunks; ck += p.nsplit) {
+        const int pos0 = ck * chunk_pos;
+        const int npos = min(chunk_pos, P - pos0);
+        if (pl < p.ppb) {
+#pragma unroll
+            for (int ps = 0; ps < CL_PASSES; ++ps) {
+                const int lp = ps * p.ppb + pl;              // position inside the chunk
+                if (lp >= npos) break;
+                const int pos = pos0 + lp;
+                int z, x;
+                const int t = fast_divmod(pos, cd, rcp_cd, z);
+                const int y = fast_divmod(t, cw, rcp_cw, x);
+                const AxisEntry ey = tab[y], ex = tab[ch + x], ez = tab[ch + cw + z];
+                const int top = ey.lo, bottom = entry_hi(ey), left = ex.lo, right = entry_hi(ex), front = ez.lo, back = entry_hi(ez);
+                const long long rt_l = ((long long)top * W + left) * D, rt_r = ((long long)top * W + right) * D;
+                const long long rb_l = ((long long)bottom * W + left) * D, rb_r = ((long long)bottom * W + right) * D;
+                const int c4 = 4 * q;
+                const v4f tlf = ldq(image, (rt_l + front) * C + c4), trf = ldq(image, (rt_r + front) * C + c4);
+                const v4f blf = ldq(image, (rb_l + front) * C + c4), brf = ldq(image, (rb_r + front) * C + c4);
+                const v4f tlb = ldq(image, (rt_l + back) * C + c4), trb = ldq(image, (rt_r + back) * C + c4);
+                const v4f blb = ldq(image, (rb_l + back) * C + c4), brb = ldq(image, (rb_r + back) * C + c4);
+                const float lx = ex.lerp, ly = ey.lerp, lz = ez.lerp;
+                const v4f top_front = tlf + (trf - tlf) * lx;
+                const v4f bottom_front = blf + (brf - blf) * lx;
+                const v4f top_back = tlb + (trb - tlb) * lx;
+                const v4f bottom_back = blb + (brb - blb) * lx;
+                const v4f frontv = top_front + (bottom_front - top_front) * ly;
+                const v4f backv = top_back + (bottom_back - top_back) * ly;
+                const v4f res = frontv + (backv - frontv) * lz;
+                float *tq = tile + c4 * trow + lp;
+                tq[0] = res.x; tq[trow] = res.y; tq[2 * trow] = res.z; tq[3 * trow] = res.w;
+            }
+        }
+        __syncthreads();
+        // the chunk leaves channel by channel: runs of `npos` consecutive positions of out[n][c][pos0 ..]
+        for (int e = tid; e < C * npos; e += CQ_THREADS) {
+            const int c = e / npos, lp = e - c * npos;
+            out[(long long)c * P + pos0 + lp] = tile[c * trow + lp];
+        }
+        __syncthreads();
     }
 }
 
@@ -462,9 +482,10 @@ int launch_fwd_cl(const PyramidMaps &maps, const float *boxes, const int *box_in
     p.maps = maps; p.boxes = boxes; p.box_ind = box_ind; p.level = level; p.crops = crops;
     p.B = B; p.ch = ch; p.cw = cw; p.cd = cd; p.C = C; p.Q = C / 4;
     p.ppb = CQ_THREADS / p.Q;
+    if ((long long)C * (p.ppb * CL_PASSES + 1) > CL_TILE_MAX) return MDT_ERR_UNSUPPORTED;
     const int P = ch * cw * cd;
-    const int npass = (P + p.ppb - 1) / p.ppb;
-    int nsplit = (1024 + N - 1) / N;             // ~4 workgroups per CU in flight
+    const int npass = (P + p.ppb * CL_PASSES - 1) / (p.ppb * CL_PASSES);
+    int nsplit = (4096 + N - 1) / N;             // one chunk per workgroup while the grid stays below ~16 workgroups per CU
     if (nsplit > npass) nsplit = npass;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 65535) nsplit = 65535;

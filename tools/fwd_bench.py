@@ -63,6 +63,14 @@ for tag, img, boxes, ind, crop in cases:
         esz = 4 if dt == "f32" else 2
         tv = touched_voxels(boxes, tuple(img.shape[2:]), crop)
         byts = 4.0 * out.numel() + esz * C * tv + 28 * len(boxes)
+        # the same RoIs on the SAME map in channels-last storage (what the conv path produces): mdt_pyramid_roi_align_forward_cl, one level
+        im_cl = im.contiguous(memory_format=torch.channels_last_3d)
+        lvl0 = torch.zeros(len(boxes), dtype=torch.int32, device=dev)
+        out_cl = _roi_align_impl.pyramid_forward([im_cl], bx, bi, lvl0, crop, channels_last=True)
+        mean_cl, med_cl = time_op(lambda: _roi_align_impl.pyramid_forward([im_cl], bx, bi, lvl0, crop, channels_last=True))
+        print(json.dumps({"case": tag, "map": dt, "kernel": "channels_last", "avg_us": round(mean_cl, 2), "median_us": round(med_cl, 2),
+                          "alg_MB": round(byts / 1e6, 2), "frac_of_8TBps": round(byts / (mean_cl * 1e-6) / 8e12, 4),
+                          "out_only_frac": round(4.0 * out.numel() / (mean_cl * 1e-6) / 8e12, 4), "bit_equal_to_row_major_kernel": bool(torch.equal(out, out_cl))}), flush=True)
         print(json.dumps({"case": tag, "map": dt, "kernel": kern, "avg_us": round(mean, 2), "median_us": round(med, 2), "out_MB": round(4e-6 * out.numel(), 2),
                           "touched_input_MB": round(esz * C * tv / 1e6, 2), "alg_MB": round(byts / 1e6, 2),
                           "GBps": round(byts / mean / 1e3, 1), "frac_of_8TBps": round(byts / (mean * 1e-6) / 8e12, 4),

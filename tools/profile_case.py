@@ -1,5 +1,5 @@
 """One case in a loop, for rocprofv3 --kernel-trace --stats.  Usage: profile_case.py <case> [iters]
-cases: bwd_fast | bwd_twophase | bwd_ordered | fwd | nms6000 | nms6000_keep75 | pmc_bwd
+cases: bwd_fast | bwd_twophase | bwd_ordered | fwd | fwd_cl | nms6000 | nms6000_keep75 | pmc_bwd
        | pyramid_bwd (all four levels in one launch, 48 RoIs routed 24/12/8/4)
 env: MDT_N, MDT_CROP, MDT_ROIS=random|trainlike, MDT_INVALID=1, MDT_LEVEL=P2..P5,
      MDT_ROTATE=k (round 4: bwd_fast / pmc_bwd write k rotating output buffers -- 4 x 151 MB = 604 MB > the 256 MiB Infinity Cache -- instead of
@@ -32,6 +32,8 @@ if os.environ.get("MDT_INVALID"):        # all rows routed to other pyramid leve
     box_ind = torch.full_like(box_ind, -1)
 g = torch.randn((N, 36) + crop, device=dev)
 image = torch.randn(shape, device=dev)
+image_cl = image.contiguous(memory_format=torch.channels_last_3d)      # the same map in the conv path's layout (mdt_pyramid_roi_align_forward_cl)
+lvl0 = torch.zeros(N, dtype=torch.int32, device=dev)
 dets = nms_boxes(rng, 6000)
 ds = torch.from_numpy(dets[np.argsort(-dets[:, -1].astype(np.float64), kind="stable")]).to(dev)
 n_rot = int(os.environ.get("MDT_ROTATE", "0"))
@@ -51,6 +53,7 @@ fns = {
     "bwd_twophase": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="twophase"),
     "bwd_ordered": lambda: _roi_align_impl.crop_backward(g, boxes, box_ind, shape, mode="ordered"),
     "fwd": lambda: _roi_align_impl.crop_forward(image, boxes, box_ind, crop),
+    "fwd_cl": lambda: _roi_align_impl.pyramid_forward([image_cl], boxes, box_ind, lvl0, crop, channels_last=True),
     "nms6000": lambda: _nms_impl.nms_sorted(ds, 0.7, 3),
     "nms6000_keep75": lambda: _nms_impl.nms_sorted(ds, 0.7, 3, max_keep=75),
 }
