@@ -201,3 +201,15 @@ def test_oracle_anchor_matching_no_gt_and_subsampling():
     gt = np.array([[1, 1, 11, 11]], dtype=np.float64)
     m, d = host_numpy.anchor_matching(anchors, gt, None, 0.5, 2, [0.1, 0.1, 0.2, 0.2], rng=rng)
     assert (m > 0).sum() == 1 and m[3] == -1            # 3 anchors above 0.5, all but rpn_train_anchors // 2 reset to neutral
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """SURVEY.md section 5 (sanitizers): oracle/sanitize_main.c drives every entry point of mdt_oracle.c on seeded random and edge-case inputs
+    (spilling / inverted / degenerate boxes, out-of-range box_ind, P == 1, n around the 64-row block edges, n = 0) with exact-size heap
+    buffers, compiled with -fsanitize=address,undefined -fno-sanitize-recover=all: any out-of-bounds access or undefined operation fails"""
+    import subprocess
+    odir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run(["make", "-C", odir, "sanitize"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([os.path.join(odir, "build", "oracle_sanitize")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "clean" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-2000:])
