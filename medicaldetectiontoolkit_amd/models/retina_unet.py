@@ -186,6 +186,21 @@ class net(nn.Module):
         detections, det_valid = refine_detections(self.anchors, flat_class_softmax, flat_bb_outputs, B, self.cf)
         return detections, det_valid, class_logits, bb_outputs, seg_logits
 
+    # ------------------------------------------------------------------ which parameters have a gradient only under a condition of the step
+    def grad_condition_spec(self):
+        """[(condition, [parameters])] for training.FlatAdam.attach_conditions: the reference's compute_class_loss returns constants for a step
+        without sampled anchors (retina_unet.py:139-165) and compute_bbox_loss without a positive anchor (:180-186), so autograd hands the
+        Classifier / BBRegressor heads no gradient there and torch.optim.Adam (exec.py:74) leaves them alone.  The Retina U-Net's FPN and
+        final_conv always learn from the segmentation loss; the Retina Net's FPN only from the anchors."""
+        spec = [("anchor_samples", list(self.Classifier.parameters())), ("positive_anchors", list(self.BBRegressor.parameters()))]
+        if self.cf.model != "retina_unet":
+            spec.append(("anchor_samples_fpn", list(self.Fpn.parameters())))
+        return spec
+
+    def set_grad_cond_buffer(self, t):
+        """float32 device tensor (or None) that train_forward fills with the counts of grad_condition_spec()"""
+        self._grad_cond = t
+
     def train_forward(self, batch, monitor=True, **kwargs):
         """retina_unet.py:381-457."""
         cf, dev = self.cf, self.device_
@@ -210,6 +225,11 @@ class net(nn.Module):
             shem_poolsize=getattr(cf, "retina_shem_poolsize", 20),      # the reference calls compute_class_loss with its default 20 (retina_unet.py:432)
             gt_dev=gt_dev)
         loss = batch_class_loss + batch_bbox_loss
+        gc = getattr(self, "_grad_cond", None)
+        if gc is not None:          # who had something to learn from in this step (FlatAdam skips the others like torch.optim.Adam does)
+            n_pos, n_neg = samples[1].sum(), samples[3].sum()
+            vals = [n_pos + n_neg, n_pos] + ([n_pos + n_neg] if cf.model != "retina_unet" else [])
+            gc.copy_(torch.stack(vals))
         seg_dice = seg_ce = None
         if seg_logits is not None:
             var_seg = mutils.upload(batch["seg"], dev, channel="seg").long()

@@ -335,3 +335,72 @@ def test_flat_adam_rehomes_a_repointed_parameter_and_adopts_mixed_steps():
     for k in r2:
         assert float(s2[k]["step"]) == float(r2[k]["step"]), k
     assert float(s2[keys[0]]["step"]) == 9.0
+
+
+class _CondNet(nn.Module):
+    """a model with a head whose gradient exists only when the step had a 'positive' (training.FlatAdam.attach_conditions)"""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = nn.Linear(4, 3)
+        self.head = nn.Linear(3, 2)
+        self._grad_cond = None
+
+    def grad_condition_spec(self):
+        return [("positives", list(self.head.parameters()))]
+
+    def set_grad_cond_buffer(self, t):
+        self._grad_cond = t
+
+    def step_loss(self, x, n_pos):
+        h = self.trunk(x)
+        # the masked fixed-size form of this repo: the head's loss term is multiplied by 0 when the step has no positive (an exact zero gradient),
+        # where the reference would return a constant and autograd would produce NO gradient for the head
+        loss = h.pow(2).mean() + self.head(h).pow(2).mean() * (1.0 if n_pos > 0 else 0.0)
+        if self._grad_cond is not None:
+            self._grad_cond.copy_(torch.tensor([float(n_pos)]))
+        return loss
+
+
+def _cond_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = _CondNet()
+    sync = training.FlatGradAllReduce(net, n_buckets=2)
+    opt = _TorchMathFlatAdam(net.parameters(), lr=1e-2, grad_sync=sync).attach_conditions(net)
+    torch.manual_seed(100 + rank)
+    head_moved, steps = [], None
+    # step 0: positives on both ranks; step 1: on rank 0 only (the all-reduced count is > 0: every rank updates the head);
+    # step 2: on no rank (every rank skips the head: no moment decay, no step count)
+    for it, pos in enumerate(([3, 2], [1, 0], [0, 0])):
+        x = torch.randn(5, 4)
+        before = net.head.weight.detach().clone()
+        loss = net.step_loss(x, pos[rank])
+        opt.zero_grad()
+        loss.backward()
+        sync.finish()
+        opt.step()
+        head_moved.append(not torch.equal(before, net.head.weight.detach()))
+    st = opt.state_dict()["state"]
+    params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    both = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(both, params)
+    if rank == 0:
+        torch.save({"head_moved": head_moved, "steps": [float(st[k]["step"]) for k in sorted(st)], "ranks_equal": bool(torch.equal(both[0], both[1])),
+                    "extra": int(sync.n_extra), "last_bucket_end": int(sync.bucket_range[-1][1]), "numel": int(sync.numel)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_adam_conditions_are_all_reduced_with_the_gradients_world2(tmp_path):
+    """the step's "this head had a positive sample" counts ride behind the gradients in the last bucket's all-reduce: a head is updated iff ANY
+    rank had a positive, skipped (torch.optim.Adam's skip: no decay, no step count) iff none had -- and the ranks stay bit-identical"""
+    out = str(tmp_path / "cond_r0.pt")
+    mp.spawn(_cond_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    assert got["head_moved"] == [True, True, False]
+    assert got["ranks_equal"]
+    assert got["extra"] == 1 and got["last_bucket_end"] == got["numel"] + 1
+    assert got["steps"] == [3.0, 3.0, 2.0, 2.0]          # trunk weight / bias: 3 steps, head weight / bias: 2

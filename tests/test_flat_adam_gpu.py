@@ -209,6 +209,70 @@ def test_mrcnn_four_steps_one_without_positives_equal_torch_adam_bit_for_bit(cud
             assert float(sa[k]["step"]) == 0.0, n           # torch keeps no state for a parameter that never had a gradient
 
 
+@pytest.mark.parametrize("model", ["retina_unet", "retina_net"])
+def test_retina_steps_one_without_positive_anchors_equal_torch_adam_bit_for_bit(model, cuda):
+    """the same for the Retina U-Net / Retina Net: a batch without GT objects has no positive anchor, so the reference's compute_bbox_loss
+    returns a constant (retina_unet.py:180-186) and torch.optim.Adam leaves the BBRegressor head alone, while the Classifier still learns
+    from the sampled negatives.  FlatAdam with the device-side conditions == torch.optim.Adam fed the same gradients with None where the
+    reference's autograd has none: weights, moments, step counters bit-equal."""
+    from tests.golden import step_inputs as si
+    from medicaldetectiontoolkit_amd.models import retina_unet
+    import numpy as np
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step_reference.npz"), allow_pickle=False)
+    nb = si.CASES["small"][1]
+    full = si.make_batch(si.make_image(), [gold["gt_boxes_%d" % b] for b in range(nb)], [gold["gt_labels_%d" % b] for b in range(nb)])
+    empty = si.make_batch(si.make_image(seed=32), [np.zeros((0, 6), np.float32)] * nb, [np.zeros((0,), np.int64)] * nb)
+    cf = si.make_cf(model)
+    net_a = retina_unet.net(cf, device=cuda)
+    net_b = copy.deepcopy(net_a)
+    oa = training.build_optimizer(net_a, cf, flat=True)
+    assert oa._cond is not None and oa._cond[2] == (2 if model == "retina_unet" else 3)
+    ob = torch.optim.Adam(net_b.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay)
+    cond_of = {}
+    for i, (_, plist) in enumerate(net_a.grad_condition_spec()):
+        for p in plist:
+            cond_of[id(p)] = i
+    names = [n for n, _ in net_a.named_parameters()]
+    n_updates, skipped = {}, None
+    for it, batch in enumerate((full, empty, full)):
+        torch.manual_seed(10 + it)
+        res = net_a.train_forward(batch, monitor=False)
+        oa.zero_grad()
+        res["torch_loss"].backward()
+        cond = net_a._grad_cond.detach().cpu().tolist()
+        assert cond[0] > 0                      # negatives are always sampled
+        assert (cond[1] > 0) == (it != 1) or it == 2
+        absent = []
+        for (n, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+            have = pa.grad is not None and (id(pa) not in cond_of or cond[cond_of[id(pa)]] > 0)
+            pb.grad = pa.grad.clone() if have else None
+            if not have:
+                absent.append(n)
+        if it == 1:
+            skipped = set(absent)
+        for n in names:
+            if n not in absent:
+                n_updates[n] = n_updates.get(n, 0) + 1
+        before = [p.detach().clone() for p in net_a.parameters()]
+        oa.step()
+        ob.step()
+        for (n, pa), pb, p0 in zip(net_a.named_parameters(), net_b.parameters(), before):
+            assert torch.equal(pa, pb), (it, n, float((pa - pb).abs().max()))
+            if n in absent:
+                assert torch.equal(pa, p0), (it, n)
+    head = {n for n in names if n.startswith("BBRegressor.")}
+    assert head and head <= skipped
+    assert not any(n.startswith("Classifier.") for n in skipped)
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    for k, n in enumerate(names):
+        if k in sb:
+            assert float(sa[k]["step"]) == float(sb[k]["step"]) == float(n_updates[n]), n
+            assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"]), n
+        else:
+            assert float(sa[k]["step"]) == 0.0, n
+
+
 def test_flat_adam_with_grad_sync_refuses_dropped_gradient_views(cuda):
     """with a FlatGradAllReduce the gradients live in ITS flat buffer: a dropped view is an error, never a silent freeze"""
     net = _toy(cuda)
