@@ -431,6 +431,23 @@ size_t mdt_conv_stem_wgrad_workspace_bytes(int c_out, int k);
 int mdt_conv_stem_wgrad(const float *grad_out, const float *x_padded, float *grad_weight, int batch, int OY, int OX, int OZ,
                         int c_out, int k, int sy, int sx, int YP, int XP, int ZP, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- stride-(2, 2, 1) convolutions with MANY input channels (csrc/conv_s221.hip) -----------------------------------------------
+ * The Retina U-Net's C1 = conv(18 -> 18, ks 7, stride (2, 2, 1), pad 3) on the full-resolution C0 output (models/backbone.py:84), which
+ * the reference gets from cuDNN through nn.Conv3d.  Channels-last fp32 storage everywhere; k odd, pad = k / 2, Y and X even.
+ *
+ * mdt_s2d221_input: x [B, Y, X, Z, C] -> xs [B, (Y + 2p) / 2, (X + 2p) / 2, Z + 2p, 4C], the 2 x 2 (y, x) phases of the zero-padded input
+ *   as channels (c, py, px): the layer becomes a 4C -> c_out, ((k+1)/2, (k+1)/2, k), unit-stride convolution.
+ * mdt_s2d221_fold_input_grad: the gradient w.r.t. xs -> the gradient w.r.t. x (the inverse gather, padding rows dropped).
+ * mdt_conv_s221_wgrad: grad_weight[co][ky][kx][kz][ci] = sum_{b, oy, ox, z} grad_out[b, oy, ox, z][co] * x[b, 2 oy + ky - p, 2 ox + kx - p,
+ *   z + kz - p][ci]  (= aten.convolution_backward(..., output_mask = [0, 1, 0]) in channels_last_3d storage).  fp32 MFMA, deterministic;
+ *   supported (`..._supported` answers 1) when k * c_in <= 128, c_out <= 32, Z % 16 == 0; otherwise MDT_ERR_UNSUPPORTED. */
+int mdt_s2d221_input(const float *x, float *xs, int batch, int channels, int Y, int X, int Z, int k, void *stream);
+int mdt_s2d221_fold_input_grad(const float *grad_xs, float *grad_x, int batch, int channels, int Y, int X, int Z, int k, void *stream);
+int mdt_conv_s221_wgrad_supported(int batch, int Y, int X, int Z, int c_in, int c_out, int k);
+size_t mdt_conv_s221_wgrad_workspace_bytes(int batch, int Y, int X, int Z, int c_in, int c_out, int k);
+int mdt_conv_s221_wgrad(const float *grad_out, const float *x, float *grad_weight, int batch, int Y, int X, int Z, int c_in, int c_out, int k,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- forward of the one-channel stem convolution (csrc/conv_stem_fwd.hip) -----------------------------------------------------
  * out[b, oy, ox, oz][co] = (bias[co] +) sum_{ky, kx, kz} weight[co][ky, kx, kz] * x_padded[b, 2 oy + ky, 2 ox + kx, oz + kz]
  * (optionally ReLU): C1 = conv(1 -> 18, ks 7, stride (2, 2, 1), pad 3) of models/backbone.py:66-68, which the reference gets from

@@ -39,6 +39,11 @@ _SIGNATURES = {
     "mdt_conv3x3x3_small_forward_bias_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p]),
     "mdt_conv_stem_wgrad_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mdt_conv_stem_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_size_t, c_void_p]),
+    "mdt_s2d221_input": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mdt_s2d221_fold_input_grad": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "mdt_conv_s221_wgrad_supported": (c_int, [c_int] * 7),
+    "mdt_conv_s221_wgrad_workspace_bytes": (c_size_t, [c_int] * 7),
+    "mdt_conv_s221_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "mdt_conv1x1_dgrad_add_supported": (c_int, [c_int, c_int]),
     "mdt_conv1x1_dgrad_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mdt_adam_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong] + [c_double] * 5 + [c_longlong, c_double, c_void_p]),

@@ -401,6 +401,135 @@ def stem_forward(x, w, bias=None, relu=False):
     return out, xp
 
 
+# ---- space-to-depth form of a stride-(2, 2, 1) convolution (any channel count) --------------------------------------------------------------
+S2D_GENERAL = True      # module switch (A/B: bench.py --conv-s2d 0): stride-(2, 2, 1) layers with many input channels in space-to-depth form
+
+
+def _cl_rows(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.is_contiguous(memory_format=torch.channels_last_3d) and _on_current_device(x)
+
+
+def s2d_input(x, k):
+    """[B, C, Y, X, Z] -> the 2 x 2 (y, x) phases of the input padded by k // 2 as channels: [B, 4C, (Y + 2p) / 2, (X + 2p) / 2, Z + 2p]
+    in channels-last storage, channel = (c, py, px).  On the GPU one pass of csrc/conv_s221.hip (torch: a padded copy + a permuted copy)."""
+    p = k // 2
+    B, C = int(x.shape[0]), int(x.shape[1])
+    if _cl_rows(x) and int(x.shape[2]) % 2 == 0 and int(x.shape[3]) % 2 == 0:
+        Y, X, Z = (int(v) for v in x.shape[2:])
+        xs = torch.empty((B, (Y + 2 * p) // 2, (X + 2 * p) // 2, Z + 2 * p, 4 * C), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().mdt_s2d221_input(x.data_ptr(), xs.data_ptr(), B, C, Y, X, Z, k, _lib.raw_stream())
+        if rc == 0:
+            return xs.permute(0, 4, 1, 2, 3)
+        if rc != _lib.MDT_ERR_UNSUPPORTED:
+            _lib.check(rc, "mdt_s2d221_input")
+    xp = F.pad(x, (p, p, p, p, p, p))
+    Y, X, Z = (int(v) for v in xp.shape[2:])
+    return xp.view(B, C, Y // 2, 2, X // 2, 2, Z).permute(0, 2, 4, 6, 1, 3, 5).reshape(B, Y // 2, X // 2, Z, 4 * C).permute(0, 4, 1, 2, 3)
+
+
+def s2d_filter(w):
+    """[O, C, k, k, k] -> [O, 4C, (k+1)/2, (k+1)/2, k] (the taps outside the k x k window are zero), channels-last"""
+    O, C, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+    h = (k + 1) // 2
+    ws = F.pad(w, (0, 0, 0, 1, 0, 1)).view(O, C, h, 2, h, 2, k).permute(0, 1, 3, 5, 2, 4, 6).reshape(O, 4 * C, h, h, k)
+    return ws.contiguous(memory_format=torch.channels_last_3d)
+
+
+def s2d_input_grad_conv(gy, ws):
+    """gradient w.r.t. the space-to-depth input, as a FORWARD convolution of the zero-padded output gradient with the flipped filter"""
+    h, k = int(ws.shape[2]), int(ws.shape[4])
+    wf = ws.flip(2, 3, 4).transpose(0, 1).contiguous(memory_format=torch.channels_last_3d)
+    return F.conv3d(F.pad(gy, (k - 1, k - 1, h - 1, h - 1, h - 1, h - 1)), wf, None, 1, 0)
+
+
+def s2d_input_grad_fold(gxs, x_shape, k):
+    """[B, 4C, Y'/2, X'/2, Z'] (gradient of s2d_input's output) -> gradient of x, channels-last, in one pass (csrc/conv_s221.hip on the GPU;
+    torch's strided copy takes 4.5 ms for the 2.6 GB of the Retina U-Net's C1 layer, the kernel moves them at HBM speed)"""
+    p = k // 2
+    B, C, Y, X, Z = (int(v) for v in x_shape)
+    Y2, X2, Zp = (int(v) for v in gxs.shape[2:])
+    if _cl_rows(gxs) and Y % 2 == 0 and X % 2 == 0 and (Y2, X2, Zp) == ((Y + 2 * p) // 2, (X + 2 * p) // 2, Z + 2 * p):
+        gx = torch.empty((B, Y, X, Z, C), dtype=torch.float32, device=gxs.device)
+        rc = _lib.lib().mdt_s2d221_fold_input_grad(gxs.data_ptr(), gx.data_ptr(), B, C, Y, X, Z, k, _lib.raw_stream())
+        if rc == 0:
+            return gx.permute(0, 4, 1, 2, 3)
+        if rc != _lib.MDT_ERR_UNSUPPORTED:
+            _lib.check(rc, "mdt_s2d221_fold_input_grad")
+    g = gxs.view(B, C, 2, 2, Y2, X2, Zp).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, C, 2 * Y2, 2 * X2, Zp)
+    return g[:, :, p:p + Y, p:p + X, p:p + Z].contiguous(memory_format=torch.channels_last_3d)
+
+
+def s2d_filter_grad_fold(gws, w_shape):
+    """gradient of s2d_filter's output -> gradient of w"""
+    O, C, k = int(w_shape[0]), int(w_shape[1]), int(w_shape[2])
+    h = (k + 1) // 2
+    g = gws.reshape(O, C, 2, 2, h, h, k).permute(0, 1, 4, 2, 5, 3, 6).reshape(O, C, 2 * h, 2 * h, k)
+    return g[:, :, :k, :k, :].contiguous(memory_format=torch.channels_last_3d)
+
+
+S221_WGRAD = True      # module switch: weight gradient of those layers on the fp32-MFMA kernel of csrc/conv_s221.hip
+
+
+def s221_weight_grad(gy, x, w):
+    """Weight gradient of a k x k x k, stride (2, 2, 1), pad k // 2 convolution with k * C_in <= 128 and C_out <= 32 (the Retina U-Net's C1:
+    18 -> 18, k = 7) on the fp32-MFMA kernel of csrc/conv_s221.hip (MIOpen: 45.9 ms on 8 x 128^3).  None when the layer is not of that form."""
+    if not (S221_WGRAD and _cl_rows(x) and gy.is_cuda and gy.dtype == torch.float32 and w.dim() == 5):
+        return None
+    k = int(w.shape[2])
+    if tuple(int(v) for v in w.shape[2:]) != (k, k, k):
+        return None
+    B, Ci, Y, X, Z = (int(v) for v in x.shape)
+    Co = int(w.shape[0])
+    L = _lib.lib()
+    if int(w.shape[1]) != Ci or tuple(int(v) for v in gy.shape) != (B, Co, Y // 2, X // 2, Z) or not L.mdt_conv_s221_wgrad_supported(B, Y, X, Z, Ci, Co, k):
+        return None
+    if not gy.is_contiguous(memory_format=torch.channels_last_3d):
+        gy = gy.contiguous(memory_format=torch.channels_last_3d)
+    ws = _workspace(L.mdt_conv_s221_wgrad_workspace_bytes(B, Y, X, Z, Ci, Co, k), gy.device)
+    gw = torch.empty((Co, k, k, k, Ci), dtype=torch.float32, device=gy.device)
+    rc = L.mdt_conv_s221_wgrad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, Y, X, Z, Ci, Co, k, ws.data_ptr(), ws.numel(), _lib.raw_stream())
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        _lib.check(rc, "mdt_conv_s221_wgrad")
+    return gw.permute(0, 4, 1, 2, 3)
+
+
+class _ConvS2D221(Function):
+    """k x k x k, stride (2, 2, 1), pad k // 2 convolution with MANY input channels (backbone.py:84: the Retina U-Net's C1 = 18 -> 18, k = 7
+    on the full-resolution C0 output; 40 % of the config-2 step on MIOpen's direct problem: 39.6 ms forward, 58.1 ms input gradient, 45.9 ms
+    weight gradient at 8 x 128^3).  Posed in space-to-depth form (4 C_in channels, ((k+1)/2, (k+1)/2, k) filter, unit stride) the forward takes
+    33.2 ms and the input gradient becomes a FORWARD convolution of the padded output gradient with the flipped filter: 26.2 ms
+    (tools/c1_probe.py).  The weight gradient runs on this repo's fp32-MFMA kernel (`s221_weight_grad`), else on MIOpen's direct problem."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.conv3d(s2d_input(x, int(w.shape[2])), s2d_filter(w), None, 1, 0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        k = int(w.shape[2])
+        p = k // 2
+        if not gy.is_contiguous(memory_format=torch.channels_last_3d):
+            gy = gy.contiguous(memory_format=torch.channels_last_3d)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = s2d_input_grad_fold(s2d_input_grad_conv(gy, s2d_filter(w)), x.shape, k)
+        if ctx.needs_input_grad[1]:
+            gw = s221_weight_grad(gy, x, w)
+            if gw is None:
+                gw = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2, 1], [p, p, p], [1, 1, 1], False, [0, 0, 0], 1, [False, True, False])[1]
+        return gx, gw
+
+
+def _is_s221_general(conv, x):
+    k = conv.kernel_size
+    return x.dim() == 5 and tuple(conv.stride) == (2, 2, 1) and k[0] == k[1] == k[2] and k[0] % 2 == 1 and k[0] >= 3 \
+        and tuple(conv.padding) == (k[0] // 2,) * 3 and 4 < conv.in_channels <= 64 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+
+
 class _ConvStem221(Function):
     """The stem: few input channels, odd k x k x k filter, stride (2, 2, 1), pad k // 2 (backbone.py:66-68: 1 -> 18, 7x7x7).
     Forward in space-to-depth form: the 2 x 2 (y, x) phases of the padded input become 4x the input channels and the filter
@@ -501,6 +630,9 @@ def _conv(conv, x):
     if STEM_SPACE_TO_DEPTH and x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and _unit(conv.dilation) \
             and not isinstance(conv.padding, str) and _is_stem221(conv, x):
         return _ConvStem221.apply(x, conv.weight)
+    if S2D_GENERAL and x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and _unit(conv.dilation) and not isinstance(conv.padding, str) \
+            and _is_s221_general(conv, x) and not torch.is_autocast_enabled():
+        return _ConvS2D221.apply(x if x.is_contiguous(memory_format=torch.channels_last_3d) else x.contiguous(memory_format=torch.channels_last_3d), conv.weight)
     fn = F.conv3d if isinstance(conv, nn.Conv3d) else F.conv2d
     return fn(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 

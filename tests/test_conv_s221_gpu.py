@@ -1,0 +1,83 @@
+"""GPU: the stride-(2, 2, 1) many-channel convolution of the Retina U-Net's C1 layer (backbone.py:84) in space-to-depth form
+(utils/fused_epilogue._ConvS2D221, csrc/conv_s221.hip) against torch's direct convolution and its autograd."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last_3d
+
+
+def _rand(shape, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return torch.randn(shape, device=dev, generator=g)
+
+
+@pytest.mark.parametrize("B,C,Y,X,Z,k", [(2, 18, 8, 12, 16, 7), (1, 5, 6, 4, 10, 3), (1, 7, 4, 4, 3, 5)])
+def test_space_to_depth_kernels_equal_the_torch_permutes_bitwise(B, C, Y, X, Z, k, cuda):
+    x = _rand((B, C, Y, X, Z), cuda, 1).contiguous(memory_format=CL)
+    xs = fe.s2d_input(x, k)                                     # kernel (channels-last fp32 on the GPU)
+    xs_ref = fe.s2d_input(x.cpu(), k)                           # torch pad + permute
+    assert xs.shape == xs_ref.shape and xs.is_contiguous(memory_format=CL)
+    assert torch.equal(xs.cpu(), xs_ref)
+    g = _rand(tuple(xs.shape), cuda, 2).contiguous(memory_format=CL)
+    gx = fe.s2d_input_grad_fold(g, x.shape, k)
+    gx_ref = fe.s2d_input_grad_fold(g.cpu(), x.shape, k)
+    assert gx.shape == x.shape and gx.is_contiguous(memory_format=CL)
+    assert torch.equal(gx.cpu(), gx_ref)
+    # and the fold is the adjoint of the gather: <s2d(x), g> == <x, fold(g)>
+    assert float((xs.double() * g.double()).sum()) == pytest.approx(float((x.double() * gx.double()).sum()), rel=1e-9, abs=1e-9)
+
+
+@pytest.mark.parametrize("B,Ci,Co,Y,X,Z,k", [(2, 18, 18, 16, 16, 32, 7), (1, 18, 18, 8, 70, 16, 7), (1, 5, 3, 8, 8, 16, 3), (2, 9, 32, 4, 6, 48, 5),
+                                            (1, 4, 7, 6, 6, 16, 7)])
+def test_weight_gradient_kernel_equals_aten(B, Ci, Co, Y, X, Z, k, cuda):
+    """fp32 MFMA against MIOpen's backward-weights of the direct problem; the float64 CPU gradient arbitrates"""
+    x = _rand((B, Ci, Y, X, Z), cuda, 3).contiguous(memory_format=CL)
+    w = _rand((Co, Ci, k, k, k), cuda, 4)
+    gy = _rand((B, Co, Y // 2, X // 2, Z), cuda, 5).contiguous(memory_format=CL)
+    gw = fe.s221_weight_grad(gy, x, w)
+    assert gw is not None and gw.shape == w.shape
+    xd, wd = x.double().cpu(), w.double().cpu().requires_grad_(True)
+    ref, = torch.autograd.grad(F.conv3d(xd, wd, None, (2, 2, 1), k // 2), wd, gy.double().cpu())
+    err = float((gw.double().cpu() - ref).abs().max())
+    assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, (err, float(ref.abs().max()))
+    again = fe.s221_weight_grad(gy, x, w)
+    assert torch.equal(gw, again)                       # deterministic: fixed split, fixed-order partial sums
+
+
+def test_weight_gradient_kernel_declines_what_it_does_not_cover(cuda):
+    x = _rand((1, 18, 8, 8, 16), cuda, 6).contiguous(memory_format=CL)
+    assert fe.s221_weight_grad(_rand((1, 40, 4, 4, 16), cuda, 7).contiguous(memory_format=CL), x, _rand((40, 18, 7, 7, 7), cuda, 8)) is None      # c_out > 32
+    x = _rand((1, 20, 8, 8, 16), cuda, 6).contiguous(memory_format=CL)
+    assert fe.s221_weight_grad(_rand((1, 8, 4, 4, 16), cuda, 7).contiguous(memory_format=CL), x, _rand((8, 20, 7, 7, 7), cuda, 8)) is None        # k * c_in > 128
+    x = _rand((1, 18, 8, 8, 24), cuda, 6).contiguous(memory_format=CL)
+    assert fe.s221_weight_grad(_rand((1, 8, 4, 4, 24), cuda, 7).contiguous(memory_format=CL), x, _rand((8, 18, 7, 7, 7), cuda, 8)) is None        # Z % 16
+
+
+@pytest.mark.parametrize("Z", [32, 24])
+def test_c1_layer_dispatch_forward_and_gradients_equal_the_direct_convolution(Z, cuda):
+    """nn.Conv3d(18, 18, 7, stride (2, 2, 1), pad 3) through fused_epilogue._conv: space-to-depth forward, input gradient as a forward
+    convolution + fold, weight gradient on the MFMA kernel (Z = 32) or on MIOpen's direct problem (Z = 24) == torch's direct layer"""
+    torch.manual_seed(0)
+    conv = nn.Conv3d(18, 18, 7, stride=(2, 2, 1), padding=3).to(cuda)
+    x = _rand((2, 18, 16, 20, Z), cuda, 9).contiguous(memory_format=CL).requires_grad_(True)
+    assert fe._is_s221_general(conv, x)
+    y = fe._conv(conv, x)
+    assert y.grad_fn is not None and "ConvS2D221" in type(y.grad_fn).__name__
+    ref = F.conv3d(x, conv.weight, None, (2, 2, 1), 3)
+    assert torch.allclose(y, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    gy = _rand(tuple(ref.shape), cuda, 10)
+    gx, gw = torch.autograd.grad(y, (x, conv.weight), gy)
+    rx, rw = torch.autograd.grad(ref, (x, conv.weight), gy)
+    assert torch.allclose(gx, rx, rtol=1e-4, atol=1e-4 * float(rx.abs().max()))
+    assert torch.allclose(gw, rw, rtol=1e-4, atol=1e-4 * float(rw.abs().max()))
+    old = fe.S2D_GENERAL
+    fe.S2D_GENERAL = False
+    try:
+        assert "ConvS2D221" not in type(fe._conv(conv, x).grad_fn).__name__
+    finally:
+        fe.S2D_GENERAL = old
