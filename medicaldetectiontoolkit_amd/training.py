@@ -3,6 +3,8 @@ plus patch-level data parallelism -- one process per GPU, gradients averaged wit
 all-reduce over RCCL (the whole model is 4.94 M fp32 parameters = 19.75 MB)."""
 import os
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -102,7 +104,11 @@ class FlatAdam(torch.optim.Adam):
             if len(gs.params) != len(params) or any(a is not b for a, b in zip(gs.params, params)):
                 raise ValueError("FlatAdam: grad_sync was built over a different parameter list")
             fgrad = gs.flat if gs.n_extra == 0 else gs.flat[:n]
+            owner = getattr(gs, "_div_owner", None)
+            if owner is not None and owner() is not None and owner() is not self:
+                raise ValueError("FlatAdam: this grad_sync already feeds another FlatAdam (its deferred division by the world size belongs to ONE optimizer)")
             gs.defer_div = True         # this optimizer divides by the world size inside its launch
+            gs._div_owner = weakref.ref(self)
             cond_t = gs.extra[:n_cond] if n_cond else None
             if cond_t is not None and cond_t.data_ptr() != self._cond_buf.data_ptr():
                 cond_t.copy_(self._cond_buf)                 # what the step has already written (the first forward precedes this build)
@@ -367,6 +373,13 @@ class FlatGradAllReduce(object):
         elif w > 1:
             self.flat.div_(w)
 
+    @property
+    def grad_scale(self):
+        """what the gradients in the flat buffer (and every p.grad view) must be multiplied by to be the MEAN over ranks: 1 except between
+        finish() and the step() of the FlatAdam built over this sync (deferred division: the buffer holds the SUM).  Gradient-norm logging or
+        clipping between the two must use it."""
+        return 1.0 / self.pending_div
+
     def finish_all(self):
         """after a captured backward (GraphedTrainStep: hooks suspended): all buckets in order, wait, average"""
         if not self._active():
@@ -401,6 +414,11 @@ def train_step(net, optimizer, batch, grad_sync=None, monitor=False):
         raise ValueError("train_step: this FlatAdam was built %s, the step was called %s: the optimizer would read a gradient buffer the "
                          "collective never touches" % ("without a grad_sync" if optimizer._grad_sync is None else "over another grad_sync",
                                                        "with one" if grad_sync is not None else "without"))
+    if grad_sync is not None and grad_sync.defer_div and not isinstance(optimizer, FlatAdam):
+        # after a FlatAdam was built over this sync, finish() leaves the SUM over ranks in the buffer (grad_scale says by what
+        # to multiply): any other optimizer would step on gradients world_size times too large
+        raise ValueError("train_step: this grad_sync defers the division by the world size to the FlatAdam built over it; "
+                         "%s would see the SUM over ranks (grad_sync.grad_scale = 1 / world)" % type(optimizer).__name__)
     results = net.train_forward(batch, monitor=monitor)
     if isinstance(optimizer, FlatAdam):
         optimizer.zero_grad()            # one fill (and the bucket bookkeeping of its grad_sync, if any)

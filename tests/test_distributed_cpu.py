@@ -121,13 +121,24 @@ def _adam_worker(rank, world, port, out):
     sync = training.FlatGradAllReduce(net, n_buckets=2)
     opt = _TorchMathFlatAdam(net.parameters(), lr=1e-2, grad_sync=sync)
     torch.manual_seed(100 + rank)
+    scales = []
     for it in range(3):
         x = torch.randn(5, 4)
         loss = net(x, use_second=True)          # forward BEFORE zero_grad, as training.train_step does (the first zero_grad re-homes p.data)
         opt.zero_grad()
         loss.backward()
         sync.finish()
+        scales.append(sync.grad_scale)           # the buffer holds the SUM over the two ranks until the optimizer's step divides it
         opt.step()
+        scales.append(sync.grad_scale)
+    guards = []
+    for make in (lambda: training.train_step(net, torch.optim.Adam(net.parameters(), lr=1e-2), None, grad_sync=sync),
+                 lambda: _TorchMathFlatAdam(net.parameters(), lr=1e-2, grad_sync=sync).step()):
+        try:
+            make()
+            guards.append(None)
+        except ValueError as e:
+            guards.append(str(e))
     fparam, fgrad, fm, fv = opt._flat
     ok_views = all(p.data.untyped_storage().data_ptr() == fparam.untyped_storage().data_ptr() and
                    p.grad.untyped_storage().data_ptr() == sync.flat.untyped_storage().data_ptr() for p in net.parameters())
@@ -136,7 +147,7 @@ def _adam_worker(rank, world, port, out):
     dist.all_gather(both, params)
     if rank == 0:
         torch.save({"params": {n: p.detach().clone() for n, p in net.named_parameters()}, "ok_views": ok_views, "fgrad_is_sync": fgrad is sync.flat,
-                    "ranks_equal": bool(torch.equal(both[0], both[1])), "state": opt.state_dict()}, out)
+                    "ranks_equal": bool(torch.equal(both[0], both[1])), "state": opt.state_dict(), "scales": scales, "guards": guards}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -148,6 +159,11 @@ def test_flat_adam_over_flat_grad_allreduce_world2(tmp_path):
     mp.spawn(_adam_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out, weights_only=False)
     assert got["ok_views"] and got["fgrad_is_sync"] and got["ranks_equal"]
+    # ADVICE r4 (deferred division): between finish() and step() the gradients are SUMS and grad_scale says so; a second optimizer over the
+    # same sync -- a plain torch.optim.Adam through train_step, or another FlatAdam -- is refused instead of stepping on 2x gradients
+    assert got["scales"] == [0.5, 1.0] * 3
+    assert got["guards"][0] is not None and "defers the division" in got["guards"][0]
+    assert got["guards"][1] is not None and "already feeds another FlatAdam" in got["guards"][1]
     torch.manual_seed(0)
     ref = Tiny()
     opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
