@@ -12,6 +12,8 @@ Also here, because they hang off the same modules (each with a module switch for
     (`conv1x1_weight_grad`, csrc/conv1x1_wgrad.hip), few-channel 3x3x3 layers forward / input gradient / weight gradient
     (`conv3x3x3_small*`, csrc/conv3x3x3_small.hip), the one-channel 7x7x7 stem forward with bias + ReLU epilogue and its weight
     gradient (`stem_forward`, `_ConvStemBiasReLU`, `stem_weight_grad`; csrc/conv_stem_fwd.hip, csrc/conv_stem_wgrad.hip)."""
+import sys
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -815,10 +817,36 @@ class _StrideTap(Function):
         if g_s is None:
             return g_lat, None
         # g_lat is the lateral convolution's input gradient: a fresh dense tensor this node is the only consumer of (the alias has ONE
-        # user by construction, backbone.FPN._stage) -- dense and non-overlapping is checked, anything else is copied first
-        g = g_lat if (g_lat.is_contiguous(memory_format=ctx.mf) or g_lat.is_contiguous()) and g_lat._base is None else g_lat.clone(memory_format=ctx.mf)
+        # user by construction, backbone.FPN._stage).  Autograd does not promise that: a tensor hook on the alias that KEEPS the gradient
+        # it is shown, or a producer that hands one tensor to two inputs, shares it -- the in-place add would corrupt the other holder's
+        # copy.  So the add runs in place only when ownership is provable: dense, not a view, and no more Python references
+        # than the engine itself holds when it calls this function (calibrated once per process by `_tap_owned_refs`); otherwise on a clone.
+        refs = sys.getrefcount(g_lat)
+        if _TAP_REFS[0] == -1:           # calibration call
+            _TAP_REFS[0] = refs
+        owned = refs <= _tap_owned_refs() and g_lat._base is None and (g_lat.is_contiguous(memory_format=ctx.mf) or g_lat.is_contiguous())
+        g = g_lat if owned else g_lat.clone(memory_format=ctx.mf)
+        _TAP_REFS[1 if owned else 2] += 1
         g[sl].add_(g_s)
         return g, None
+
+
+_TAP_REFS = [None, 0, 0]     # [references the engine holds on a gradient it passes to _StrideTap.backward, in-place adds, cloned adds]
+
+
+def _tap_owned_refs():
+    """sys.getrefcount of a gradient nobody else holds, at the line of _StrideTap.backward that asks: measured, not assumed (it depends on the
+    interpreter and on how torch's engine wraps gradients for Python functions) -- one tiny CPU backward the first time it is needed"""
+    if _TAP_REFS[0] is None:
+        _TAP_REFS[0] = -1
+        with torch.enable_grad():
+            x = torch.zeros((1, 1, 2, 2, 2), requires_grad=True)
+            lat, xs = _StrideTap.apply(x * 1.0, (2, 2, 2))
+            (F.conv3d(lat, torch.ones((1, 1, 1, 1, 1))).sum() + xs.sum()).backward()
+        if _TAP_REFS[0] == -1:          # the calibration backward did not come by (never expected): nothing is provably owned
+            _TAP_REFS[0] = 0
+        _TAP_REFS[1] = _TAP_REFS[2] = 0
+    return _TAP_REFS[0] if _TAP_REFS[0] != -1 else (1 << 30)
 
 
 def stride_tap_applies(block, x):
@@ -840,6 +868,7 @@ def stride_tap_applies(block, x):
 
 def stride_tap(x, stride):
     """(alias of x for the lateral, x sub-sampled by `stride`)"""
+    _tap_owned_refs()          # calibrated here, in forward context, not inside the first backward
     return _StrideTap.apply(x, tuple(int(s) for s in stride))
 
 

@@ -384,3 +384,61 @@ def test_bench_step_form_text_builds_for_both_models():
         text = eval(src[i:j + 1], {"args": A})
         assert isinstance(text, str) and "exec.py:68-74" in text
         assert ("exec_equivalent" in text) == (model == "mrcnn")
+
+
+def _stride_tap_case(mode):
+    """x -> _StrideTap -> (lateral 1x1 convolution, strided consumer); returns x.grad, what a hook on the lateral alias kept, the reference
+    gradients, and how the node's in-place / cloned counters moved"""
+    import torch
+    import torch.nn.functional as F
+    from medicaldetectiontoolkit_amd.utils import fused_epilogue as fe
+
+    class PyConv1x1(torch.autograd.Function):          # a Python producer of the lateral's gradient, like fused_epilogue._ConvStride1
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return F.conv3d(x, w)
+
+        @staticmethod
+        def backward(ctx, gy):
+            x, w = ctx.saved_tensors
+            gx = torch.einsum("bodhw,oc->bcdhw", gy, w[:, :, 0, 0, 0]).contiguous(memory_format=torch.channels_last_3d)
+            return gx, torch.einsum("bodhw,bcdhw->oc", gy, x)[:, :, None, None, None]
+
+    torch.manual_seed(0)
+    x = torch.randn(1, 4, 8, 8, 8).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    w1, w2 = torch.randn(3, 4, 1, 1, 1), torch.randn(5, 4, 1, 1, 1)
+    fe._tap_owned_refs()
+    before = list(fe._TAP_REFS)
+    kept = []
+    lat, xs = fe.stride_tap(x * 1.0, (2, 2, 2))
+    if mode == "hook_keeps_gradient":
+        lat.register_hook(lambda g: kept.append(g))
+    if mode == "retain_grad":
+        lat.retain_grad()
+    a = PyConv1x1.apply(lat, w1) if mode == "python_producer" else F.conv3d(lat, w1)
+    (a.sum() + F.conv3d(xs, w2).sum() * 3).backward()
+    xr = x.detach().clone().requires_grad_(True)
+    lat_only, = torch.autograd.grad(F.conv3d(xr, w1).sum(), xr)
+    xr2 = x.detach().clone().requires_grad_(True)
+    full, = torch.autograd.grad(F.conv3d(xr2, w1).sum() + F.conv3d(xr2[:, :, ::2, ::2, ::2], w2).sum() * 3, xr2)
+    seen = kept[0] if kept else (lat.grad if mode == "retain_grad" else None)
+    return x.grad, seen, lat_only, full, (fe._TAP_REFS[1] - before[1], fe._TAP_REFS[2] - before[2])
+
+
+def test_stride_tap_adds_in_place_only_into_a_gradient_nobody_else_holds():
+    """_StrideTap.backward adds the strided consumers' gradient INTO the lateral's incoming gradient.  In the model's graph that
+    tensor is fresh and this node is its only holder: the add runs in place (one strided pass over 1/8 of the rows).  A tensor hook that
+    keeps the gradient it is shown shares the tensor: then the add must run on a clone, and what the hook kept stays the lateral's own
+    gradient."""
+    import torch
+    for mode in ("plain", "python_producer", "retain_grad"):
+        gx, seen, lat_only, full, (inplace, cloned) = _stride_tap_case(mode)
+        assert torch.allclose(gx, full, rtol=1e-5, atol=1e-5), mode
+        assert (inplace, cloned) == (1, 0), (mode, inplace, cloned)
+        if seen is not None:
+            assert torch.allclose(seen, lat_only, rtol=1e-5, atol=1e-5), mode            # retain_grad clones for itself: untouched
+    gx, seen, lat_only, full, (inplace, cloned) = _stride_tap_case("hook_keeps_gradient")
+    assert (inplace, cloned) == (0, 1)
+    assert torch.allclose(gx, full, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(seen, lat_only, rtol=1e-5, atol=1e-5)                          # NOT the sum: the kept tensor was not written to
