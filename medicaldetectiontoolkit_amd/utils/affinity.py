@@ -78,11 +78,16 @@ def pin_rank(local_rank, local_world, device_indices=None, set_torch_threads=Tru
         return {"pinned": False, "why": "no sched_getaffinity on this platform"}
     if device_indices is None:
         device_indices = list(range(local_world))
-    numa = [gpu_numa_node(d) for d in device_indices]
-    cpus = plan(local_rank, local_world, allowed, numa, node_cpulists())
-    if not cpus:
-        return {"pinned": False, "why": "no allowed cores"}
-    os.sched_setaffinity(0, cpus)
+    # placement is an optimisation: whatever goes wrong here (sysfs without the expected files, a cgroup that refuses the mask) must leave
+    # the rank running unpinned, never take a multi-GPU job down
+    try:
+        numa = [gpu_numa_node(d) for d in device_indices]
+        cpus = plan(local_rank, local_world, allowed, numa, node_cpulists())
+        if not cpus:
+            return {"pinned": False, "why": "no allowed cores"}
+        os.sched_setaffinity(0, cpus)
+    except Exception as e:       # noqa: BLE001
+        return {"pinned": False, "why": "%s: %s" % (type(e).__name__, e)}
     rec = {"pinned": True, "local_rank": local_rank, "numa_node": numa[local_rank], "cores": len(cpus), "first_core": cpus[0], "last_core": cpus[-1]}
     if set_torch_threads:
         try:

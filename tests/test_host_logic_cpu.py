@@ -442,3 +442,22 @@ def test_stride_tap_adds_in_place_only_into_a_gradient_nobody_else_holds():
     assert (inplace, cloned) == (0, 1)
     assert torch.allclose(gx, full, rtol=1e-5, atol=1e-5)
     assert torch.allclose(seen, lat_only, rtol=1e-5, atol=1e-5)                          # NOT the sum: the kept tensor was not written to
+
+
+def test_rank_pinning_never_takes_the_job_down(monkeypatch):
+    """a cgroup that refuses the mask, or a sysfs without the expected files: the rank runs unpinned and says why"""
+    import os
+    from medicaldetectiontoolkit_amd.utils import affinity
+
+    def refuse(pid, cpus):
+        raise OSError(22, "Invalid argument")
+    monkeypatch.setattr(os, "sched_setaffinity", refuse)
+    rec = affinity.pin_rank(0, 2, [0, 1], set_torch_threads=False)
+    assert rec["pinned"] is False and "OSError" in rec["why"]
+    monkeypatch.undo()
+
+    def broken(d):
+        raise RuntimeError("no sysfs")
+    monkeypatch.setattr(affinity, "gpu_numa_node", broken)
+    rec = affinity.pin_rank(1, 2, [0, 1], set_torch_threads=False)
+    assert rec["pinned"] is False and "RuntimeError" in rec["why"]
