@@ -137,13 +137,6 @@ int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, co
                                    const int *D, int crop_height, int crop_width, int crop_zdepth,
                                    float *const *grads_images, void *stream);
 
-/* Same for the round-3 gather-form backward (csrc/roi_align_bwd_v3.hip; tools/bwd3_probe.py): dev_buf >= 16 int64 or NULL;
- * dbg bit0 / bit1 make the scatter / zero role return at once (role-by-role timing); wg = traced scatter workgroup. */
-void mdt_debug_bwd3(long long *dev_buf, int dbg, int wg);
-/* Same for the channel-quad forward (csrc/roi_align_fwd.hip; tools/fwd_stamp_probe.py): dev_buf >= 4 * grid int64 (grid = num_boxes x channel groups)
- * or NULL; per workgroup the 100 MHz wall clock at its start, after its box / extents, when its first stage has landed in LDS, at its end. */
-void mdt_debug_fwd_stamps(long long *dev_buf);
-
 /* Exact-order form: gather kernel that adds, per voxel, the terms in exactly the order a
  * sequential out_idx loop would (corner order of crop_and_resize_kernel.cu:256-301), so the
  * result equals the fp32 CPU oracle bit for bit.  Any shape, no workspace, slower. */

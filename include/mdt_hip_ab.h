@@ -50,6 +50,17 @@ int mdt_crop_and_resize_3d_backward_atomic(
 int mdt_ab_crop_and_resize_backward_territory(int dim, const float *grads, const float *boxes, const int *box_ind, int num_boxes, int batch,
                                               int H, int W, int D, int ch, int cw, int cd, int depth, float *grads_image, void *stream);
 
+/* ---- libmdt_hip_tuning.so (csrc/Makefile: the product sources compiled with -DMDT_TUNING_HOOKS) --------------------------------------
+ * The product library libmdt_hip.so holds NO mutable process state and exports neither of the two setters below; the tuning build is the
+ * same code plus these hooks, loaded by tools/bwd3_probe.py, tools/fwd_stamp_probe.py and tools/profile_case.py only
+ * (medicaldetectiontoolkit_amd/_lib.py: use_tuning_build()).
+ * mdt_debug_bwd3: gather-form backward (csrc/roi_align_bwd_v3.hip): dev_buf >= 16 int64 or NULL; dbg bit0 / bit1 make the scatter / zero
+ * role return at once (role-by-role timing); wg = traced scatter workgroup.
+ * mdt_debug_fwd_stamps: channel-quad forward (csrc/roi_align_fwd.hip): dev_buf >= 4 * grid int64 (grid = num_boxes x channel groups) or
+ * NULL; per workgroup the 100 MHz wall clock at its start, after its box / extents, when its first stage has landed in LDS, at its end. */
+void mdt_debug_bwd3(long long *dev_buf, int dbg, int wg);
+void mdt_debug_fwd_stamps(long long *dev_buf);
+
 #ifdef __cplusplus
 }
 #endif

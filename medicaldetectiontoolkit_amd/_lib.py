@@ -16,6 +16,11 @@ NMS_RULE_GT = 0  # GPU rule, IoU >  thresh (nms_kernel.cu:71)
 NMS_RULE_GE = 1  # CPU rule, IoU >= thresh (nms.c:64)
 
 _lib = None
+# tuning hooks: exported by libmdt_hip_tuning.so only (include/mdt_hip_ab.h), bound by use_tuning_build()
+_TUNING_SIGNATURES = {
+    "mdt_debug_bwd3": (None, [c_void_p, c_int, c_int]),
+    "mdt_debug_fwd_stamps": (None, [c_void_p]),
+}
 
 _SIGNATURES = {
     "mdt_version": (c_char_p, []),
@@ -30,8 +35,6 @@ _SIGNATURES = {
     "mdt_pyramid_roi_align_forward": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mdt_pyramid_roi_align_forward_cl": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mdt_pyramid_roi_align_backward": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "mdt_debug_bwd3": (None, [c_void_p, c_int, c_int]),
-    "mdt_debug_fwd_stamps": (None, [c_void_p]),
     "mdt_upsample2x_yx_cl_forward": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_longlong, c_void_p]),
     "mdt_upsample2x_yx_cl_backward": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_longlong, c_void_p]),
     "mdt_conv3x3x3_small_supported": (c_int, [c_int] * 5),
@@ -118,6 +121,21 @@ def ab_lib():
             fn.argtypes = args
         _ab_lib = handle
     return _ab_lib
+
+
+def use_tuning_build():
+    """TOOLS ONLY (tools/bwd3_probe.py, tools/fwd_stamp_probe.py, tools/profile_case.py): make lib() load libmdt_hip_tuning.so -- the product
+    sources compiled with -DMDT_TUNING_HOOKS -- instead of libmdt_hip.so, and bind mdt_debug_bwd3 / mdt_debug_fwd_stamps.  Must be called
+    before the first lib(); the package never calls it."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_tuning_build() must precede the first _lib.lib() call")
+    path = os.path.join(_HERE, "libmdt_hip_tuning.so")
+    if not os.path.exists(path):
+        raise RuntimeError("libmdt_hip_tuning.so not found at %s -- make -C medicaldetectiontoolkit_amd/csrc" % path)
+    LIB_PATH = path
+    _SIGNATURES.update(_TUNING_SIGNATURES)
+    return lib()
 
 
 def lib():

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void conv_s221_wgrad_kernel(const flo
     // output columns whose input column 2 ox + kx - P exists
     const int d = q.P - kx;                                     // ix = 2 ox - d
     const int ox_min = d > 0 ? (d + 1) / 2 : 0;
-    int ox_max = (q.X - 1 + d) / 2;
+    int ox_max = (q.X - 1 + d) >= 0 ? (q.X - 1 + d) / 2 : -1;   // FLOOR: C division truncates towards zero, (-1) / 2 == 0 would admit ox = 0 with ix >= X (X < K)
     if (ox_max > q.OX - 1) ox_max = q.OX - 1;
     const int tpc = q.Z / (2 * G_UNROLL);                       // trips per column
 

@@ -762,7 +762,7 @@ inline int cu_count()
 
 int resident_per_cu(size_t lds)
 {
-    static int cached_lds = -1, cached = 0;
+    static thread_local int cached_lds = -1, cached = 0;      // per thread: the pair is read and written together
     if (cached_lds != (int)lds) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, crop_bwd_gather_kernel, V3_NT, lds) != hipSuccess) n = 0;
@@ -772,13 +772,17 @@ int resident_per_cu(size_t lds)
     return cached;
 }
 
+#ifdef MDT_TUNING_HOOKS        // libmdt_hip_tuning.so only (csrc/Makefile): the product library holds no mutable process state
 long long *g_v3_ts = nullptr;
 int g_v3_dbg = 0, g_v3_dbg_wg = 0;
+#endif
 
 }  // namespace
 
-// tuning hook (tools/bwd3_probe.py): stamp buffer (device, >= 16 int64) or null, role switches, traced workgroup
+#ifdef MDT_TUNING_HOOKS
+// tuning hook (tools/bwd3_probe.py, include/mdt_hip_ab.h): stamp buffer (device, >= 16 int64) or null, role switches, traced workgroup
 extern "C" void mdt_debug_bwd3(long long *dev_buf, int dbg, int wg) { g_v3_ts = dev_buf; g_v3_dbg = dbg; g_v3_dbg_wg = wg; }
+#endif
 
 namespace mdt_ra {
 
@@ -795,7 +799,11 @@ int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *bo
     V3Params p;
     p.grads = grads; p.boxes = boxes; p.box_ind = batch_ix; p.level = level;
     p.dim = dim; p.N = N; p.B = B; p.C = C; p.n_levels = n_levels;
+#ifdef MDT_TUNING_HOOKS
     p.ts = g_v3_ts; p.dbg = g_v3_dbg; p.dbg_wg = g_v3_dbg_wg;
+#else
+    p.ts = nullptr; p.dbg = 0; p.dbg_wg = 0;
+#endif
     if (dim == 3) { p.ph = ph; p.pw = pw; p.pd = pd; }
     else { p.ph = ph; p.pw = 1; p.pd = pw; }                   // 2D: (y, -, x)
     if (p.ph > 255 || p.pw > 255 || p.pd > 255) return MDT_ERR_UNSUPPORTED;   // sample ranges are packed in bytes

@@ -47,7 +47,9 @@ struct CqParams {
     int B, ch, cw, cd, C, nq, groups, qpg;
 };
 
+#ifdef MDT_TUNING_HOOKS        // libmdt_hip_tuning.so only (csrc/Makefile): the product library holds no mutable process state
 long long *g_fwd_stamps = nullptr;
+#endif
 
 // a / d for 0 <= a < 2^24, d >= 1 with a precomputed reciprocal: the float product is off by at most one, fixed up with the remainder
 __device__ __forceinline__ int fast_divmod(int a, int d, float rcp, int &rem)
@@ -451,7 +453,11 @@ int launch_fwd_cq(const PyramidMaps &maps, const float *boxes, const int *box_in
     }
     CqParams p;
     p.maps = maps; p.boxes = boxes; p.box_ind = box_ind; p.level = level; p.crops = crops;
+#ifdef MDT_TUNING_HOOKS
     p.stamps = g_fwd_stamps;
+#else
+    p.stamps = nullptr;
+#endif
     p.B = B; p.ch = ch; p.cw = cw; p.cd = cd; p.C = C;
     p.nq = (C + 3) / 4;
     // enough workgroups to give every CU three at a time (the pipeline inside a workgroup hides its own latency, neighbours hide the
@@ -503,7 +509,9 @@ template int launch_fwd_cq<u8raw>(const PyramidMaps &, const float *, const int 
 
 }  // namespace mdt_ra
 
+#ifdef MDT_TUNING_HOOKS
 extern "C" void mdt_debug_fwd_stamps(long long *dev_buf) { g_fwd_stamps = dev_buf; }
+#endif
 
 extern "C" int mdt_pyramid_roi_align_forward_cl(int n_levels, const void *const *images, int bf16, const int *H, const int *W, const int *D,
                                                 const float *boxes, const int *batch_ix, const int *level, int num_boxes, int batch, int depth,

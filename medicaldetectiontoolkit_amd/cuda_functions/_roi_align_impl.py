@@ -255,8 +255,12 @@ def pyramid_forward(maps, boxes, batch_ix, level, crop, channels_last=False):
             rc = L.mdt_pyramid_roi_align_forward_cl(len(maps), _ptr_array(maps), int(maps[0].dtype == torch.bfloat16), H, W, D,
                                                     _lib.ptr(boxes), _lib.ptr(batch_ix), _lib.ptr(level), n, B, C,
                                                     crop[0], crop[1], crop[2], _lib.ptr(crops), _lib.current_stream_ptr())
-        _lib.check(rc, "mdt_pyramid_roi_align_forward_cl")
-        return crops
+        if rc != _lib.MDT_ERR_UNSUPPORTED:
+            _lib.check(rc, "mdt_pyramid_roi_align_forward_cl")
+            return crops
+        # outside the channels-last kernel's budgets (ch + cw + cd > 192, C / 4 > 256, tile budget: launch_fwd_cl): the row-major entry serves
+        # every shape (it falls back to the generic kernel itself, roi_align.hip) -- one row-major copy of the maps, as before round 5
+        maps = [m.contiguous() for m in maps]
     with torch.cuda.device(maps[0].device):
         rc = L.mdt_pyramid_roi_align_forward(dim, len(maps), _ptr_array(maps), int(maps[0].dtype == torch.bfloat16), H, W, D,
                                              _lib.ptr(boxes), _lib.ptr(batch_ix), _lib.ptr(level), n, B, C,

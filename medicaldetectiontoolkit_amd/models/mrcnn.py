@@ -516,7 +516,16 @@ def refine_detections(rois, probs, deltas, batch_ixs, cf, B):
     bix = torch.arange(B, device=dev, dtype=torch.float32)[:, None].expand_as(top_s)
     result = torch.cat([top_b, bix.unsqueeze(-1), cls_ids.unsqueeze(-1), top_s.unsqueeze(-1)], 2)
     result = result * valid.unsqueeze(-1).to(result.dtype)
-    return result.view(-1, 2 * dim + 3), valid.view(-1)
+    # mrcnn.py:708-709: when NO roi of the whole batch reaches model_min_confidence the reference keeps index 0 of its repeated arrays --
+    # roi 0 of element 0 with class 1 and its (sub-threshold) score -- and get_results (:717-799) emits it unfiltered.  Same here, decided
+    # on the device (no host sync): slot 0 takes that row when nothing is valid.
+    none = ~valid.any()
+    fallback = torch.cat([groups_boxes[0][0, 0], mutils.const_tensor([0.0, 1.0], torch.float32, dev), groups_scores[0][0, :1]])
+    result = result.view(-1, 2 * dim + 3)
+    valid = valid.reshape(-1).clone()
+    result[0] = torch.where(none, fallback, result[0])
+    valid[0] = valid[0] | none
+    return result, valid
 
 
 ############################################################
@@ -720,8 +729,11 @@ class net(nn.Module):
         self._grad_cond = t
 
     # ------------------------------------------------------------------ forward passes
-    def forward(self, img, is_training=True, with_masks=True, rpn_graph=True):
-        """mrcnn.py:987-1050.  with_masks=False skips the mask head over the detections (the reference always runs it and
+    def forward(self, img, is_training=True, with_masks=True, rpn_graph=True, keep_rpn_maps=None):
+        """mrcnn.py:987-1050.  `is_training` selects the proposal count exactly as the reference does (:1014); note that the reference's
+        own test_forward (:982) calls `self.forward(img)` with the DEFAULT True, so its inference runs on post_nms_rois_training proposals
+        (75 in 3D) and post_nms_rois_inference is never reached -- test_forward below follows that (cf.test_forward_proposals).
+        keep_rpn_maps (default: is_training) keeps the FPN outputs for rpn_at_anchors.  with_masks=False skips the mask head over the detections (the reference always runs it and
         drops the result when return_masks is off, mrcnn.py:1046-1048 / :984): box-only inference.  rpn_graph=False: the dense RPN
         outputs carry no autograd graph (train_forward_device differentiates the RPN losses through rpn_at_anchors instead)."""
         cf = self.cf
@@ -739,7 +751,9 @@ class net(nn.Module):
             self.mrcnn_feature_maps = list(rpn_feature_maps)
         else:
             self.mrcnn_feature_maps = [m.contiguous() for m in rpn_feature_maps]
-        self.rpn_feature_maps = rpn_feature_maps if is_training else None       # read by rpn_at_anchors, released after the RPN losses
+        if keep_rpn_maps is None:
+            keep_rpn_maps = is_training
+        self.rpn_feature_maps = rpn_feature_maps if keep_rpn_maps else None       # read by rpn_at_anchors, released after the RPN losses
         with torch.set_grad_enabled(rpn_graph and torch.is_grad_enabled()):
             layer_outputs = [self.rpn(p) for p in rpn_feature_maps]
             rpn_pred_logits, rpn_pred_probs, rpn_pred_deltas = [torch.cat(list(o), dim=1) for o in zip(*layer_outputs)]
@@ -944,12 +958,18 @@ class net(nn.Module):
         entry = d.flush() if d is not None else None
         return self._resolve_deferred(entry) if entry is not None else None
 
+    def _test_is_training(self):
+        """the `is_training` argument test_forward hands to forward(): the reference passes none (mrcnn.py:982 -> default True ->
+        post_nms_rois_training proposals, :1014).  cf.test_forward_proposals = "inference" selects post_nms_rois_inference instead
+        (what the config comment intends; NOT what the reference computes)."""
+        return getattr(self.cf, "test_forward_proposals", "reference") != "inference"
+
     def test_forward(self, batch, return_masks=True):
         """mrcnn.py:969-985."""
         img = batch["data"]
         img = torch.from_numpy(np.ascontiguousarray(img)).to(self.device_).float() if not torch.is_tensor(img) else img.to(self.device_).float()
         with torch.no_grad():
-            _, _, _, detections, det_valid, detection_masks = self.forward(img, is_training=False, with_masks=return_masks)
+            _, _, _, detections, det_valid, detection_masks = self.forward(img, is_training=self._test_is_training(), with_masks=return_masks, keep_rpn_maps=False)
         return get_results(self.cf, img.shape, detections, det_valid, detection_masks, return_masks=return_masks)
 
     def test_forward_detections(self, img):
@@ -959,7 +979,7 @@ class net(nn.Module):
         Rows are element-major in detection order -- the order get_results emits box dicts in.  No mask head, no read-out."""
         with torch.no_grad():
             img = img.to(self.device_).float()
-            _, _, _, det, det_valid, _ = self.forward(img, is_training=False, with_masks=False)
+            _, _, _, det, det_valid, _ = self.forward(img, is_training=self._test_is_training(), with_masks=False, keep_rpn_maps=False)
             dim = self.cf.dim
             boxes = det[:, :2 * dim].to(torch.int32).float()
             ext = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])

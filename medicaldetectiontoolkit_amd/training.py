@@ -84,6 +84,9 @@ class FlatAdam(torch.optim.Adam):
         # the tensor exists from now on (the first step's forward runs BEFORE the lazy `_build`): ones = "everything has a gradient"
         self._cond_buf = torch.ones(len(spec), dtype=torch.float32, device=next(net.parameters()).device)
         net.set_grad_cond_buffer(self._cond_buf)
+        if self._flat is not None:      # called after steps: the per-parameter counters live on the device -- keep them for the re-build
+            for p, t in zip(self._rparams, self._device_steps()):
+                self.state[p]["step"] = torch.tensor(float(t))
         self._flat = None
         return self
 
@@ -184,6 +187,30 @@ class FlatAdam(torch.optim.Adam):
         super().load_state_dict(state_dict)
         self._flat = None           # re-adopt the loaded moments and step counters at the next step (`_build` copies them into the flat buffers)
 
+    def _agree_present(self, flags):
+        """the host-side presence flags come from rank-LOCAL accumulate hooks; ranks that disagreed would take different skip
+        decisions and their weights and step counters would drift apart silently.  With N > 1 the flags of the FIRST step are combined
+        once (MAX all-reduce over the process group: every rank reaches its first step, so the collective sequence stays rank-symmetric)
+        and that agreed set is used from then on -- the set is structural (the reference FPN's unused P1 convolutions; data-dependent
+        absences are the device-side conditions, which already travel with the gradient all-reduce).  A later step in which this rank
+        holds a gradient for a parameter OUTSIDE the agreed set raises instead of diverging; a parameter inside the set without a local
+        gradient contributes its zeros like in every DDP."""
+        gs = self._grad_sync
+        if not gs._active() or dist.get_world_size() == 1:
+            return flags
+        agreed = getattr(self, "_present_agreed", None)
+        if agreed is None or len(agreed) != len(flags):
+            dev = self._flat[0].device if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.tensor(list(flags), dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            agreed = self._present_agreed = bytearray(int(v) for v in t.cpu().tolist())
+        extra = [i for i in range(len(flags)) if flags[i] and not agreed[i]]
+        if extra:
+            raise RuntimeError("FlatAdam: rank %d holds gradients for %d parameter(s) that no rank had in the first step (first: #%d, shape %s) -- the "
+                               "ranks' gradient structure diverged; data-dependent absences belong in net.grad_condition_spec()" % (
+                                   dist.get_rank(), len(extra), extra[0], tuple(self._rparams[extra[0]].shape)))
+        return bytearray(agreed)
+
     def _set_present(self, flags):
         """host-known gradient presence per segment (bytes, `_rparams` order) -> device, only when it changed"""
         if flags == self._present_host:
@@ -221,6 +248,7 @@ class FlatAdam(torch.optim.Adam):
                     raise RuntimeError("FlatAdam: a gradient view was dropped; clear gradients with FlatAdam.zero_grad()")
                 if touched is not None and not touched[i]:
                     flags[i] = 0
+            flags = self._agree_present(flags)
         else:                            # gather autograd's gradient tensors into the flat buffer: one multi-tensor copy
             dst, src = [], []
             for i, p in enumerate(self._rparams):
@@ -291,7 +319,7 @@ class FlatGradAllReduce(object):
         # "this head had a positive sample" values there (FlatAdam.attach_conditions), so that every rank takes the same skip decision
         self.n_extra = 0
         self.extra = None
-        # touched[i]: an accumulate hook fired for parameter i (backward order) since zero(); None without hooks (overlap=False)
+        # touched[i]: an accumulate hook fired for parameter i (backward order) since zero() (recorded with and without overlap)
         self.touched = None
 
     # -- setup (lazy: parameters must already live on their device)
@@ -320,10 +348,11 @@ class FlatGradAllReduce(object):
                 start, count, b = off, 0, b + 1
         self._left = list(self.bucket_left0)
         self._next = 0
-        if self.overlap:
-            self.touched = bytearray(len(order))
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        # the hooks always record WHICH parameters received a gradient (`touched`: FlatAdam's presence flags); only with overlap do they
+        # also launch the bucket collectives during backward
+        self.touched = bytearray(len(order))
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _active(self):
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force)
@@ -336,7 +365,7 @@ class FlatGradAllReduce(object):
 
     def _on_grad(self, p):
         self.touched[self._index[p]] = 1
-        if self.suspended or not self._active():
+        if self.suspended or not self.overlap or not self._active():
             return
         b = self.bucket_of[p]
         self._left[b] -= 1

@@ -420,3 +420,83 @@ def test_flat_adam_conditions_are_all_reduced_with_the_gradients_world2(tmp_path
     assert got["ranks_equal"]
     assert got["extra"] == 1 and got["last_bucket_end"] == got["numel"] + 1
     assert got["steps"] == [3.0, 3.0, 2.0, 2.0]          # trunk weight / bias: 3 steps, head weight / bias: 2
+
+
+def _presence_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for overlap in (True, False):
+        torch.manual_seed(0)
+        net = Tiny()
+        sync = training.FlatGradAllReduce(net, n_buckets=2, overlap=overlap)
+        opt = _TorchMathFlatAdam(net.parameters(), lr=1e-2, grad_sync=sync)
+        torch.manual_seed(100 + rank)
+        for it in range(3):
+            x = torch.randn(5, 4)
+            loss = net(x, use_second=(rank == 0))       # `sometimes` gets a gradient on rank 0 ONLY, `never` on no rank
+            opt.zero_grad()
+            loss.backward()
+            sync.finish()
+            opt.step()
+        params = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        both = [torch.zeros_like(params) for _ in range(world)]
+        dist.all_gather(both, params)
+        steps = {n: float(opt.state_dict()["state"][k]["step"]) for k, (n, _) in enumerate(net.named_parameters())}
+        res[overlap] = {"equal": bool(torch.equal(both[0], both[1])), "steps": steps, "agreed": bytes(opt._present_agreed)}
+    # a parameter NO rank had in the first step shows up later on one rank: loud, not silent divergence
+    torch.manual_seed(0)
+    net = Tiny()
+    sync = training.FlatGradAllReduce(net, n_buckets=2)
+    opt = _TorchMathFlatAdam(net.parameters(), lr=1e-2, grad_sync=sync)
+    err = None
+    for it in range(2):
+        loss = net(torch.randn(5, 4), use_second=(it == 1 and rank == 1))
+        opt.zero_grad()
+        loss.backward()
+        sync.finish()
+        try:
+            opt.step()
+        except RuntimeError as e:
+            err = str(e)
+    got = [None, None]
+    dist.all_gather_object(got, err)
+    if rank == 0:
+        torch.save({"res": res, "errs": got}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_adam_presence_flags_are_agreed_across_ranks_world2(tmp_path):
+    """FlatAdam's host-side 'present' flags come from rank-local accumulate hooks.  `sometimes` receives a gradient on rank 0 only:
+    both ranks must update it (MAX over ranks in the first step), skip `never`, and end bit-identical -- with the bucket hooks (overlap) and
+    without (overlap=False used to count every parameter, also `never`, as present).  A gradient appearing later for a parameter outside
+    the agreed set raises on the rank that sees it."""
+    out = str(tmp_path / "presence_r0.pt")
+    mp.spawn(_presence_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    for overlap in (True, False):
+        r = got["res"][overlap]
+        assert r["equal"], overlap
+        assert r["steps"] == {"used.weight": 3.0, "used.bias": 3.0, "sometimes.weight": 3.0, "sometimes.bias": 3.0, "never.weight": 0.0, "never.bias": 0.0}, (overlap, r["steps"])
+        assert sorted(r["agreed"]) == [0, 0, 1, 1, 1, 1]
+    assert got["errs"][0] is None and got["errs"][1] is not None and "gradient structure diverged" in got["errs"][1]
+
+
+def test_attach_conditions_after_steps_keeps_the_step_counters():
+    """attach_conditions() drops the flat buffers; the per-parameter counters live on the device and must survive the re-build"""
+    torch.manual_seed(0)
+    net = _CondNet()
+    opt = _TorchMathFlatAdam(net.parameters(), lr=1e-2)
+    for it in range(2):
+        loss = net.step_loss(torch.randn(5, 4), 1)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    opt.attach_conditions(net)
+    loss = net.step_loss(torch.randn(5, 4), 1)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert all(float(v["step"]) == 3.0 for v in opt.state_dict()["state"].values()), [float(v["step"]) for v in opt.state_dict()["state"].values()]

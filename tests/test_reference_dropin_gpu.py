@@ -274,3 +274,155 @@ def test_reference_adam_leaves_the_same_parameters_alone_as_flat_adam_in_a_step_
     for k, n in enumerate(names):
         assert float(ms[k]["step"]) == (float(rs[k]["step"]) if k in rs else 0.0), n
     assert max(float(rs[k]["step"]) for k, n in enumerate(names) if n in heads) < 3.0 == max(float(v["step"]) for v in rs.values())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Assembled INFERENCE forward (BASELINE config 5's own path; VERDICT r5 "What's missing" 1): the reference's `net.test_forward` --
+# forward -> refine_detections -> mask head -> get_results incl. the mask unmolding into `seg_preds` (mrcnn.py:969-1050, 620-714, 717-799;
+# retina_unet.py:459-520, 187-272, 275-338) -- UNMODIFIED on the HIP ops, against this repo's net with the same name-seeded weights.
+# Bars: equal detection counts per element, integer box coordinates equal (the cast of mrcnn.py:752 happens after
+# torch.round: a difference would be >= 1 px, none is allowed), class ids equal, scores <= 1e-5, seg_preds voxel-for-voxel -- a voxel may
+# differ only where the reference's own un-rounded value is a tie (|value - 0.5| <= 1e-4 for the pasted masks; top-2 soft-max margin
+# <= 1e-4 for the Retina U-Net arg-max), which the test counts and bounds.
+# ------------------------------------------------------------------------------------------------------------------------------
+INFER_CASES = {"small": ([64, 64, 32], 2), "bench_patch": ([128, 128, 128], 1)}
+
+
+def _infer_cf(model, case, backbone_path=None):
+    from medicaldetectiontoolkit_amd.configs import Configs
+    patch, nb = INFER_CASES[case]
+    cf = Configs(dim=3, model=model, patch_size=list(patch), batch_size=nb)
+    if backbone_path is not None:
+        cf.backbone_path = backbone_path
+    return cf
+
+
+def _infer_image(case, seed=57):
+    patch, nb = INFER_CASES[case]
+    return np.random.default_rng(seed).standard_normal([nb, 1] + list(patch)).astype(np.float32)
+
+
+def _det_rows(res):
+    """per element: detections as sorted rows (class id, coords..., score) -- the reference emits them in index order of its repeated
+    class-major arrays (mrcnn.py:704-711 unique1d), this repo in score order; consumers (predictor.py:458-510, WBC) do not depend on it"""
+    out = []
+    for bl in res["boxes"]:
+        rows = [[int(b["box_pred_class_id"])] + [int(v) for v in b["box_coords"]] + [float(b["box_score"])] for b in bl if b["box_type"] == "det"]
+        out.append(sorted(rows, key=lambda r: (r[0], tuple(r[1:-1]), -r[-1])))
+    return out
+
+
+def _compare_detections(rres, mres, what, min_total):
+    rr, mm = _det_rows(rres), _det_rows(mres)
+    assert [len(r) for r in rr] == [len(m) for m in mm], "%s: detection counts per element differ: reference %s, this repo %s" % (
+        what, [len(r) for r in rr], [len(m) for m in mm])
+    assert sum(len(r) for r in rr) >= min_total, "%s: the case must produce detections to compare (got %d)" % (what, sum(len(r) for r in rr))
+    worst = 0.0
+    for e, (re_, me_) in enumerate(zip(rr, mm)):
+        for r, m in zip(re_, me_):
+            assert r[:-1] == m[:-1], "%s: element %d: class id / integer box differ: reference %s, this repo %s" % (what, e, r, m)
+            worst = max(worst, abs(r[-1] - m[-1]))
+    assert worst <= 1e-5, "%s: scores differ by %.3g" % (what, worst)
+    return sum(len(r) for r in rr), worst
+
+
+@pytest.mark.parametrize("case", ["small", "bench_patch"])
+def test_reference_mrcnn_test_forward_equals_this_repos_test_forward(ref, cuda, case):
+    """reference mrcnn.py `net.test_forward(batch, return_masks=True)` (:969-985) vs models/mrcnn.py `net.test_forward`, same weights.
+    The reference calls `self.forward(img)` with the DEFAULT is_training=True (:982): its inference uses post_nms_rois_training proposals
+    (75 in 3D), never post_nms_rois_inference -- this repo's test_forward does the same."""
+    from medicaldetectiontoolkit_amd.models import mrcnn as my_mrcnn
+    mr, _lib = ref["mrcnn"], ref["lib"]
+    cf = _infer_cf("mrcnn", case, os.path.join(REF_PY, "models/backbone.py"))
+    rnet = mr.net(cf, _log()).cuda().eval()
+    si.fill_by_name(rnet)
+    mnet = my_mrcnn.net(_infer_cf("mrcnn", case), device=cuda).eval()
+    si.fill_by_name(mnet)
+    batch = {"data": _infer_image(case)}
+    unmolded = []
+    orig_unmold = mr.mutils.unmold_mask_3D
+
+    def spy(mask, bbox, image_shape):
+        full = orig_unmold(mask, bbox, image_shape)
+        unmolded.append(full)
+        return full
+    mr.mutils.unmold_mask_3D = spy
+    _lib.count_calls(True)
+    try:
+        with torch04(), torch.no_grad():
+            rres = rnet.test_forward(batch, return_masks=True)
+        ref_calls = dict(_lib.CALLS)
+    finally:
+        _lib.count_calls(False)
+        mr.mutils.unmold_mask_3D = orig_unmold
+    _lib.count_calls(True)
+    try:
+        mres = mnet.test_forward(batch, return_masks=True)
+        my_calls = dict(_lib.CALLS)
+    finally:
+        _lib.count_calls(False)
+    nb = INFER_CASES[case][1]
+    assert ref_calls.get("mdt_nms_3d", 0) >= nb and ref_calls.get("mdt_crop_and_resize_3d_forward", 0) >= 2, ref_calls
+    assert sum(v for k, v in my_calls.items() if "roi_align" in k or "crop_and_resize" in k) >= 2 and sum(
+        v for k, v in my_calls.items() if "nms" in k) >= 2, my_calls
+    n, worst = _compare_detections(rres, mres, "mrcnn test_forward [%s]" % case, min_total=nb)
+    # seg_preds: max over the pasted, zoomed masks, rounded (mrcnn.py:768-797)
+    rs, ms = rres["seg_preds"], mres["seg_preds"]
+    assert rs.shape == ms.shape == (nb, 1) + tuple(INFER_CASES[case][0]) and rs.dtype == ms.dtype == np.uint8
+    assert rs.any(), "the case must paste masks"
+    counts = [sum(1 for b in bl if b["box_type"] == "det") for bl in rres["boxes"]]
+    assert sum(counts) == len(unmolded)
+    diff = rs != ms
+    off = 0
+    for e, c in enumerate(counts):
+        if c:
+            pre = np.max(np.array(unmolded[off:off + c]), 0)
+            off += c
+            bad = diff[e, 0] & (np.abs(pre - 0.5) > 1e-4)
+            assert not bad.any(), "mrcnn test_forward [%s]: element %d: %d seg_preds voxels differ away from a rounding tie" % (case, e, int(bad.sum()))
+        else:
+            assert not diff[e].any()
+    assert int(diff.sum()) <= max(4, int(1e-5 * diff.size)), "%d of %d seg_preds voxels differ (ties)" % (int(diff.sum()), diff.size)
+
+
+@pytest.mark.parametrize("case", ["small", "bench_patch"])
+def test_reference_retina_unet_test_forward_equals_this_repos_test_forward(ref, cuda, case):
+    """reference retina_unet.py `net.test_forward` (:459-475): forward (:478-513) -> refine_detections (:187-272, nms_3D per element and class)
+    -> get_results (:275-338, seg_preds = arg-max of the soft-max over the full-resolution segmentation logits)"""
+    from medicaldetectiontoolkit_amd.models import retina_unet as my_ru
+    ru, _lib = ref["retina_unet"], ref["lib"]
+    cf = _infer_cf("retina_unet", case, os.path.join(REF_PY, "models/backbone.py"))
+    rnet = ru.net(cf, _log()).cuda().eval()
+    si.fill_by_name(rnet)
+    mnet = my_ru.net(_infer_cf("retina_unet", case), device=cuda).eval()
+    si.fill_by_name(mnet)
+    batch = {"data": _infer_image(case)}
+    seg_logits = []
+    orig = ru.get_results
+
+    def spy(cf_, shape, detections, logits, *a, **k):
+        seg_logits.append(logits.detach().float().cpu().numpy())
+        return orig(cf_, shape, detections, logits, *a, **k)
+    ru.get_results = spy
+    _lib.count_calls(True)
+    try:
+        with torch04(), torch.no_grad():
+            rres = rnet.test_forward(batch)
+        ref_calls = dict(_lib.CALLS)
+    finally:
+        _lib.count_calls(False)
+        ru.get_results = orig
+    mres = mnet.test_forward(batch)
+    nb = INFER_CASES[case][1]
+    assert ref_calls.get("mdt_nms_3d", 0) >= nb, ref_calls
+    _compare_detections(rres, mres, "retina_unet test_forward [%s]" % case, min_total=nb)
+    rs, ms = rres["seg_preds"], mres["seg_preds"]
+    assert rs.shape == ms.shape == (nb, 1) + tuple(INFER_CASES[case][0]) and rs.dtype == ms.dtype == np.uint8
+    assert len(np.unique(rs)) >= 2, "the case must produce a non-trivial label map"
+    diff = (rs != ms)[:, 0]
+    if diff.any():
+        lg = np.sort(seg_logits[0], axis=1)                    # the soft-max is monotone: the arg-max margin is the logit margin
+        margin = lg[:, -1] - lg[:, -2]
+        assert not (diff & (margin > 1e-4)).any(), "retina_unet test_forward [%s]: %d label voxels differ away from a tie" % (
+            case, int((diff & (margin > 1e-4)).sum()))
+    assert int(diff.sum()) <= max(4, int(1e-5 * diff.size)), "%d of %d seg_preds voxels differ (ties)" % (int(diff.sum()), diff.size)

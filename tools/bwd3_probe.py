@@ -8,7 +8,7 @@ from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
 from medicaldetectiontoolkit_amd.utils.synthetic_data import random_boxes_3d, trainlike_rois_3d
 
 dev = torch.device("cuda:0")
-L = _lib.lib()
+L = _lib.use_tuning_build()      # libmdt_hip_tuning.so: the product sources + the stamp / role hooks (include/mdt_hip_ab.h)
 B, C, N = 8, 36, 48
 LEVELS = {"P2": (32, 32, 128), "P3": (16, 16, 64), "P5": (4, 4, 16)}
 names = ["list", "plan", "wzero", "wtables", "dma_wait", "pass_y", "pass_x", "final", "zero_fill"]

@@ -13,7 +13,7 @@ rng = np.random.default_rng(0)
 torch.manual_seed(0)
 B, C = 8, 36
 P2 = torch.randn((B, C, 32, 32, 128), device=dev)
-L = _lib.lib()
+L = _lib.use_tuning_build()      # libmdt_hip_tuning.so: the product sources + the stamp / role hooks (include/mdt_hip_ab.h)
 for tag, n, crop in (("N240_14x14x5", 240, (14, 14, 5)), ("N600_7x7x3", 600, (7, 7, 3)), ("N48_14x14x5", 48, (14, 14, 5))):
     bx = torch.from_numpy(random_boxes_3d(rng, n)).to(dev)
     bi = torch.from_numpy(rng.integers(0, B, n).astype(np.int32)).to(dev)

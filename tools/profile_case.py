@@ -12,6 +12,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("MDT_BWD3_DBG"):       # role switches of the gather-form backward: the tuning build (include/mdt_hip_ab.h mdt_debug_bwd3),
+    from medicaldetectiontoolkit_amd import _lib      # chosen before anything loads the product library
+    _lib.use_tuning_build().mdt_debug_bwd3(None, int(os.environ["MDT_BWD3_DBG"]), 0)
 from medicaldetectiontoolkit_amd.cuda_functions import _nms_impl, _roi_align_impl  # noqa: E402
 from medicaldetectiontoolkit_amd.utils.synthetic_data import nms_boxes, random_boxes_3d, trainlike_rois_3d  # noqa: E402
 
@@ -57,9 +60,6 @@ fns = {
     "nms6000": lambda: _nms_impl.nms_sorted(ds, 0.7, 3),
     "nms6000_keep75": lambda: _nms_impl.nms_sorted(ds, 0.7, 3, max_keep=75),
 }
-if os.environ.get("MDT_BWD3_DBG"):       # role switches of the gather-form backward (include/mdt_hip.h mdt_debug_bwd3)
-    from medicaldetectiontoolkit_amd import _lib
-    _lib.lib().mdt_debug_bwd3(None, int(os.environ["MDT_BWD3_DBG"]), 0)
 if case == "pyramid_bwd":
     shapes = [(8, 36) + LEVELS[k] for k in ("P2", "P3", "P4", "P5")]
     per = []
