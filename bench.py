@@ -340,7 +340,8 @@ def _graph_preflight(args, device_index, legs=False, timeout_s=600):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--graph-preflight", "legs" if legs else "check", "--patch", args.patch, "--batch", str(args.batch),
            "--gmax", str(args.gmax), "--steps", str(args.steps), "--device-index", str(device_index), "--channels-last", str(args.channels_last),
-           "--merge-rpn-heads", str(args.merge_rpn_heads), "--sparse-rpn-loss", str(args.sparse_rpn_loss)] + (["--no-exec-leg"] if args.no_exec_leg else [])
+           "--merge-rpn-heads", str(args.merge_rpn_heads), "--sparse-rpn-loss", str(args.sparse_rpn_loss), "--step-form", args.step_form] + (
+               ["--no-exec-leg"] if args.no_exec_leg else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                           "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     t0 = time.time()
@@ -379,7 +380,10 @@ def graph_preflight_main(args):
     torch.manual_seed(0)
     net = mrcnn.net(cf, device=dev)
     opt = training.build_optimizer(net, cf, flat=True)
-    step = training.GraphedTrainStep(net, opt, gmax=args.gmax)
+    exec_form = args.step_form == "exec"
+    if exec_form:
+        cf.run_detection_mask_head_in_training = True
+    step = training.GraphedTrainStep(net, opt, gmax=args.gmax, monitor="deferred" if exec_form else False, with_masks=exec_form)
     pool = [to_device(make_batch(patch, args.batch, seed=1000 + i), dev) for i in range(3)]
     for i in range(3):
         res = step(pool[i % 3])
@@ -392,8 +396,11 @@ def graph_preflight_main(args):
     n = max(2, min(args.steps, 10))
     step.host_ms = {}
     t0 = time.time()
+    used = 0
     for i in range(n):
-        step(pool[i % 3])
+        r = step(pool[i % 3])
+        if "logger_string" in r:
+            used += len(r["logger_string"]) + len(r["boxes"]) + len(r["monitor_values"])
     torch.cuda.synchronize()
     dt = time.time() - t0
     hm, step.host_ms = step.host_ms, None
@@ -409,7 +416,8 @@ def graph_preflight_main(args):
     torch.cuda.synchronize()
     rec = {"graphed_step": {"value": round(args.batch * n / dt, 3), "unit": "patches/s", "steps": n, "ms_per_step": round(dt / n * 1e3, 2),
                             "host_ms_per_step": hw, "hipGraphLaunch_host_ms_gpu_idle": round(min(idle), 2),
-                            "note": "training.GraphedTrainStep in a child process (fresh net of the same seed, same batch generator): the device half of the step as "
+                            "step_form": args.step_form,
+                            "note": "training.GraphedTrainStep in a child process (fresh net of the same seed, same batch generator; the headline's step form): the device half of the step as "
                                     "ONE hipGraph replay (+ Adam launch); `replay` in host_ms_per_step includes waiting for the previous replay of the same "
                                     "graph (= the GPU), the idle figure is the launch itself"}}
     if not args.no_exec_leg:
@@ -429,7 +437,7 @@ def exec_equivalent_leg(net, opt, cf, patch, args, dev, use_graph, deferred=True
     late, no host sync in the step); deferred=False: the synchronous read-out of round 4 (1 sync per step)."""
     from medicaldetectiontoolkit_amd import training
     from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch
-    n = max(3, min(args.steps, 8))
+    n = max(3, args.steps if deferred else min(args.steps, 8))
     host_pool = [make_batch(patch, args.batch, seed=50 + i) for i in range(2)]
     seq = [host_pool[i % 2] for i in range(n + 2)]
     prev = getattr(cf, "run_detection_mask_head_in_training", False)
@@ -611,6 +619,10 @@ def main():
     ap.add_argument("--pin-cores", type=int, default=1, help="N > 1: 1 (default) pins every rank to its own slice of the cores of its GPU's NUMA node (utils/affinity.py); 0: only caps the intra-op threads")
     ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
     ap.add_argument("--channels-last", type=int, default=1)
+    ap.add_argument("--step-form", type=str, default="exec", choices=["exec", "no-readout"],
+                    help="exec (default): the step exec.py:68-79 runs -- train_forward WITH the per-batch read-out (logger_string, box lists, monitor_values; one "
+                         "packed asynchronous device->host copy, consumed every step) and the mask head over the detections (mrcnn.py:1046-1048), backward, Adam; "
+                         "no-readout: round 5's headline form (train_forward(monitor=False), no detection mask head), otherwise timed as the `no_readout_step` leg")
     ap.add_argument("--host-batches", action="store_true", help="hand numpy batches to train_forward (PCIe-inclusive rate)")
     args = ap.parse_args()
 
@@ -716,12 +728,21 @@ def main():
         use_graph = ok
     graph_rec["used_for_headline"] = use_graph
     # graphed headline: capture FIRST, before any eager step of this net (graph_preflight_main explains)
-    gstep = training.GraphedTrainStep(net, opt, grad_sync=sync, gmax=args.gmax) if use_graph else None
+    exec_form = args.step_form == "exec"
+    # the read-out mode of the headline step: Mask R-CNN hands the packed read-out over with an asynchronous copy and the entries of step i
+    # are consumed while step i + 1 is queued ("deferred"); the Retina nets read back synchronously like the reference
+    mon_mode = False if not exec_form else ("deferred" if args.model == "mrcnn" else True)
+    if exec_form and args.model == "mrcnn":
+        cf.run_detection_mask_head_in_training = True       # mrcnn.py:1046-1048: the reference runs it in every training step
+    gstep = training.GraphedTrainStep(net, opt, grad_sync=sync, gmax=args.gmax, monitor=mon_mode, with_masks=exec_form) if use_graph else None
+    consumed = [0, None]               # what exec.py:76-79 reads every batch: characters / boxes / values consumed, the last log line
 
     def run_step(b):
-        if gstep is not None:
-            return gstep(b)
-        return training.train_step(net, opt, b, grad_sync=sync, monitor=False)
+        r = gstep(b) if gstep is not None else training.train_step(net, opt, b, grad_sync=sync, monitor=mon_mode)
+        if "logger_string" in r:       # (deferred: absent on the very first call only)
+            consumed[0] += len(r["logger_string"]) + len(r["boxes"]) + len(r["monitor_values"])
+            consumed[1] = r["logger_string"]
+        return r
 
     def host_work_of(g):
         hm, g.host_ms = g.host_ms, None
@@ -729,6 +750,12 @@ def main():
         hw = {k: round(v / c, 3) for k, v in hm.items()}
         hw["work_total"] = round(sum(v for k, v in hw.items() if k != "ring_wait_backpressure"), 3)
         return hw
+
+    def eager_step(b):                 # the headline step's form, launched eagerly (A/B legs)
+        r = training.train_step(net, opt, b, grad_sync=sync, monitor=mon_mode)
+        if "logger_string" in r:
+            consumed[0] += len(r["logger_string"]) + len(r["boxes"]) + len(r["monitor_values"])
+        return r
 
     for i in range(max(args.warmup, 1 if use_graph else 0)):
         run_step(pool[i % len(pool)])
@@ -764,14 +791,36 @@ def main():
     # ---- A/B leg: the other form of the step, same net / optimizer / batches, warmed up like the headline
     eager_rec, graphed_rec = None, None
     n_ab = max(2, min(args.steps, 8))
+    # ---- round 5's headline form as a named leg: no read-out, no mask head over the detections (what the step costs without exec.py's consumers)
+    no_readout_rec = None
+    if exec_form:
+        prev_mh = getattr(cf, "run_detection_mask_head_in_training", False)
+        cf.run_detection_mask_head_in_training = False
+        try:
+            n_nr = max(2, min(args.steps, 10))
+            for i in range(2):
+                training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+            barrier()
+            tn = time.time()
+            for i in range(n_nr):
+                training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+            th_n = time.time() - tn
+            barrier()
+            tn = time.time() - tn
+            no_readout_rec = {"value": round(args.batch * world * n_nr / tn, 3), "unit": "patches/s", "steps": n_nr, "ms_per_step": round(tn / n_nr * 1e3, 2),
+                              "host_issue_ms_per_step": round(th_n / n_nr * 1e3, 2),
+                              "note": "train_step(monitor=False), eager: forward + backward + Adam with every loss term and gradient, WITHOUT the per-batch read-out of "
+                                      "exec.py:76-79 and without the mask head over the detections (round 5's `value` form)"}
+        finally:
+            cf.run_detection_mask_head_in_training = prev_mh
     if use_graph and not args.no_eager_leg:
         for i in range(3):
-            training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+            eager_step(pool[i % len(pool)])
         barrier()
         _roi_align_impl.PROFILE = []
         te = time.time()
         for i in range(n_ab):
-            training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+            eager_step(pool[i % len(pool)])
         th_e = time.time() - te
         barrier()
         te = time.time() - te
@@ -787,11 +836,11 @@ def main():
         mrcnn.SPARSE_RPN_LOSS = False
         try:
             for i in range(3):
-                training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+                eager_step(pool[i % len(pool)])
             barrier()
             td = time.time()
             for i in range(n_ab):
-                training.train_step(net, opt, pool[i % len(pool)], grad_sync=sync, monitor=False)
+                eager_step(pool[i % len(pool)])
             barrier()
             td = time.time() - td
             dense_rpn_rec = {"value": round(args.batch * world * n_ab / td, 3), "unit": "patches/s", "steps": n_ab, "ms_per_step": round(td / n_ab * 1e3, 2),
@@ -814,11 +863,11 @@ def main():
             from medicaldetectiontoolkit_amd.utils.synthetic_data import batch_with_gt_from_proposals
             b48 = batch_with_gt_from_proposals(net, cf, pool[0] if not args.host_batches else to_device(pool[0], dev), dev)
             for _ in range(2):
-                training.train_step(net, opt, b48, monitor=False)
+                eager_step(b48)
             torch.cuda.synchronize()
             _roi_align_impl.PROFILE = []
             for _ in range(12):          # 12 launches of the mask head's pyramid backward (4 were too few: 0.598 .. 0.643 between runs)
-                training.train_step(net, opt, b48, monitor=False)
+                eager_step(b48)
             torch.cuda.synchronize()
             prof48, _roi_align_impl.PROFILE = _roi_align_impl.PROFILE, None
             # the same step TIMED on that batch (VERDICT r4 "weak" 2): every RoI-head slot that can be valid is, positives exist, the mask and
@@ -827,7 +876,7 @@ def main():
             barrier()
             t48 = time.time()
             for _ in range(n_ab):
-                c48.append(training.train_step(net, opt, b48, monitor=False)["sample_counts"])
+                c48.append(eager_step(b48)["sample_counts"])
             barrier()
             t48 = time.time() - t48
             heads_full_rec = {"value": round(args.batch * n_ab / t48, 3), "unit": "patches/s", "steps": n_ab, "ms_per_step": round(t48 / n_ab * 1e3, 2),
@@ -920,20 +969,23 @@ def main():
                            "Mask R-CNN (3D RoIAlign + 3D NMS)" if args.model == "mrcnn" else "Retina U-Net", "x".join(map(str, patch)), args.batch),
                        "parallelism": "dp%d (one process per GPU, flat-bucket gradient all-reduce over %s)" % (world, "RCCL" if args.backend == "nccl" else args.backend),
                        "global_batch": args.batch * world,
-                       "step_form": ("forward + backward + Adam of exec.py:68-74, every loss term and every parameter gradient of the reference step "
-                                     "(tests/test_step_parity_gpu.py pins them against the reference at this configuration).  "
-                                     + ("NOT in `value`, IN `exec_equivalent`: "
-                                        "(1) train_forward(monitor=False): the per-batch read-out exec.py:76-79 consumes (logger_string, box lists, monitor_values) is not "
-                                        "built and nothing is copied to the host; (2) the mask head over the DETECTIONS (mrcnn.py:1046-1048, :946-964) is not run -- "
-                                        "no loss term or gradient depends on it, the reference computes it in every training step and only its validation pass reads it.  "
-                                        "`exec_equivalent` is the step with both, fed host numpy batches: the figure to quote for SURVEY 8(d) M1 as exec.py runs it.  "
-                                        if args.model == "mrcnn" else "train_forward(monitor=False): the per-batch read-out of exec.py:76-79 is not built.  ")
+                       "step_form": ("exec.py:68-79 as the reference runs it: results = net.train_forward(batch) -- forward, losses, "
+                                     + ("the mask head over the detections (mrcnn.py:1046-1048), the per-batch read-out exec.py:76-79 consumes (logger_string, box lists, "
+                                        "monitor_values: ONE packed device->host copy per step, asynchronous, the entries of step i consumed while step i + 1 is queued) -- "
+                                        if (args.model == "mrcnn" and args.step_form == "exec") else
+                                        ("the per-batch read-out exec.py:76-79 consumes (logger_string, box lists, seg_preds, monitor_values; synchronous) -- "
+                                         if args.step_form == "exec" else "WITHOUT the per-batch read-out (--step-form no-readout) -- "))
+                                     + "zero_grad, backward, Adam (exec.py:68-74); every loss term and every parameter gradient of the reference step "
+                                     "(tests/test_step_parity_gpu.py pins them against the reference at this configuration).  Batches resident in HBM when the timed region "
+                                     "starts (measurement contract); the same step fed host numpy batches through training.DevicePrefetcher is `exec_equivalent`"
+                                     + (", the step without read-out and detection mask head is `no_readout_step`.  " if args.step_form == "exec" else ".  ")
                                      + ("The timed batches are random-GT batches on random-init weights: see `timed_batches` for how full the RoI heads were, "
                                         "`heads_full_step` for the same step with full RoI heads.  " if args.model == "mrcnn" else "") + "RPN losses back-propagated "
                                      + ("through the sampled anchors only (same gradients as the dense graph, which is timed as dense_rpn_graph_step)"
                                         if (args.model == "mrcnn" and args.sparse_rpn_loss) else "through the dense RPN outputs"))},
             "timed_batches": timed_batches, "heads_full_step": heads_full_rec,
-            "graph": graph_rec, "eager_step": eager_rec, "graphed_step": graphed_rec, "dense_rpn_graph_step": dense_rpn_rec, "exec_equivalent": exec_eq,
+            "readout_consumed": {"items": consumed[0], "last_logger_string": consumed[1]},
+            "no_readout_step": no_readout_rec, "graph": graph_rec, "eager_step": eager_rec, "graphed_step": graphed_rec, "dense_rpn_graph_step": dense_rpn_rec, "exec_equivalent": exec_eq,
             "roofline": roofline, "cpu_baseline": cpu, "h2d_inclusive": h2d, "distributed": dist_rec,
         }
         if world == 1 and not args.no_rccl_selftest:

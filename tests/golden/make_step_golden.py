@@ -132,7 +132,56 @@ def grad_norms(net):
     return {k: float(np.sqrt(sum(v))) for k, v in mods.items()}
 
 
+def retina_bench():
+    """round 6: BASELINE config 2 AT ITS BENCHMARKED SIZE -- the reference's retina_unet.py `net.train_forward` + backward at
+    128^3, batch 8, on the CPU -> step_reference_bench_retina.npz.  The batch is the one of the Mask R-CNN `bench` case (GT boxes read from
+    step_reference_bench.npz, so the ~15 min Mask R-CNN step is not repeated).
+    Run:  (ulimit -v 56000000; timeout 7200 python tests/golden/make_step_golden.py bench-retina)"""
+    log = logging.getLogger("step_golden")
+    log.addHandler(logging.NullHandler())
+    case = "bench"
+    nb = si.CASES[case][1]
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    g = np.load(os.path.join(HERE, "step_reference_bench.npz"), allow_pickle=False)
+    out = {}
+    gt_boxes = [g["gt_boxes_%d" % b] for b in range(nb)]
+    gt_labels = [g["gt_labels_%d" % b] for b in range(nb)]
+    for b in range(nb):
+        out["gt_boxes_%d" % b], out["gt_labels_%d" % b] = gt_boxes[b], gt_labels[b]
+    batch = si.make_batch(si.make_image(case=case), gt_boxes, gt_labels)
+    cfr = si.make_cf("retina_unet", case)
+    cfr.backbone_path = os.path.join(REF, "models/backbone.py")
+    ru.compute_class_loss.__defaults__ = (1,)                   # shem_poolsize default 20 -> 1 (deterministic SHEM)
+    netr = ru.net(cfr, log)
+    si.fill_by_name(netr)
+    recr = {"class": Recorder(ru, "compute_class_loss"), "bbox": Recorder(ru, "compute_bbox_loss")}
+    dice = Recorder(ru.mutils, "batch_dice")
+    np.random.seed(0)
+    torch.manual_seed(0)
+    with torch04():
+        resr = netr.train_forward(batch)
+    for k, r in recr.items():
+        out["retina_term_" + k] = np.float64(sum(r.vals) / nb)
+    out["retina_term_seg_dice"] = np.float64(1.0 - dice.vals[0])
+    out["retina_term_seg_ce"] = np.float64(2.0 * (resr["torch_loss"].item() - out["retina_term_class"] - out["retina_term_bbox"]) - out["retina_term_seg_dice"])
+    netr.zero_grad()
+    resr["torch_loss"].backward()
+    out["retina_logger_string"] = np.array(resr["logger_string"])
+    out["retina_loss"] = np.float64(resr["torch_loss"].item())
+    out["retina_class_loss"] = np.float64(resr["monitor_values"]["class_loss"])
+    for k, v in grad_norms(netr).items():
+        out["retina_gradnorm_" + k] = np.float64(v)
+    out["retina_n_pos_neg_anchors"] = np.array([sum(1 for bl in resr["boxes"] for bx in bl if bx["box_type"] == "pos_anchor"),
+                                                 sum(1 for bl in resr["boxes"] for bx in bl if bx["box_type"] == "neg_anchor")])
+    print("retina[bench]:", resr["logger_string"], out["retina_n_pos_neg_anchors"])
+    np.savez_compressed(os.path.join(HERE, "step_reference_bench_retina.npz"), **out)
+    for k, v in out.items():
+        print(k, np.asarray(v).shape, v if np.asarray(v).size < 8 else "")
+
+
 def main(case="small"):
+    if case == "bench-retina":
+        return retina_bench()
     log = logging.getLogger("step_golden")
     log.addHandler(logging.NullHandler())
     out = {}

@@ -378,12 +378,16 @@ def test_bench_step_form_text_builds_for_both_models():
                 break
 
     class A(object):
-        model, sparse_rpn_loss = "mrcnn", 1
+        model, sparse_rpn_loss, step_form = "mrcnn", 1, "exec"
     for model in ("mrcnn", "retina_unet"):
-        A.model = model
-        text = eval(src[i:j + 1], {"args": A})
-        assert isinstance(text, str) and "exec.py:68-74" in text
-        assert ("exec_equivalent" in text) == (model == "mrcnn")
+        for form in ("exec", "no-readout"):
+            A.model, A.step_form = model, form
+            text = eval(src[i:j + 1], {"args": A})
+            assert isinstance(text, str) and "exec.py:68-74" in text
+            # the headline IS the step exec.py runs -- no "NOT in `value`" clause in its description
+            assert "NOT in" not in text
+            assert ("no_readout_step" in text) == (form == "exec")
+            assert ("WITHOUT the per-batch read-out" in text) == (form == "no-readout")
 
 
 def _stride_tap_case(mode):

@@ -426,3 +426,129 @@ def test_reference_retina_unet_test_forward_equals_this_repos_test_forward(ref, 
         assert not (diff & (margin > 1e-4)).any(), "retina_unet test_forward [%s]: %d label voxels differ away from a tie" % (
             case, int((diff & (margin > 1e-4)).sum()))
     assert int(diff.sum()) <= max(4, int(1e-5 * diff.size)), "%d of %d seg_preds voxels differ (ties)" % (int(diff.sum()), diff.size)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Metric-level parity FROM A REFERENCE-FORMAT CHECKPOINT (VERDICT r5 missing 3 / next 7): the reference's own net, trained
+# K steps on the GPU (drop-in ops) with torch.optim.Adam as exec.py:39,68-74 does, is saved BY THE REFERENCE'S OWN WRITER
+# (utils/exp_utils.py:147-192 ModelSelector.run_model_selection: `<epoch>_best_checkpoint/params.pth` = bare state dict,
+# `last_checkpoint/params.pth` = {epoch, state_dict, optimizer}); this repo's net + FlatAdam load both files; patch-tiled prediction of two
+# synthetic volumes through this repo's predictor with either net behind it; then weighted box clustering and the ROI AP of evaluator.py.
+# ------------------------------------------------------------------------------------------------------------------------------
+class _RefNetAdapter(object):
+    """what predictor.collect_raw_boxes needs from a net (`device_`, `test_forward(batch)`), over the reference's net: the patch batch goes in
+    as the numpy array its test_forward expects (mrcnn.py:980-981)"""
+
+    def __init__(self, rnet, dev):
+        self.rnet, self.device_ = rnet, dev
+
+    def test_forward(self, batch, return_masks=False):
+        data = batch["data"]
+        with torch04(), torch.no_grad():
+            return self.rnet.test_forward({"data": data.detach().cpu().numpy() if torch.is_tensor(data) else data}, return_masks=return_masks)
+
+
+def test_reference_checkpoint_loads_and_gives_the_same_detections_wbc_and_ap(ref, cuda, tmp_path):
+    import types
+    from medicaldetectiontoolkit_amd import evaluator, predictor, training
+    from medicaldetectiontoolkit_amd.models import mrcnn as my_mrcnn
+    from medicaldetectiontoolkit_amd.utils import exp_utils as my_exp
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import make_batch
+    mr = ref["mrcnn"]
+    ref_exp = sys.modules["utils.exp_utils"]
+    assert os.path.realpath(ref_exp.__file__).startswith(os.path.realpath(REF_PY))
+    patch, nb, K = [64, 64, 32], 2, 20
+    cf = si.make_cf("mrcnn")
+    cf.backbone_path = os.path.join(REF_PY, "models/backbone.py")
+    rnet = mr.net(cf, _log()).cuda()
+    si.fill_by_name(rnet)
+    ropt = torch.optim.Adam(rnet.parameters(), lr=cf.learning_rate[0], weight_decay=cf.weight_decay)      # exec.py:39
+    for it in range(K):                                 # exec.py:68-74
+        np.random.seed(it)
+        torch.manual_seed(it)
+        with torch04():
+            res = rnet.train_forward(make_batch(patch, nb, seed=200 + it))
+        ropt.zero_grad()
+        res["torch_loss"].backward()
+        ropt.step()
+    assert np.isfinite(float(res["torch_loss"].item()))
+    # ---- the reference's own checkpoint writer
+    cf.fold_dir = str(tmp_path)
+    cf.save_n_models, cf.min_save_thresh, cf.model_selection_criteria = 1, 0, ["malignant_ap"]
+    selector = ref_exp.ModelSelector(cf, _log())
+    selector.run_model_selection(rnet, ropt, {"val": {"malignant_ap": [None, 0.5]}, "train": {"malignant_ap": [None, 0.4]}}, 1)
+    best, last = os.path.join(cf.fold_dir, "1_best_checkpoint"), os.path.join(cf.fold_dir, "last_checkpoint")
+    assert os.path.exists(os.path.join(best, "params.pth")) and os.path.exists(os.path.join(last, "params.pth"))
+    # ---- loaded by this repo: bare state dict into the net; {epoch, state_dict, optimizer} into net + FlatAdam
+    mcf = si.make_cf("mrcnn")
+    mnet = my_mrcnn.net(mcf, device=cuda)
+    start, _ = my_exp.load_checkpoint(best, mnet, map_location="cpu")
+    assert start == 1
+    for (n1, p1), (n2, p2) in zip(rnet.state_dict().items(), mnet.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1.detach().cpu(), p2.detach().cpu()), n1
+    mnet2 = my_mrcnn.net(si.make_cf("mrcnn"), device=cuda)
+    mopt2 = training.build_optimizer(mnet2, mnet2.cf, flat=True)
+    start, metrics = my_exp.load_checkpoint(last, mnet2, mopt2, map_location="cpu")
+    assert start == 2 and metrics["val"]["malignant_ap"][1] == 0.5
+    rs, ms = ropt.state_dict()["state"], mopt2.state_dict()["state"]
+    assert set(rs) == set(ms)
+    for k in rs:
+        assert float(rs[k]["step"]) == float(ms[k]["step"]) and torch.equal(rs[k]["exp_avg"].cpu(), ms[k]["exp_avg"].cpu())
+    # one more step from the loaded optimizer state == one more reference step (FlatAdam adopts per-parameter counters and moments)
+    b = make_batch(patch, nb, seed=300)
+    np.random.seed(77)
+    torch.manual_seed(77)
+    with torch04():
+        res = rnet.train_forward(b)
+    ropt.zero_grad()
+    res["torch_loss"].backward()
+    ropt.step()
+    training.train_step(mnet2, mopt2, b, monitor=False)
+    worst = max(float((p1.detach() - p2.detach()).abs().max() / (p1.detach().abs().max() + 1e-12))
+                for (_, p1), (_, p2) in zip(rnet.state_dict().items(), mnet2.state_dict().items()))
+    assert worst <= 2e-3, "one step after loading the reference checkpoint: parameters differ by %.3g (relative to the tensor's max)" % worst
+    rnet.load_state_dict(torch.load(os.path.join(best, "params.pth")))        # back to the checkpointed weights for the inference comparison
+    # ---- patch-tiled inference of two synthetic volumes with either net behind this repo's predictor (predictor.py:279-455 semantics)
+    rnet.eval()
+    mnet.eval()
+    mcf.class_dict = {1: "benign", 2: "malignant"}
+    mcf.ap_match_ious = [0.1]
+    results = {"ref": [], "mine": []}
+    n_raw = 0
+    for v in range(2):
+        vol = np.random.default_rng(900 + v).standard_normal((1, 96, 96, 48)).astype(np.float32)
+        raw_r, info_r = predictor.collect_raw_boxes(_RefNetAdapter(rnet, cuda), vol, mcf)
+        raw_m, info_m = predictor.collect_raw_boxes(mnet, vol, mcf)
+        assert info_r["n_patches"] == info_m["n_patches"] >= 8
+        key = lambda bx: (bx["patch_id"], bx["box_pred_class_id"], tuple(np.round(bx["box_coords"]).astype(int)))
+        raw_r, raw_m = sorted(raw_r, key=key), sorted(raw_m, key=key)
+        assert len(raw_r) == len(raw_m) and len(raw_r) > 0, (len(raw_r), len(raw_m))
+        n_raw += len(raw_r)
+        for a, c in zip(raw_r, raw_m):
+            assert a["patch_id"] == c["patch_id"] and a["box_pred_class_id"] == c["box_pred_class_id"]
+            assert np.abs(np.asarray(a["box_coords"]) - np.asarray(c["box_coords"])).max() <= 1e-4
+            assert abs(a["box_score"] - c["box_score"]) <= 1e-5
+            assert abs(a["box_patch_center_factor"] - c["box_patch_center_factor"]) <= 1e-9 and a["box_n_overlaps"] == c["box_n_overlaps"]
+        wbc_r = predictor.apply_wbc_to_patient(raw_r, mcf, info_r["n_passes"], device=cuda)
+        wbc_m = predictor.apply_wbc_to_patient(raw_m, mcf, info_m["n_passes"], device=cuda)
+        assert len(wbc_r) == len(wbc_m) > 0
+        for a, c in zip(wbc_r, wbc_m):
+            assert a["box_pred_class_id"] == c["box_pred_class_id"]
+            assert np.abs(np.asarray(a["box_coords"]) - np.asarray(c["box_coords"])).max() <= 1e-3 and abs(a["box_score"] - c["box_score"]) <= 1e-5
+        # ground truth for the AP: the two best consolidated boxes of the reference's prediction become GT objects of their class, a third GT
+        # object sits where nothing was predicted -- tp, fp and fn all occur
+        top = sorted(wbc_r, key=lambda bx: -bx["box_score"])[:2]
+        gts = [{"box_type": "gt", "box_coords": np.asarray(t["box_coords"]), "box_label": t["box_pred_class_id"]} for t in top]
+        gts.append({"box_type": "gt", "box_coords": np.array([1.0, 1.0, 4.0, 4.0, 1.0, 3.0]), "box_label": 2})
+        results["ref"].append([[wbc_r + gts], "vol_%d" % v])
+        results["mine"].append([[wbc_m + gts], "vol_%d" % v])
+    ecf = types.SimpleNamespace(ap_match_ious=[0.1], class_dict={1: "benign", 2: "malignant"}, fold=0)
+    df_r, df_m = evaluator.evaluate_predictions(results["ref"], ecf, "test"), evaluator.evaluate_predictions(results["mine"], ecf, "test")
+    assert list(df_r.det_type) == list(df_m.det_type) and list(df_r.class_label) == list(df_m.class_label)
+    aps = {}
+    for cl in (1, 2):
+        a_r = evaluator.get_roi_ap_from_df(df_r[df_r.pred_class == cl], 0.1, False)
+        a_m = evaluator.get_roi_ap_from_df(df_m[df_m.pred_class == cl], 0.1, False)
+        assert a_r == a_m, (cl, a_r, a_m)
+        aps[cl] = a_r
+    assert n_raw >= 16 and any(0.0 < v <= 1.0 for v in aps.values()), aps

@@ -27,7 +27,9 @@ GOLDS = {"small": GOLD, "large": np.load(os.path.join(_GDIR, "step_reference_lar
 
 
 def _batch(case="small"):
-    gold, nb = GOLDS[case], si.CASES[case][1]
+    gold = GOLDS[case]
+    case = "bench" if case == "bench_retina" else case           # same images and GT boxes as the Mask R-CNN bench case
+    nb = si.CASES[case][1]
     gt_boxes = [gold["gt_boxes_%d" % b] for b in range(nb)]
     gt_labels = [gold["gt_labels_%d" % b] for b in range(nb)]
     return si.make_batch(si.make_image(case=case), gt_boxes, gt_labels)
@@ -123,23 +125,33 @@ def test_mrcnn_step_matches_reference_with_mfma_conv_kernels_dispatched(case, cu
         _close(v, float(gold["mrcnn_gradnorm_" + k]), 1e-3, "mrcnn[%s] grad norm of %s" % (case, k))
 
 
-def test_retina_unet_large_step_matches_reference_with_mfma_conv_kernels_dispatched(cuda):
-    """Retina U-Net at 128 x 128 x 64, batch 1 (decoder up to P0 at full resolution): same bars, same dispatch assertion"""
+_RETINA_BENCH = os.path.join(_GDIR, "step_reference_bench_retina.npz")
+
+
+@pytest.mark.parametrize("case", ["large", "bench"])
+def test_retina_unet_large_step_matches_reference_with_mfma_conv_kernels_dispatched(case, cuda):
+    """Retina U-Net at 128 x 128 x 64, batch 1 (decoder up to P0 at full resolution) and -- round 6, VERDICT r5 next 2b -- AT THE BENCHMARKED
+    CONFIGURATION (BASELINE config 2: 128^3, batch 8; golden = the reference's retina_unet.py step on the CPU, make_step_golden.py
+    bench-retina): same bars, same dispatch assertion, plus the C1 layer's own kernels (18 -> 18, 7x7x7, stride (2, 2, 1): space-to-depth
+    input + the fp32-MFMA weight gradient of csrc/conv_s221.hip)"""
     from medicaldetectiontoolkit_amd import _lib, miopen_env
     miopen_env.setup()
     from medicaldetectiontoolkit_amd.models import retina_unet
-    gold = GOLDS["large"]
+    if case == "bench":
+        assert os.path.exists(_RETINA_BENCH), "tests/golden/step_reference_bench_retina.npz is missing (make_step_golden.py bench-retina)"
+        GOLDS["bench_retina"] = np.load(_RETINA_BENCH, allow_pickle=False)
+    gold = GOLDS["large" if case == "large" else "bench_retina"]
     prev = torch.backends.cudnn.benchmark
     torch.backends.cudnn.benchmark = True
     try:
-        cf = si.make_cf("retina_unet", "large")
+        cf = si.make_cf("retina_unet", case)
         cf.channels_last = True
         net = retina_unet.net(cf, device=cuda)
         si.fill_by_name(net)
         torch.manual_seed(0)
         _lib.count_calls(True)
         try:
-            res = net.train_forward(_batch("large"), monitor=True)
+            res = net.train_forward(_batch("large" if case == "large" else "bench_retina"), monitor=True)
             net.zero_grad()
             res["torch_loss"].backward()
             torch.cuda.synchronize()
@@ -150,14 +162,18 @@ def test_retina_unet_large_step_matches_reference_with_mfma_conv_kernels_dispatc
         torch.backends.cudnn.benchmark = prev
     for name in ("mdt_conv3x3x3_small_forward+mdt_conv3x3x3_small_forward_bias_act", "mdt_conv3x3x3_small_wgrad", "mdt_conv1x1_wgrad"):
         assert _ncalls(calls, name) >= MFMA_CALLS[name], (name, calls)
+    # the C1 layer of models/backbone.py:54 runs in space-to-depth form with its weight gradient on this repo's kernel (round 5): a use-rule
+    # that silently routed it back to MIOpen's direct strided problem must fail here
+    for name in (("mdt_s2d221_input", "mdt_conv_s221_wgrad", "mdt_s2d221_fold_input_grad") if case == "bench" else ()):
+        assert _ncalls(calls, name) >= 1, (name, {k: v for k, v in calls.items() if "s2" in k or "conv" in k})
     terms = {k: float(v) for k, v in res["loss_terms"].items()}
     for k in ("class", "bbox", "seg_dice", "seg_ce"):
-        _close(terms[k], float(gold["retina_term_" + k]), 1e-4, "retina[large] " + k)
-    _close(float(res["torch_loss"]), float(gold["retina_loss"]), 1e-4, "retina[large] total loss")
+        _close(terms[k], float(gold["retina_term_" + k]), 1e-4, "retina[%s] %s" % (case, k))
+    _close(float(res["torch_loss"]), float(gold["retina_loss"]), 1e-4, "retina[%s] total loss" % case)
     boxes = [bx for bl in res["boxes"] for bx in bl]
     assert [sum(1 for bx in boxes if bx["box_type"] == t) for t in ("pos_anchor", "neg_anchor")] == gold["retina_n_pos_neg_anchors"].tolist()
     for k, v in _grad_norms(net).items():
-        _close(v, float(gold["retina_gradnorm_" + k]), 1e-3, "retina[large] grad norm of " + k)
+        _close(v, float(gold["retina_gradnorm_" + k]), 1e-3, "retina[%s] grad norm of %s" % (case, k))
 
 
 def test_retina_unet_train_forward_matches_reference_step(cuda):
