@@ -189,6 +189,12 @@ int mdt_maxpool3d_k3s221_cl_backward(const float *gy, const unsigned char *argma
  * storage [cout, taps, cin] -> [cin, taps, cout] (channels_last = 1): the filter of the forward convolution that computes
  * a unit-stride convolution's input gradient (utils/fused_epilogue.py). */
 int mdt_filter_flip_transpose(const float *w, float *out, int cout, int cin, int taps, int channels_last, void *stream);
+/* The same for MANY filters in one launch (a training step flips ~60, once per step since weights change only in the optimizer):
+ * records_dev = DEVICE array of n_records records of 40 bytes each, laid out as
+ *     { const float *w; float *out; int cout; int cin; int taps; int channels_last; long long first; }
+ * with first = number of output elements of all earlier records (ascending, record 0 has first == 0); total_elements = their sum.  The
+ * caller owns the table and the buffers (utils/fused_epilogue.py builds it once and re-uses it every step). */
+int mdt_filter_flip_transpose_batched(const void *records_dev, int n_records, long long total_elements, void *stream);
 
 /*
  * y = act(x + bias[c] (+ residual)) in one pass; y may alias x.  The convolutions stay on MIOpen (torch); this
@@ -206,6 +212,13 @@ size_t mdt_bias_act_backward_workspace_bytes(long long n, int channels, long lon
 int mdt_bias_act_backward(float *gx, const float *gy, const float *y, float *gbias,
                           long long n, int channels, long long inner, int relu,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* The same in ONE launch for channels-last storage (inner == 1): the block that draws the last ticket folds the per-block partials into gbias
+ * inside the launch (agent-scope release / acquire around the ticket).  `ticket`: one device int the CALLER owns, 0 on entry, left 0 on exit
+ * (launches that share a ticket must be ordered on one stream).  inner != 1 runs the two-launch form.  The summation order differs from
+ * mdt_bias_act_backward's (both fixed); no state inside the library. */
+int mdt_bias_act_backward_ticket(float *gx, const float *gy, const float *y, float *gbias,
+                                 long long n, int channels, long long inner, int relu,
+                                 void *workspace, size_t workspace_bytes, int *ticket, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Non-maximum suppression                                                    */

@@ -66,9 +66,11 @@ _SIGNATURES = {
     "mdt_maxpool3d_k3s221_cl_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mdt_maxpool3d_k3s221_cl_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mdt_filter_flip_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdt_filter_flip_transpose_batched": (c_int, [c_void_p, c_int, c_longlong, c_void_p]),
     "mdt_bias_act_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p]),
     "mdt_bias_act_backward_workspace_bytes": (c_size_t, [c_longlong, c_int, c_longlong]),
     "mdt_bias_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_size_t, c_void_p]),
+    "mdt_bias_act_backward_ticket": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mdt_nms_mask_3d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdt_nms_mask_2d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdt_nms_mask_full_3d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),

@@ -85,12 +85,17 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_fwd_kernel(float *y, cons
 // Thread t of a block owns channel slots; a block walks a contiguous range of pixels.  C < 256: ppb = 256 / C pixels are
 // processed side by side (thread t -> pixel lane t / C, channel t % C) and the lanes are folded in LDS in lane order;
 // C >= 256: thread t owns channels t, t + 256, ... of every pixel.  Per-block partials go to `partial[block][C]`.
+// ticket != null (round 6): the second stage runs INSIDE this launch -- every block publishes its partial row (agent-scope release), draws a
+// ticket, and the block that draws the last one folds all rows into gbias (agent-scope acquire first: per-XCD L2s are not coherent, the
+// recipe of cdna_hip_programming.md 6 G16 / MI355X_MICROARCH.md "inter-workgroup visibility") and resets the ticket to 0 for the next launch.
+// One launch instead of two per convolution layer (~60 per training step); still a fixed summation order (deterministic).
 template <bool RELU>
 __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__restrict__ gx, const float *__restrict__ gy,
                                                                      const float *__restrict__ y, float *__restrict__ partial,
-                                                                     long long npix, int C, int ppb, int ktiles, long long pix_per_block)
+                                                                     long long npix, int C, int ppb, int ktiles, long long pix_per_block,
+                                                                     int *__restrict__ ticket, float *__restrict__ gbias)
 {
-    __shared__ float s_acc[EP_THREADS];
+    __shared__ float s_acc[EP_THREADS + 1];        // [EP_THREADS]: "this block drew the last ticket" (one LDS object)
     const int t = threadIdx.x;
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     long long p1 = p0 + pix_per_block;
@@ -153,6 +158,46 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
                 }
                 partial[(long long)blockIdx.x * C + c] = acc;
             }
+        }
+    }
+    if (ticket == nullptr) return;
+    // ---- publish this block's row, draw a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int drawn = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_acc[EP_THREADS] = (drawn == (int)gridDim.x - 1) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (s_acc[EP_THREADS] == 0.0f) return;
+    // ---- last arriver: gbias[c] = sum over blocks of partial[block][c], rows read whole (coalesced), lanes folded in lane order
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
+    }
+    __syncthreads();
+    const long long nb = gridDim.x;
+    if (ktiles == 1) {
+        const int lanes = ppb * C;
+        const int pl = t / C, c = t - pl * C;
+        float acc = 0.0f;
+        if (t < lanes)
+            for (long long b = pl; b < nb; b += ppb) acc = acc + partial[b * C + c];
+        __syncthreads();
+        s_acc[t] = acc;
+        __syncthreads();
+        if (t < C) {
+            float sum = 0.0f;
+            for (int l = 0; l < ppb; ++l) sum = sum + s_acc[l * C + t];
+            gbias[t] = sum;
+        }
+    } else {
+        for (int c = t; c < C; c += EP_THREADS) {
+            float sum = 0.0f;
+            for (long long b = 0; b < nb; ++b) sum = sum + partial[b * C + c];
+            gbias[c] = sum;
         }
     }
 }
@@ -348,9 +393,26 @@ size_t mdt_bias_act_backward_workspace_bytes(long long n, int channels, long lon
     return (size_t)(rows * chunks) * sizeof(float) + 256;
 }
 
+static int bias_act_backward_impl(float *gx, const float *gy, const float *y, float *gbias, long long n, int channels, long long inner, int relu,
+                                  void *workspace, size_t workspace_bytes, int *ticket, void *stream);
+
 int mdt_bias_act_backward(float *gx, const float *gy, const float *y, float *gbias,
                           long long n, int channels, long long inner, int relu,
                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    return bias_act_backward_impl(gx, gy, y, gbias, n, channels, inner, relu, workspace, workspace_bytes, nullptr, stream);
+}
+
+int mdt_bias_act_backward_ticket(float *gx, const float *gy, const float *y, float *gbias,
+                                 long long n, int channels, long long inner, int relu,
+                                 void *workspace, size_t workspace_bytes, int *ticket, void *stream)
+{
+    if (ticket == nullptr) return MDT_ERR_INVALID_ARGUMENT;
+    return bias_act_backward_impl(gx, gy, y, gbias, n, channels, inner, relu, workspace, workspace_bytes, ticket, stream);
+}
+
+static int bias_act_backward_impl(float *gx, const float *gy, const float *y, float *gbias, long long n, int channels, long long inner, int relu,
+                                  void *workspace, size_t workspace_bytes, int *ticket, void *stream)
 {
     if (n < 0 || channels <= 0 || inner <= 0 || (n % ((long long)channels * inner)) != 0) return MDT_ERR_INVALID_ARGUMENT;
     if (relu && y == nullptr) return MDT_ERR_INVALID_ARGUMENT;
@@ -369,14 +431,17 @@ int mdt_bias_act_backward(float *gx, const float *gy, const float *y, float *gbi
         const int ppb = (ktiles == 1) ? EP_THREADS / channels : 1;
         // enough blocks to fill the chip, each with a contiguous pixel range (a multiple of ppb)
         long long blocks = (npix + 8LL * ppb - 1) / (8LL * ppb);      // ~8 pixel iterations per thread
-        if (blocks > 4 * EP_MAX_BLOCKS) blocks = 4 * EP_MAX_BLOCKS;
+        // with the in-launch second stage the last block reads every partial row: one resident wave of blocks (256 CUs x 8), not more
+        const long long cap = ticket ? 2 * EP_MAX_BLOCKS : 4 * EP_MAX_BLOCKS;
+        if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
         long long ppblock = (npix + blocks - 1) / blocks;
         ppblock = ((ppblock + ppb - 1) / ppb) * ppb;
         blocks = (npix + ppblock - 1) / ppblock;
-        if (relu) hipLaunchKernelGGL(bias_act_bwd_cl_kernel<true>, dim3((unsigned)blocks), dim3(EP_THREADS), 0, s, gx, gy, y, partial, npix, channels, ppb, ktiles, ppblock);
-        else hipLaunchKernelGGL(bias_act_bwd_cl_kernel<false>, dim3((unsigned)blocks), dim3(EP_THREADS), 0, s, gx, gy, y, partial, npix, channels, ppb, ktiles, ppblock);
+        if (relu) hipLaunchKernelGGL(bias_act_bwd_cl_kernel<true>, dim3((unsigned)blocks), dim3(EP_THREADS), 0, s, gx, gy, y, partial, npix, channels, ppb, ktiles, ppblock, ticket, gbias);
+        else hipLaunchKernelGGL(bias_act_bwd_cl_kernel<false>, dim3((unsigned)blocks), dim3(EP_THREADS), 0, s, gx, gy, y, partial, npix, channels, ppb, ktiles, ppblock, ticket, gbias);
         if (ep_check() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
+        if (ticket) return MDT_OK;            // the last block of the launch has written gbias
         // partial[block][c]: channel stride 1, block stride C
         hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(fin_blocks), dim3(EP_THREADS), 0, s, gbias, partial, channels, blocks, 1LL, (long long)channels, 1LL, 0LL);
         return ep_check();

@@ -306,6 +306,31 @@ __global__ __launch_bounds__(PL_THREADS) void filter_flip_transpose_kernel(const
     }
 }
 
+// all filters of a step in ONE launch (round 6): a device table of filter records, element ranges by prefix offset; a block owns
+// 1024 consecutive output elements and finds their filter by binary search over the offsets (<= a few hundred entries)
+struct FlipRec { const float *w; float *out; int cout, cin, taps, cl; long long first; };      // 40 bytes, mirrored by mdt_flip_record in mdt_hip.h
+
+__global__ __launch_bounds__(PL_THREADS) void filter_flip_transpose_batched_kernel(const FlipRec *__restrict__ recs, int n_recs, long long total)
+{
+    const long long base = (long long)blockIdx.x * (PL_THREADS * 4);
+    for (int u = 0; u < 4; ++u) {
+        const long long e = base + u * PL_THREADS + threadIdx.x;
+        if (e >= total) return;
+        int lo = 0, hi = n_recs - 1;
+        while (lo < hi) {                                   // last record with first <= e
+            const int mid = (lo + hi + 1) >> 1;
+            if (recs[mid].first <= e) lo = mid; else hi = mid - 1;
+        }
+        const FlipRec r = recs[lo];
+        const int i = (int)(e - r.first);
+        int co, ci, t;
+        if (r.cl) { co = i % r.cout; const int q = i / r.cout; t = q % r.taps; ci = q / r.taps; }
+        else { t = i % r.taps; const int q = i / r.taps; co = q % r.cout; ci = q / r.cout; }
+        const int ts = r.taps - 1 - t;
+        r.out[i] = r.cl ? r.w[((long long)co * r.taps + ts) * r.cin + ci] : r.w[((long long)co * r.cin + ci) * r.taps + ts];
+    }
+}
+
 inline unsigned grid_for(long long n)
 {
     long long blocks = (n + PL_THREADS - 1) / PL_THREADS;
@@ -367,6 +392,18 @@ int mdt_filter_flip_transpose(const float *w, float *out, int cout, int cin, int
     (void)hipGetLastError();
     if (channels_last) hipLaunchKernelGGL(filter_flip_transpose_kernel<true>, dim3(grid_for(n)), dim3(PL_THREADS), 0, (hipStream_t)stream, w, out, cout, cin, taps);
     else hipLaunchKernelGGL(filter_flip_transpose_kernel<false>, dim3(grid_for(n)), dim3(PL_THREADS), 0, (hipStream_t)stream, w, out, cout, cin, taps);
+    return pl_check();
+}
+
+int mdt_filter_flip_transpose_batched(const void *records_dev, int n_records, long long total_elements, void *stream)
+{
+    if (n_records < 0 || total_elements < 0 || (n_records > 0 && records_dev == nullptr)) return MDT_ERR_INVALID_ARGUMENT;
+    if (n_records == 0 || total_elements == 0) return MDT_OK;
+    const long long blocks = (total_elements + PL_THREADS * 4 - 1) / (PL_THREADS * 4);
+    if (blocks > 0x7fffffffLL) return MDT_ERR_UNSUPPORTED;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(filter_flip_transpose_batched_kernel, dim3((unsigned)blocks), dim3(PL_THREADS), 0, (hipStream_t)stream,
+                       reinterpret_cast<const FlipRec *>(records_dev), n_records, total_elements);
     return pl_check();
 }
 

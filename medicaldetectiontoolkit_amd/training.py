@@ -282,6 +282,8 @@ class FlatAdam(torch.optim.Adam):
                 self._cond_t.data_ptr() if self._cond_t is not None else None, self._policy, self._arith, lr, beta1, beta2, eps, weight_decay,
                 grad_div, self._ws.data_ptr(), self._ws.numel(), _lib.raw_stream(fparam))
         _lib.check(rc, "mdt_adam_flat_segments")
+        from .utils import fused_epilogue
+        fused_epilogue.weights_changed()        # the kernel rewrote the parameters behind torch's version counters (cached flipped filters are stale)
 
 
 class FlatGradAllReduce(object):

@@ -12,6 +12,7 @@ Also here, because they hang off the same modules (each with a module switch for
     (`conv1x1_weight_grad`, csrc/conv1x1_wgrad.hip), few-channel 3x3x3 layers forward / input gradient / weight gradient
     (`conv3x3x3_small*`, csrc/conv3x3x3_small.hip), the one-channel 7x7x7 stem forward with bias + ReLU epilogue and its weight
     gradient (`stem_forward`, `_ConvStemBiasReLU`, `stem_weight_grad`; csrc/conv_stem_fwd.hip, csrc/conv_stem_wgrad.hip)."""
+import math
 import sys
 
 import torch
@@ -108,11 +109,105 @@ BWD_DATA_AS_FWD = True   # module switch (A/B: bench.py --conv-bwd-as-fwd 0)
 STEM_SPACE_TO_DEPTH = True   # module switch (A/B: bench.py --stem-s2d 0)
 
 
+FLIP_BATCHED = True      # module switch (A/B): all flipped filters of a step from ONE launch (mdt_filter_flip_transpose_batched)
+_WEIGHT_EPOCH = [0]      # bumped by weights_changed(): optimizers that update parameters without torch's version counter (training.FlatAdam)
+_FLIP = {}               # device -> _FlipCache
+
+
+def weights_changed():
+    """an optimizer has rewritten parameters through a raw kernel (training.FlatAdam._update): cached flipped filters are stale.  In-place
+    torch ops (torch.optim.*, load_state_dict, copy_) are seen through the tensors' own version counters."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+class _FlipCache(object):
+    """the flipped / transposed filters of every unit-stride convolution whose input gradient runs as a forward convolution: the weights
+    change once per step (the optimizer), the ~60 flips of a step's backward are therefore ONE launch over a device table of
+    {source, destination, shape} records -- issued by the first request of a backward, served from the persistent buffers for the rest.
+    A filter is registered at its first request (single launch that time); dead weights (their nets were deleted) are dropped and the
+    table rebuilt.  Nothing is rebuilt while a hipGraph is being captured (the table upload is a host copy): requests that would need
+    it fall back to the single-filter launch."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = {}          # (data_ptr, shape, cl) -> [weakref(w), out, version_seen]
+        self.table = None          # uint8 device tensor holding the records
+        self.order = []            # keys in table order
+        self.total = 0
+        self.dirty = True
+        self.epoch = -1            # _WEIGHT_EPOCH value the buffers were made for
+
+    def _rebuild(self):
+        import struct
+        self.entries = {k: e for k, e in self.entries.items() if e[0]() is not None and e[0]().data_ptr() == k[0]}
+        self.order = list(self.entries)
+        recs, first = [], 0
+        for k in self.order:
+            w = self.entries[k][0]()
+            out = self.entries[k][1]
+            cout, cin, taps = int(k[1][0]), int(k[1][1]), int(math.prod(k[1][2:]))
+            recs.append(struct.pack("<QQiiiiq", w.data_ptr(), out.data_ptr(), cout, cin, taps, int(k[2]), first))
+            first += cout * cin * taps
+        self.total = first
+        blob = b"".join(recs)
+        self.table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device) if blob else None
+        self.dirty = False
+
+    def get(self, w, mf):
+        import weakref
+        cl = 0 if mf == torch.contiguous_format else 1
+        key = (w.data_ptr(), tuple(w.shape), cl)
+        e = self.entries.get(key)
+        if e is not None and e[0]() is not w:
+            e = None                                        # the address was re-used by another tensor
+        if e is None:
+            if _lib.CAPTURING:
+                return None
+            out = torch.empty((int(w.shape[1]), int(w.shape[0])) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device, memory_format=mf)
+            _flip_single(w, out, cl)
+            self.entries[key] = [weakref.ref(w), out, w._version]
+            self.dirty = True
+            return out
+        if self.epoch == _WEIGHT_EPOCH[0] and e[2] == w._version and not self.dirty:
+            return e[1]
+        # stale: one launch refreshes EVERY registered filter
+        if self.dirty or any(en[0]() is None for en in self.entries.values()):
+            if _lib.CAPTURING:
+                return None
+            self._rebuild()
+            e = self.entries.get(key)
+            if e is None:
+                return self.get(w, mf)
+        if self.table is not None:
+            rc = _lib.lib().mdt_filter_flip_transpose_batched(self.table.data_ptr(), len(self.order), self.total, _lib.raw_stream())
+            if rc != 0:
+                _lib.check(rc, "mdt_filter_flip_transpose_batched")
+        for en in self.entries.values():
+            t = en[0]()
+            en[2] = t._version if t is not None else -1
+        self.epoch = _WEIGHT_EPOCH[0]
+        return e[1]
+
+
+def _flip_single(w, out, cl):
+    rc = _lib.lib().mdt_filter_flip_transpose(w.data_ptr(), out.data_ptr(), int(w.shape[0]), int(w.shape[1]), int(w.shape[2:].numel()), cl, _lib.raw_stream())
+    if rc != 0:
+        _lib.check(rc, "mdt_filter_flip_transpose")
+
+
 def flip_transpose_filter(w, mf):
-    """w [cout, cin, *k] -> [cin, cout, *k] with every spatial axis reversed, dense in memory format `mf`: one launch of
-    mdt_filter_flip_transpose when w is an fp32 GPU tensor dense in `mf`, torch ops otherwise"""
+    """w [cout, cin, *k] -> [cin, cout, *k] with every spatial axis reversed, dense in memory format `mf`: served from the per-step batched
+    launch (_FlipCache) for parameters, one launch of mdt_filter_flip_transpose for other fp32 GPU tensors dense in `mf`, torch ops otherwise.
+    The returned tensor of the cached path is a persistent buffer: valid until the weights change (read it within the step)."""
     nd = w.dim() - 2
     if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous(memory_format=mf) and _on_current_device(w):
+        if FLIP_BATCHED and isinstance(w, torch.nn.Parameter):
+            cache = _FLIP.get(w.device)
+            if cache is None:
+                cache = _FLIP[w.device] = _FlipCache(w.device)
+            out = cache.get(w, mf)
+            if out is not None:
+                return out
         cout, cin = int(w.shape[0]), int(w.shape[1])
         out = torch.empty((cin, cout) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device, memory_format=mf)
         rc = _lib.lib().mdt_filter_flip_transpose(w.data_ptr(), out.data_ptr(), cout, cin, int(w.shape[2:].numel()),
@@ -282,6 +377,10 @@ def _stride1_grads(x, w, padding, gy, need_x, need_w):
     return gx, gw
 
 
+BIAS_GRAD_IN_LAUNCH = True      # module switch (A/B): the bias gradient's second stage inside the backward epilogue's launch (mdt_bias_act_backward_ticket)
+_TICKET = {}                    # device -> int32[1], zero between launches
+
+
 def _bias_act_bwd(gy, y, relu, mf):
     """g = gy * (y > 0) (when relu) and the bias gradient (per-channel sum of g) in one pass (csrc/epilogue.hip), channels-last or contiguous"""
     if not gy.is_contiguous(memory_format=mf):
@@ -292,6 +391,18 @@ def _bias_act_bwd(gy, y, relu, mf):
     g = torch.empty_like(gy)
     gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
     wsb = (4096 * C * 4 + 256) if inner == 1 else L.mdt_bias_act_backward_workspace_bytes(n, C, inner)
+    if inner == 1 and BIAS_GRAD_IN_LAUNCH:
+        # one launch: the per-block partial rows are folded by the last block of the same launch (a ticket this module owns; every call of a
+        # device's backward runs on one stream, so launches sharing the ticket and the workspace are ordered)
+        tk = _TICKET.get(gy.device)
+        if tk is None:
+            tk = _TICKET[gy.device] = torch.zeros(1, dtype=torch.int32, device=gy.device)
+        ws = _workspace(wsb, gy.device)
+        rc = L.mdt_bias_act_backward_ticket(g.data_ptr(), gy.data_ptr(), y.data_ptr() if relu else None, gbias.data_ptr(), n, C, inner, 1 if relu else 0,
+                                            ws.data_ptr(), ws.numel(), tk.data_ptr(), _lib.raw_stream())
+        if rc != 0:
+            _lib.check(rc, "mdt_bias_act_backward_ticket")
+        return g, gbias
     ws = _workspace(wsb, gy.device)
     rc = L.mdt_bias_act_backward(g.data_ptr(), gy.data_ptr(), y.data_ptr() if relu else None, gbias.data_ptr(), n, C, inner, 1 if relu else 0,
                                  ws.data_ptr(), ws.numel(), _lib.raw_stream())

@@ -48,6 +48,36 @@ def test_bias_act_matches_torch(shape, channels_last, with_res, relu, cuda):
     assert torch.equal(gbf, gbf2) and torch.equal(gxf, gxf2)
 
 
+@pytest.mark.parametrize("shape", [(8, 36, 32, 32, 128), (8, 18, 64, 64, 32), (4, 288, 4, 4, 16), (1, 7, 33, 17, 5)])
+def test_bias_grad_second_stage_inside_the_launch(shape, cuda):
+    """mdt_bias_act_backward_ticket (round 6): the last block of the launch folds the per-block partial rows -- thousands of blocks spread over
+    the eight XCDs, whose L2s are not coherent: a missing release / acquire shows up as a stale partial row.  Against an fp64 sum, twenty
+    launches in a row bit-identical (the ticket is left at zero each time), equal to the two-launch form within summation-order rounding."""
+    g = torch.Generator(device=cuda).manual_seed(5)
+    gy = torch.randn(shape, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    y = torch.randn(shape, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    want = (gy.double() * (y > 0)).sum((0, 2, 3, 4))
+    scale = (gy.double().abs() * (y > 0)).sum((0, 2, 3, 4)) + 1.0
+    assert fe.BIAS_GRAD_IN_LAUNCH
+    first = None
+    for it in range(20):
+        gx, gb = fe._bias_act_bwd(gy, y, True, torch.channels_last_3d)
+        if it % 3 == 0:                                  # other traffic between launches: the partial rows must not survive in a cache
+            torch.randn(1 << 22, device=cuda).sum()
+        assert float(((gb.double() - want).abs() / scale).max()) <= 2e-6, it
+        if first is None:
+            first = gb.clone()
+            assert torch.equal(gx, gy * (y > 0))
+        assert torch.equal(gb, first), it
+    assert int(fe._TICKET[gy.device].item()) == 0
+    fe.BIAS_GRAD_IN_LAUNCH = False
+    try:
+        _, gb2 = fe._bias_act_bwd(gy, y, True, torch.channels_last_3d)
+    finally:
+        fe.BIAS_GRAD_IN_LAUNCH = True
+    assert float(((gb2.double() - first.double()).abs() / scale).max()) <= 2e-6
+
+
 def test_fused_modules_keep_reference_state_dict_layout(cuda):
     from medicaldetectiontoolkit_amd.utils.model_utils import NDConvGenerator
     conv = NDConvGenerator(3)
@@ -174,6 +204,59 @@ WGRAD_CASES = [
     (8, 18, 72, (32, 32, 128)),
     (8, 72, 18, (32, 32, 128)),
 ]
+
+
+def test_batched_filter_flips_follow_the_weights(cuda):
+    """_FlipCache (round 6): the flipped / transposed filters of all registered parameters from ONE launch per step.  Registered at first
+    sight; refreshed when a raw kernel rewrote the weights (weights_changed(), what training.FlatAdam calls) or a torch op did (version
+    counter); filters of deleted parameters are dropped from the table; results equal the torch expression."""
+    from medicaldetectiontoolkit_amd import _lib
+
+    def want(w, mf):
+        wt = w.detach().transpose(0, 1)
+        if w.shape[2:].numel() > 1:
+            wt = wt.flip(*range(2, w.dim()))
+        return wt.contiguous(memory_format=mf)
+    fe._FLIP.clear()
+    g = torch.Generator(device=cuda).manual_seed(3)
+    shapes = [(18, 18, 3, 3, 3), (36, 36, 3, 3, 3), (72, 18, 1, 1, 1), (36, 128, 3, 3, 3), (7, 5, 7, 7, 3)]
+    mfs = [torch.channels_last_3d, torch.channels_last_3d, torch.contiguous_format, torch.channels_last_3d, torch.contiguous_format]
+    ws = [torch.nn.Parameter(torch.randn(sh, device=cuda, generator=g).contiguous(memory_format=mf)) for sh, mf in zip(shapes, mfs)]
+    for w, mf in zip(ws, mfs):                       # first sight: registered, flipped one by one
+        assert torch.equal(fe.flip_transpose_filter(w, mf), want(w, mf))
+    _lib.count_calls(True)
+    try:
+        with torch.no_grad():
+            ws[1].mul_(2.0)                          # a torch op: seen through the version counter
+        outs = [fe.flip_transpose_filter(w, mf) for w, mf in zip(ws, mfs)]
+        for w, mf, o in zip(ws, mfs, outs):
+            assert torch.equal(o, want(w, mf))
+        c1 = dict(_lib.CALLS)
+        assert c1.get("mdt_filter_flip_transpose_batched", 0) == 1 and c1.get("mdt_filter_flip_transpose", 0) == 0, c1
+        ws[3].data.add_(1.0)                         # a raw update: .data does not bump the version of the parameter
+        fe.weights_changed()
+        outs = [fe.flip_transpose_filter(w, mf) for w, mf in zip(ws, mfs)]
+        for w, mf, o in zip(ws, mfs, outs):
+            assert torch.equal(o, want(w, mf))
+        c2 = dict(_lib.CALLS)
+        assert c2.get("mdt_filter_flip_transpose_batched", 0) == 2 and c2.get("mdt_filter_flip_transpose", 0) == 0, c2
+        # unchanged weights: served from the buffers, no launch at all
+        outs = [fe.flip_transpose_filter(w, mf) for w, mf in zip(ws, mfs)]
+        assert dict(_lib.CALLS) == c2
+        # a parameter dies: its record leaves the table at the next refresh
+        wdev = ws[0].device
+        del ws[0], outs
+        import gc
+        gc.collect()
+        fe.weights_changed()
+        for w, mf in zip(ws, mfs[1:]):
+            assert torch.equal(fe.flip_transpose_filter(w, mf), want(w, mf))
+        assert len(fe._FLIP[wdev].entries) == 4
+    finally:
+        _lib.count_calls(False)
+    # a non-parameter tensor keeps the single launch
+    t = torch.randn(6, 4, 3, 3, 3, device=cuda, generator=g)
+    assert torch.equal(fe.flip_transpose_filter(t, torch.contiguous_format), want(t, torch.contiguous_format))
 
 
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=[str(c) for c in WGRAD_CASES])
