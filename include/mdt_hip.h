@@ -501,6 +501,40 @@ int mdt_adam_flat_segments(float *param, const float *grad, float *exp_avg, floa
                            double beta1, double beta2, double eps, double weight_decay, double grad_div, void *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* Loss / target glue of the training step (csrc/glue.hip, round 6)           */
+/* ------------------------------------------------------------------------- */
+/* Each entry replaces a chain of small tensor operations of the reference's host code with one launch (two for mdt_rpn_sample), operation for
+ * operation in the same precision.  Selections break ties towards the lower index.  Replaces, at the call sites of models/mrcnn.py:
+ *   mdt_roi_levels            the level rule of pyramid_roi_align (reference models/mrcnn.py:394-409): rois [n, 2 dim + 1] (normalised box,
+ *                             batch index) -> boxes [n, 2 dim], batch_ix [n] (truncated), level [n] = clamp(round(4 + log2(sqrt(h w))), lo, hi) - lo
+ *                             (five_levels: h w > 0.65 -> level 5)
+ *   mdt_rpn_sample            compute_rpn_class_loss's sampling (reference :176-214 + utils/model_utils.py:566-571, 674-691): per batch element the
+ *                             n_pos_max best of {rand_pos[a] : match[a] > 0}, the SHEM pool = kpool best of {max fg soft-max prob : match[a] == -1},
+ *                             of whose first poolsize * max(pos_count, 1) entries the n_pos_max best by rand_pool[rank] are drawn; nvalid[j] =
+ *                             drawn && j < max(pos_count, 1); tgt_pos = max(match[pidx], 0).  MDT_ERR_UNSUPPORTED outside
+ *                             mdt_rpn_sample_supported (n_pos_max, kpool <= 128, A x k within the merge block's LDS)
+ *   mdt_anchor_delta_targets  utils/model_utils.py:575-617 on gathered rows, fp64 arithmetic, fp32 result [B, n, 2 dim]
+ *   mdt_detection_targets     detection_target_layer (reference :461-613) up to the mask crop: one block per batch element; outputs in the slot
+ *                             layout [P positives | Nn negatives] per element; pos_rois / box_ids feed the GT-mask RoIAlign. */
+int mdt_roi_levels(const float *rois, int n, int dim, int level_lo, int level_hi, int five_levels,
+                   float *boxes, int *batch_ix, int *level, void *stream);
+int mdt_rpn_sample_supported(int A, int n_pos_max, int kpool);
+size_t mdt_rpn_sample_workspace_bytes(int B, int A, int n_pos_max, int kpool);
+int mdt_rpn_sample(const int *match, const float *logits, int K, const float *rand_pos, const float *rand_pool,
+                   int B, int A, int n_pos_max, int poolsize, int kpool,
+                   long long *pidx, unsigned char *pvalid, long long *nidx, unsigned char *nvalid, long long *pos_count, long long *tgt_pos,
+                   void *workspace, size_t workspace_bytes, void *stream);
+int mdt_anchor_delta_targets(const double *anchors, const double *gt_boxes, const int *argmax, const long long *pidx, const unsigned char *pvalid,
+                             const double *std_dev, int B, int A, int G, int n, int dim, float *out, void *stream);
+int mdt_detection_targets_supported(int pc, int G, int P, int pool_max, int Nn);
+int mdt_detection_targets(const float *rois, int roi_stride, const float *scores, int n_classes, const double *gt_px, const float *scale,
+                          const long long *gt_cls, const unsigned char *gt_valid, const int *gt_gidx, const float *rand_pos, const float *rand_pool,
+                          const float *std_dev, int B, int pc, int G, int dim, int P, int pool_max, int Nn, int poolsize,
+                          float pos_thr, float neg_thr, float ratio_r,
+                          long long *sample_indices, unsigned char *valid, unsigned char *is_pos, long long *target_class_ids, float *target_deltas,
+                          float *pos_rois, int *box_ids, long long *counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

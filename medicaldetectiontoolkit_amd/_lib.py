@@ -71,6 +71,13 @@ _SIGNATURES = {
     "mdt_bias_act_backward_workspace_bytes": (c_size_t, [c_longlong, c_int, c_longlong]),
     "mdt_bias_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_size_t, c_void_p]),
     "mdt_bias_act_backward_ticket": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mdt_roi_levels": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdt_rpn_sample_supported": (c_int, [c_int, c_int, c_int]),
+    "mdt_rpn_sample_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mdt_rpn_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]),
+    "mdt_anchor_delta_targets": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_void_p]),
+    "mdt_detection_targets_supported": (c_int, [c_int] * 5),
+    "mdt_detection_targets": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 8 + [c_int] * 8 + [c_float] * 3 + [c_void_p] * 9),
     "mdt_nms_mask_3d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdt_nms_mask_2d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdt_nms_mask_full_3d": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p]),

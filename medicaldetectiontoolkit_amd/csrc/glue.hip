@@ -1,0 +1,496 @@
+// glue.hip -- the loss / target glue of the training step as a handful of launches (gfx950, round 6).
+//
+// The reference runs this part as Python loops over batch elements with dozens of small tensor ops each (models/mrcnn.py:176-290 RPN
+// losses incl. SHEM, :373-457 pyramid level rule, :461-613 detection target layer; utils/model_utils.py:114-143, 575-617 box targets).
+// Rounds 2-5 of this repo made them fixed-size, batched torch expressions (no host sync) -- still ~500 elementwise / top-k launches per
+// step, each 2-10 us of GPU time behind 5-20 us of launch gap, and most of the step's host time.  Here the same arithmetic, operation
+// for operation (fp32 / fp64 exactly where the torch expressions use them, -ffp-contract=off), in one launch per logical stage:
+//
+//   mdt_roi_levels                 pyramid level of every RoI (mrcnn.py:403) + the box / batch-index / level arrays RoIAlign reads
+//   mdt_rpn_sample                 positive sub-sampling + SHEM negatives of the RPN loss over all B x A anchors (two launches: per-chunk
+//                                  top-k candidates, then one block per batch element merges and draws)
+//   mdt_anchor_delta_targets       fp64 box-regression targets of the sampled positive anchors (gather anchors / assigned GT + deltas)
+//   mdt_detection_targets          RoI <-> GT overlaps, positive / negative sampling (SHEM), class / box targets: one block per element
+//
+// All of it is index / selection work on a few thousand values (the 3.6 M anchor keys are read once, coalesced): latency-bound, no MFMA,
+// no LDS tiling beyond the selection buffers.  Ties in a selection are broken towards the LOWER index (torch.topk leaves them unspecified).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "mdt_hip.h"
+
+namespace {
+
+constexpr int GL_THREADS = 256;
+constexpr int GL_MAX_K = 128;              // largest selection size of the in-kernel top-k (rounds of a block-wide arg-max)
+constexpr int GL_MAX_CAND = 12288;         // candidates one merge block holds in LDS (48 KB)
+constexpr int GL_MAX_CHUNK = 15360;        // anchors one stage-1 block holds in LDS (60 KB)
+
+inline int gl_check()
+{
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MDT_OK;
+    if (getenv("MDT_VERBOSE")) fprintf(stderr, "libmdt_hip: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
+    return MDT_ERR_LAUNCH_FAILED;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- RoI levels
+__global__ __launch_bounds__(GL_THREADS) void roi_levels_kernel(const float *__restrict__ rois, int n, int dim, int lo, int hi, int five,
+                                                                float *__restrict__ boxes, int *__restrict__ batch_ix, int *__restrict__ level)
+{
+    const int i = blockIdx.x * GL_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int w = 2 * dim + 1;
+    const float *r = rois + (long long)i * w;
+    float b[6];
+    for (int k = 0; k < 2 * dim; ++k) { b[k] = r[k]; boxes[(long long)i * 2 * dim + k] = b[k]; }
+    batch_ix[i] = (int)r[2 * dim];                         // .to(torch.int32): truncation
+    const float h = b[2] - b[0], wd = b[3] - b[1];
+    const float area = h * wd;
+    // (4 + log(sqrt(h * w)) / log(2)).round().int().clamp(lo, hi)           (models/mrcnn.py pyramid_roi_align, reference :403)
+    const float v = 4.0f + logf(sqrtf(area)) / logf(2.0f);
+    int lv = (int)rintf(v);
+    lv = lv < lo ? lo : (lv > hi ? hi : lv);
+    if (five && area > 0.65f) lv = 5;
+    level[i] = lv - lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- block-wide selection
+// One round: every thread scans its strided slots of s[0 .. n) for the largest value (lower slot wins ties), the block reduces, the winner
+// is removed (marked -3).  Returns the winner through s_red; all threads leave with the same (value, slot).
+struct Best { float v; int i; };
+
+__device__ __forceinline__ Best better(Best a, Best b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+
+__device__ __forceinline__ Best block_argmax(const float *s, int n, float *s_red_v, int *s_red_i)
+{
+    const int t = threadIdx.x;
+    Best m{-4.0f, 0x7fffffff};
+    for (int j = t; j < n; j += GL_THREADS) {
+        const float v = s[j];
+        if (v > m.v) { m.v = v; m.i = j; }                   // ascending j: the first maximum stays
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_xor(m.v, off, 64);
+        o.i = __shfl_xor(m.i, off, 64);
+        m = better(m, o);
+    }
+    const int wave = t >> 6;
+    if ((t & 63) == 0) { s_red_v[wave] = m.v; s_red_i[wave] = m.i; }
+    __syncthreads();
+    Best r{s_red_v[0], s_red_i[0]};
+#pragma unroll
+    for (int wv = 1; wv < GL_THREADS / 64; ++wv) r = better(r, Best{s_red_v[wv], s_red_i[wv]});
+    __syncthreads();
+    return r;
+}
+
+// the k best of s[0 .. n), best first, into (out_v, out_i) through `emit(rank, value, slot)`; values < 0 count as "none": the remaining ranks
+// get (-1, slot 0).  s is consumed.
+template <typename Emit>
+__device__ __forceinline__ void block_select(float *s, int n, int k, float *s_red_v, int *s_red_i, Emit emit)
+{
+    int r = 0;
+    for (; r < k; ++r) {
+        const Best b = block_argmax(s, n, s_red_v, s_red_i);
+        if (!(b.v >= 0.0f)) break;
+        if (threadIdx.x == 0) { emit(r, b.v, b.i); s[b.i] = -3.0f; }
+        __syncthreads();
+    }
+    for (int q = r + threadIdx.x; q < k; q += GL_THREADS) emit(q, -1.0f, -1);
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------- RPN sampling
+struct RpnSampleParams {
+    const int *match;            // [B, A]  > 0 positive (class id), -1 negative, 0 neutral
+    const float *logits;         // [B, A, K]
+    const float *rand_pos;       // [B, A] uniform keys of the positive sub-sampling
+    const float *rand_pool;      // [B, kpool] uniform keys of the draw from the SHEM pool
+    int B, A, K, chunk, nchunk, kpos, kpool, poolsize;
+    float *cpv; int *cpi;        // stage-1 candidates [B, nchunk, kpos]
+    float *cnv; int *cni;        //                    [B, nchunk, kpool]
+    long long *pidx; unsigned char *pvalid; long long *nidx; unsigned char *nvalid; long long *pos_count; long long *tgt_pos;
+};
+
+__global__ __launch_bounds__(GL_THREADS) void rpn_sample_stage1_kernel(RpnSampleParams p)
+{
+    extern __shared__ float s[];                    // [chunk] keys
+    __shared__ float s_red_v[GL_THREADS / 64];
+    __shared__ int s_red_i[GL_THREADS / 64];
+    const int b = blockIdx.y, c = blockIdx.x, t = threadIdx.x;
+    const long long a0 = (long long)c * p.chunk;
+    const int n = (int)((a0 + p.chunk <= p.A) ? p.chunk : (p.A - a0));
+    const int *mrow = p.match + (long long)b * p.A + a0;
+    // ---- positives: key = match > 0 ? rand : -1
+    for (int j = t; j < n; j += GL_THREADS) s[j] = (mrow[j] > 0) ? p.rand_pos[(long long)b * p.A + a0 + j] : -1.0f;
+    __syncthreads();
+    {
+        float *ov = p.cpv + ((long long)b * p.nchunk + c) * p.kpos;
+        int *oi = p.cpi + ((long long)b * p.nchunk + c) * p.kpos;
+        block_select(s, n, p.kpos, s_red_v, s_red_i, [&](int r, float v, int slot) { ov[r] = v; oi[r] = slot < 0 ? 0 : (int)(a0 + slot); });
+    }
+    // ---- negatives: key = match == -1 ? max foreground soft-max probability : -1     (F.softmax(logits, 2)[:, :, 1:].max(2))
+    const int K = p.K;
+    for (int j = t; j < n; j += GL_THREADS) {
+        float key = -1.0f;
+        if (mrow[j] == -1) {
+            const float *l = p.logits + ((long long)b * p.A + a0 + j) * K;
+            float m = l[0];
+            for (int k = 1; k < K; ++k) m = fmaxf(m, l[k]);
+            float sum = 0.0f;
+            for (int k = 0; k < K; ++k) sum = sum + expf(l[k] - m);
+            float fg = -1.0f;
+            for (int k = 1; k < K; ++k) fg = fmaxf(fg, expf(l[k] - m) / sum);
+            key = fg;
+        }
+        s[j] = key;
+    }
+    __syncthreads();
+    {
+        float *ov = p.cnv + ((long long)b * p.nchunk + c) * p.kpool;
+        int *oi = p.cni + ((long long)b * p.nchunk + c) * p.kpool;
+        block_select(s, n, p.kpool, s_red_v, s_red_i, [&](int r, float v, int slot) { ov[r] = v; oi[r] = slot < 0 ? 0 : (int)(a0 + slot); });
+    }
+}
+
+__global__ __launch_bounds__(GL_THREADS) void rpn_sample_stage2_kernel(RpnSampleParams p)
+{
+    extern __shared__ float s[];                    // [max(nchunk * kpool, nchunk * kpos)] candidate values
+    __shared__ float s_red_v[GL_THREADS / 64];
+    __shared__ int s_red_i[GL_THREADS / 64];
+    __shared__ float s_pool_v[GL_MAX_K];
+    __shared__ int s_pool_i[GL_MAX_K];
+    __shared__ float s_key2[GL_MAX_K];
+    __shared__ int s_count;
+    const int b = blockIdx.x, t = threadIdx.x;
+    // ---- positives
+    const int ncp = p.nchunk * p.kpos;
+    for (int j = t; j < ncp; j += GL_THREADS) s[j] = p.cpv[(long long)b * ncp + j];
+    if (t == 0) s_count = 0;
+    __syncthreads();
+    block_select(s, ncp, p.kpos, s_red_v, s_red_i, [&](int r, float v, int slot) {
+        const long long a = slot < 0 ? 0 : (long long)p.cpi[(long long)b * ncp + slot];
+        p.pidx[(long long)b * p.kpos + r] = a;
+        p.pvalid[(long long)b * p.kpos + r] = v >= 0.0f ? 1 : 0;
+        const int mt = p.match[(long long)b * p.A + a];
+        p.tgt_pos[(long long)b * p.kpos + r] = mt > 0 ? mt : 0;                 // gather(rpn_match, pidx).clamp(min=0)
+        if (v >= 0.0f) atomicAdd(&s_count, 1);
+    });
+    const int pos_count = s_count;
+    if (t == 0) p.pos_count[b] = pos_count;
+    const int neg_count = pos_count > 1 ? pos_count : 1;
+    // ---- SHEM pool: the kpool best negatives, best first
+    const int ncn = p.nchunk * p.kpool;
+    for (int j = t; j < ncn; j += GL_THREADS) s[j] = p.cnv[(long long)b * ncn + j];
+    __syncthreads();
+    block_select(s, ncn, p.kpool, s_red_v, s_red_i, [&](int r, float v, int slot) {
+        s_pool_v[r] = v;
+        s_pool_i[r] = slot < 0 ? 0 : p.cni[(long long)b * ncn + slot];
+    });
+    // ---- draw: key2[rank] = in_pool ? rand : -1, the kpos best of them
+    for (int r = t; r < p.kpool; r += GL_THREADS) {
+        const bool in_pool = (s_pool_v[r] >= 0.0f) && ((long long)r < (long long)p.poolsize * neg_count);
+        s_key2[r] = in_pool ? p.rand_pool[(long long)b * p.kpool + r] : -1.0f;
+    }
+    __syncthreads();
+    block_select(s_key2, p.kpool, p.kpos, s_red_v, s_red_i, [&](int j, float v, int slot) {
+        p.nidx[(long long)b * p.kpos + j] = (long long)s_pool_i[slot < 0 ? 0 : slot];
+        p.nvalid[(long long)b * p.kpos + j] = (v >= 0.0f && j < neg_count) ? 1 : 0;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------- anchor delta targets
+// utils/model_utils.py anchor_delta_targets on gathered rows (reference :575-617), fp64: out[b, j] = float(deltas(anchor[pidx], gt[b, argmax[b, pidx]]) / std)
+__global__ __launch_bounds__(GL_THREADS) void anchor_delta_targets_kernel(const double *__restrict__ anchors, const double *__restrict__ gt,
+                                                                          const int *__restrict__ argmax, const long long *__restrict__ pidx,
+                                                                          const unsigned char *__restrict__ pvalid, const double *__restrict__ std_dev,
+                                                                          int B, int A, int G, int n, int dim, float *__restrict__ out)
+{
+    const int i = blockIdx.x * GL_THREADS + threadIdx.x;
+    if (i >= B * n) return;
+    const int b = i / n;
+    const long long a = pidx[i];
+    const double *an = anchors + a * 2 * dim;
+    int g = argmax[(long long)b * A + a];
+    g = g < 0 ? 0 : (g >= G ? G - 1 : g);
+    const double *gb = pvalid[i] ? gt + ((long long)b * G + g) * 2 * dim : an;      // torch.where(pv, g_pos, a_pos): invalid rows stay finite
+    const double a_h = an[2] - an[0], a_w = an[3] - an[1];
+    const double g_h = gb[2] - gb[0], g_w = gb[3] - gb[1];
+    const double a_cy = an[0] + 0.5 * a_h, a_cx = an[1] + 0.5 * a_w;
+    const double g_cy = gb[0] + 0.5 * g_h, g_cx = gb[1] + 0.5 * g_w;
+    float *o = out + (long long)i * 2 * dim;
+    if (dim == 3) {
+        const double a_d = an[5] - an[4], g_d = gb[5] - gb[4];
+        const double a_cz = an[4] + 0.5 * a_d, g_cz = gb[4] + 0.5 * g_d;
+        o[0] = (float)(((g_cy - a_cy) / a_h) / std_dev[0]);
+        o[1] = (float)(((g_cx - a_cx) / a_w) / std_dev[1]);
+        o[2] = (float)(((g_cz - a_cz) / a_d) / std_dev[2]);
+        o[3] = (float)(log(g_h / a_h) / std_dev[3]);
+        o[4] = (float)(log(g_w / a_w) / std_dev[4]);
+        o[5] = (float)(log(g_d / a_d) / std_dev[5]);
+    } else {
+        o[0] = (float)(((g_cy - a_cy) / a_h) / std_dev[0]);
+        o[1] = (float)(((g_cx - a_cx) / a_w) / std_dev[1]);
+        o[2] = (float)(log(g_h / a_h) / std_dev[2]);
+        o[3] = (float)(log(g_w / a_w) / std_dev[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- detection targets
+// models/mrcnn.py detection_target_layer (reference :461-613) for one batch element per block: RoI <-> GT IoU (fp32, the operation order of
+// utils/model_utils.bbox_overlaps), positive / negative flags, random positive subset, SHEM negatives, class / box targets of the sampled
+// RoIs in the fixed slot layout [P positives | Nn negatives] per element.
+struct DetTargetParams {
+    const float *rois; int roi_stride;        // [B * pc, roi_stride] normalised boxes (+ batch index column, unread)
+    const float *scores; int n_classes;       // [B * pc, n_classes] soft-max class scores
+    const double *gt_px;                      // [B, G, 2 dim] pixel boxes
+    const float *scale;                       // [2 dim]: gt box / scale = normalised
+    const long long *gt_cls;                  // [B, G]
+    const unsigned char *gt_valid;            // [B, G]
+    const int *gt_gidx;                       // [B, G]
+    const float *rand_pos;                    // [B, pc]
+    const float *rand_pool;                   // [B, pool_max]
+    const float *std_dev;                     // [2 dim]
+    int B, pc, G, dim, P, pool_max, Nn, poolsize;
+    float pos_thr, neg_thr, ratio_r;
+    long long *sample_indices; unsigned char *valid; unsigned char *is_pos; long long *target_class_ids; float *target_deltas;   // [B * (P + Nn)] ...
+    float *pos_rois; int *box_ids;            // [B * P, 2 dim], [B * P]
+    long long *counts;                        // [B, 2]: positives, negatives kept
+};
+
+__device__ __forceinline__ float iou_f32(const float *a, const float *b, int dim)
+{
+    const float y1 = fmaxf(a[0], b[0]), x1 = fmaxf(a[1], b[1]);
+    const float y2 = fminf(a[2], b[2]), x2 = fminf(a[3], b[3]);
+    float inter = fmaxf(x2 - x1, 0.0f) * fmaxf(y2 - y1, 0.0f);
+    float a1 = (a[2] - a[0]) * (a[3] - a[1]);
+    float a2 = (b[2] - b[0]) * (b[3] - b[1]);
+    if (dim == 3) {
+        const float z1 = fmaxf(a[4], b[4]), z2 = fminf(a[5], b[5]);
+        inter = inter * fmaxf(z2 - z1, 0.0f);
+        a1 = a1 * (a[5] - a[4]);
+        a2 = a2 * (b[5] - b[4]);
+    }
+    return inter / (a1 + a2 - inter);
+}
+
+__global__ __launch_bounds__(GL_THREADS) void detection_targets_kernel(DetTargetParams p)
+{
+    extern __shared__ float s[];                       // [pc] keys | [pc] fg scores | [pc] (int) assignment | [pc] (uchar-as-float) negative flag
+    __shared__ float s_red_v[GL_THREADS / 64];
+    __shared__ int s_red_i[GL_THREADS / 64];
+    __shared__ float s_gt[64 * 6];
+    __shared__ float s_pool_v[GL_MAX_K];
+    __shared__ int s_pool_i[GL_MAX_K];
+    __shared__ float s_key2[GL_MAX_K];
+    __shared__ int s_pidx[GL_MAX_K];
+    __shared__ unsigned char s_pvalid[GL_MAX_K];
+    __shared__ int s_count, s_has_gt;
+    const int b = blockIdx.x, t = threadIdx.x, dim = p.dim, pc = p.pc, G = p.G, w = 2 * dim;
+    float *s_key = s, *s_fg = s + pc;
+    int *s_assign = reinterpret_cast<int *>(s + 2 * pc);
+    float *s_neg = s + 3 * pc;
+    if (t == 0) { s_count = 0; s_has_gt = 0; }
+    __syncthreads();
+    for (int j = t; j < G * w; j += GL_THREADS) s_gt[j] = (float)p.gt_px[(long long)b * G * w + j] / p.scale[j % w];      // g.px.float() / scale
+    for (int g = t; g < G; g += GL_THREADS) if (p.gt_valid[(long long)b * G + g]) atomicOr(&s_has_gt, 1);
+    __syncthreads();
+    const int has_gt = s_has_gt;
+    for (int i = t; i < pc; i += GL_THREADS) {
+        const float *r = p.rois + ((long long)b * pc + i) * p.roi_stride;
+        float box[6];
+        for (int k = 0; k < w; ++k) box[k] = r[k];
+        float best = -__builtin_inff();
+        int arg = 0;
+        for (int g = 0; g < G; ++g) {
+            const float ov = p.gt_valid[(long long)b * G + g] ? iou_f32(box, s_gt + g * w, dim) : -1.0f;
+            if (ov > best || (ov != ov && best == best)) { best = ov; arg = g; }      // first maximum; NaN propagates like torch.max
+        }
+        const bool positive = (best >= p.pos_thr) && has_gt;
+        const bool negative = has_gt ? (best < p.neg_thr) : true;
+        s_assign[i] = arg;
+        s_key[i] = positive ? p.rand_pos[(long long)b * pc + i] : -1.0f;
+        const float *sc = p.scores + ((long long)b * pc + i) * p.n_classes;
+        float fg = sc[1];
+        for (int k = 2; k < p.n_classes; ++k) fg = fmaxf(fg, sc[k]);
+        s_fg[i] = fg;
+        s_neg[i] = negative ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    // ---- positives: random subset of <= P
+    block_select(s_key, pc, p.P, s_red_v, s_red_i, [&](int r, float v, int slot) {
+        s_pidx[r] = slot < 0 ? 0 : slot;
+        s_pvalid[r] = v >= 0.0f ? 1 : 0;
+        if (v >= 0.0f) atomicAdd(&s_count, 1);
+    });
+    const int pos_count = s_count;
+    long long neg_count = (long long)(p.ratio_r * (float)pos_count - (float)pos_count);          // (r * pos_count.float() - pos_count.float()).long()
+    if (neg_count < 1) neg_count = 1;
+    // ---- SHEM: pool = the pool_max best negatives by foreground score, `neg_count` random ones of its first poolsize * neg_count
+    for (int i = t; i < pc; i += GL_THREADS) s_key[i] = s_neg[i] != 0.0f ? s_fg[i] : -1.0f;
+    __syncthreads();
+    block_select(s_key, pc, p.pool_max, s_red_v, s_red_i, [&](int r, float v, int slot) { s_pool_v[r] = v; s_pool_i[r] = slot < 0 ? 0 : slot; });
+    for (int r = t; r < p.pool_max; r += GL_THREADS) {
+        const bool in_pool = (s_pool_v[r] >= 0.0f) && ((long long)r < (long long)p.poolsize * neg_count);
+        s_key2[r] = in_pool ? p.rand_pool[(long long)b * p.pool_max + r] : -1.0f;
+    }
+    __syncthreads();
+    const int S = p.P + p.Nn;
+    const long long base = (long long)b * pc;
+    block_select(s_key2, p.pool_max, p.Nn, s_red_v, s_red_i, [&](int j, float v, int slot) {
+        const long long o = (long long)b * S + p.P + j;
+        const bool ok = (v >= 0.0f) && (j < neg_count);
+        p.sample_indices[o] = base + s_pool_i[slot < 0 ? 0 : slot];
+        p.valid[o] = ok ? 1 : 0;
+        p.is_pos[o] = 0;
+        p.target_class_ids[o] = 0;
+        for (int k = 0; k < w; ++k) p.target_deltas[o * w + k] = 0.0f;
+    });
+    if (t == 0 && p.counts) { p.counts[2 * b] = pos_count; p.counts[2 * b + 1] = neg_count; }
+    // ---- targets of the positive slots
+    for (int r = t; r < p.P; r += GL_THREADS) {
+        const long long o = (long long)b * S + r;
+        const int i = s_pidx[r];
+        const bool pv = s_pvalid[r] != 0;
+        const float *rr = p.rois + (base + i) * p.roi_stride;
+        const int g = s_assign[i];
+        float box[6], gb[6];
+        for (int k = 0; k < w; ++k) { box[k] = rr[k]; p.pos_rois[((long long)b * p.P + r) * w + k] = box[k]; }
+        p.box_ids[(long long)b * p.P + r] = pv ? p.gt_gidx[(long long)b * G + g] : -1;
+        p.sample_indices[o] = base + i;
+        p.valid[o] = pv ? 1 : 0;
+        p.is_pos[o] = pv ? 1 : 0;
+        p.target_class_ids[o] = pv ? p.gt_cls[(long long)b * G + g] : 0;
+        if (!pv) { box[0] = 0.f; box[1] = 0.f; box[2] = 1.f; box[3] = 1.f; box[4] = 0.f; box[5] = 1.f; }      // keeps log() finite
+        for (int k = 0; k < w; ++k) gb[k] = pv ? s_gt[g * w + k] : box[k];
+        // utils/model_utils.box_refinement (reference :114-143), fp32
+        const float h = box[2] - box[0], wd = box[3] - box[1];
+        const float cy = box[0] + 0.5f * h, cx = box[1] + 0.5f * wd;
+        const float gh = gb[2] - gb[0], gw = gb[3] - gb[1];
+        const float gcy = gb[0] + 0.5f * gh, gcx = gb[1] + 0.5f * gw;
+        float d[6];
+        if (dim == 3) {
+            const float dp = box[5] - box[4], cz = box[4] + 0.5f * dp;
+            const float gd = gb[5] - gb[4], gcz = gb[4] + 0.5f * gd;
+            d[0] = (gcy - cy) / h; d[1] = (gcx - cx) / wd; d[2] = (gcz - cz) / dp;
+            d[3] = logf(gh / h); d[4] = logf(gw / wd); d[5] = logf(gd / dp);
+        } else {
+            d[0] = (gcy - cy) / h; d[1] = (gcx - cx) / wd; d[2] = logf(gh / h); d[3] = logf(gw / wd);
+        }
+        const float m = pv ? 1.0f : 0.0f;
+        for (int k = 0; k < w; ++k) p.target_deltas[o * w + k] = (d[k] / p.std_dev[k]) * m;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdt_roi_levels(const float *rois, int n, int dim, int level_lo, int level_hi, int five_levels,
+                   float *boxes, int *batch_ix, int *level, void *stream)
+{
+    if (n < 0 || (dim != 2 && dim != 3) || level_hi < level_lo) return MDT_ERR_INVALID_ARGUMENT;
+    if (n == 0) return MDT_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(roi_levels_kernel, dim3((n + GL_THREADS - 1) / GL_THREADS), dim3(GL_THREADS), 0, (hipStream_t)stream,
+                       rois, n, dim, level_lo, level_hi, five_levels, boxes, batch_ix, level);
+    return gl_check();
+}
+
+static int rpn_sample_plan(int A, int kpos, int kpool, int *chunk, int *nchunk)
+{
+    if (A <= 0 || kpos < 1 || kpool < 1 || kpos > GL_MAX_K || kpool > GL_MAX_K || kpool > A || kpos > A) return 0;
+    const int kmax = kpos > kpool ? kpos : kpool;
+    long long c = 4096;
+    const long long need = ((long long)A * kmax + GL_MAX_CAND - 1) / GL_MAX_CAND;          // nchunk * kmax <= GL_MAX_CAND
+    if (need > c) c = ((need + GL_THREADS - 1) / GL_THREADS) * GL_THREADS;
+    if (c > GL_MAX_CHUNK) return 0;
+    *chunk = (int)c;
+    *nchunk = (int)((A + c - 1) / c);
+    if ((long long)*nchunk * kmax > GL_MAX_CAND) return 0;
+    return 1;
+}
+
+int mdt_rpn_sample_supported(int A, int n_pos_max, int kpool)
+{
+    int c, n;
+    return rpn_sample_plan(A, n_pos_max, kpool, &c, &n);
+}
+
+size_t mdt_rpn_sample_workspace_bytes(int B, int A, int n_pos_max, int kpool)
+{
+    int c, n;
+    if (B <= 0 || !rpn_sample_plan(A, n_pos_max, kpool, &c, &n)) return 256;
+    return (size_t)B * n * ((size_t)n_pos_max + kpool) * 8 + 256;
+}
+
+int mdt_rpn_sample(const int *match, const float *logits, int K, const float *rand_pos, const float *rand_pool,
+                   int B, int A, int n_pos_max, int poolsize, int kpool,
+                   long long *pidx, unsigned char *pvalid, long long *nidx, unsigned char *nvalid, long long *pos_count, long long *tgt_pos,
+                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (B <= 0 || K < 2 || poolsize < 1) return MDT_ERR_INVALID_ARGUMENT;
+    RpnSampleParams p;
+    if (!rpn_sample_plan(A, n_pos_max, kpool, &p.chunk, &p.nchunk)) return MDT_ERR_UNSUPPORTED;
+    if (workspace == nullptr || workspace_bytes < mdt_rpn_sample_workspace_bytes(B, A, n_pos_max, kpool)) return MDT_ERR_WORKSPACE_TOO_SMALL;
+    p.match = match; p.logits = logits; p.rand_pos = rand_pos; p.rand_pool = rand_pool;
+    p.B = B; p.A = A; p.K = K; p.kpos = n_pos_max; p.kpool = kpool; p.poolsize = poolsize;
+    char *w = reinterpret_cast<char *>(workspace);
+    const size_t np = (size_t)B * p.nchunk * n_pos_max, nn = (size_t)B * p.nchunk * kpool;
+    p.cpv = reinterpret_cast<float *>(w); w += np * 4;
+    p.cpi = reinterpret_cast<int *>(w); w += np * 4;
+    p.cnv = reinterpret_cast<float *>(w); w += nn * 4;
+    p.cni = reinterpret_cast<int *>(w);
+    p.pidx = pidx; p.pvalid = pvalid; p.nidx = nidx; p.nvalid = nvalid; p.pos_count = pos_count; p.tgt_pos = tgt_pos;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rpn_sample_stage1_kernel, dim3(p.nchunk, B), dim3(GL_THREADS), (size_t)p.chunk * sizeof(float), (hipStream_t)stream, p);
+    if (gl_check() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
+    const int kmax = n_pos_max > kpool ? n_pos_max : kpool;
+    hipLaunchKernelGGL(rpn_sample_stage2_kernel, dim3(B), dim3(GL_THREADS), (size_t)p.nchunk * kmax * sizeof(float), (hipStream_t)stream, p);
+    return gl_check();
+}
+
+int mdt_anchor_delta_targets(const double *anchors, const double *gt_boxes, const int *argmax, const long long *pidx, const unsigned char *pvalid,
+                             const double *std_dev, int B, int A, int G, int n, int dim, float *out, void *stream)
+{
+    if (B < 0 || A <= 0 || G <= 0 || n < 0 || (dim != 2 && dim != 3)) return MDT_ERR_INVALID_ARGUMENT;
+    if (B * n == 0) return MDT_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(anchor_delta_targets_kernel, dim3((B * n + GL_THREADS - 1) / GL_THREADS), dim3(GL_THREADS), 0, (hipStream_t)stream,
+                       anchors, gt_boxes, argmax, pidx, pvalid, std_dev, B, A, G, n, dim, out);
+    return gl_check();
+}
+
+int mdt_detection_targets_supported(int pc, int G, int P, int pool_max, int Nn)
+{
+    return (pc >= 1 && pc <= 3072 && G >= 1 && G <= 64 && P >= 1 && P <= GL_MAX_K && pool_max >= 1 && pool_max <= GL_MAX_K && Nn >= 1 && Nn <= pool_max &&
+            P <= pc && pool_max <= pc) ? 1 : 0;
+}
+
+int mdt_detection_targets(const float *rois, int roi_stride, const float *scores, int n_classes, const double *gt_px, const float *scale,
+                          const long long *gt_cls, const unsigned char *gt_valid, const int *gt_gidx, const float *rand_pos, const float *rand_pool,
+                          const float *std_dev, int B, int pc, int G, int dim, int P, int pool_max, int Nn, int poolsize,
+                          float pos_thr, float neg_thr, float ratio_r,
+                          long long *sample_indices, unsigned char *valid, unsigned char *is_pos, long long *target_class_ids, float *target_deltas,
+                          float *pos_rois, int *box_ids, long long *counts, void *stream)
+{
+    if (B < 0 || (dim != 2 && dim != 3) || n_classes < 2 || roi_stride < 2 * dim || poolsize < 1) return MDT_ERR_INVALID_ARGUMENT;
+    if (!mdt_detection_targets_supported(pc, G, P, pool_max, Nn)) return MDT_ERR_UNSUPPORTED;
+    if (B == 0) return MDT_OK;
+    DetTargetParams p;
+    p.rois = rois; p.roi_stride = roi_stride; p.scores = scores; p.n_classes = n_classes; p.gt_px = gt_px; p.scale = scale; p.gt_cls = gt_cls;
+    p.gt_valid = gt_valid; p.gt_gidx = gt_gidx; p.rand_pos = rand_pos; p.rand_pool = rand_pool; p.std_dev = std_dev;
+    p.B = B; p.pc = pc; p.G = G; p.dim = dim; p.P = P; p.pool_max = pool_max; p.Nn = Nn; p.poolsize = poolsize;
+    p.pos_thr = pos_thr; p.neg_thr = neg_thr; p.ratio_r = ratio_r;
+    p.sample_indices = sample_indices; p.valid = valid; p.is_pos = is_pos; p.target_class_ids = target_class_ids; p.target_deltas = target_deltas;
+    p.pos_rois = pos_rois; p.box_ids = box_ids; p.counts = counts;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(detection_targets_kernel, dim3(B), dim3(GL_THREADS), (size_t)4 * pc * sizeof(float), (hipStream_t)stream, p);
+    return gl_check();
+}
+
+}  // extern "C"

@@ -34,6 +34,8 @@ from . import backbone as backbone_module
 ############################################################
 HEAD_AS_LINEAR = True    # module switch (A/B: bench.py --head-as-linear 0): classifier-head convolutions as matrix products
 MERGE_RPN_HEADS = True   # module switch (A/B: bench.py --merge-rpn-heads 0): conv_class and conv_bbox of the RPN as ONE 1x1 convolution
+FUSED_GLUE = True        # module switch (A/B: bench.py --fused-glue 0): level rule, RPN sampling, box targets and the detection target layer as single
+                         # launches of csrc/glue.hip instead of chains of small tensor operations (same arithmetic, same random keys)
 SPARSE_RPN_LOSS = True   # module switch (A/B: bench.py --sparse-rpn-loss 0): RPN losses differentiate through the SAMPLED anchors only
 
 
@@ -306,6 +308,16 @@ def pyramid_roi_align(feature_maps, rois, pool_size, pyramid_levels, dim):
     Level rule :403 (h*w of the normalised box only).  All levels are pooled by ONE kernel launch (and one backward
     launch): every RoI reads its own level's map and writes its own output row, so there is no per-level loop, no
     nonzero()/gather/sort-back and no host sync."""
+    if FUSED_GLUE and rois.is_cuda and rois.dtype == torch.float32 and rois.dim() == 2 and rois.shape[1] == 2 * dim + 1:
+        r = rois.detach().contiguous()
+        n = int(r.shape[0])
+        boxes = torch.empty((n, 2 * dim), dtype=torch.float32, device=r.device)
+        ints = torch.empty((2, n), dtype=torch.int32, device=r.device)
+        with torch.cuda.device(r.device):
+            rc = _lib.lib().mdt_roi_levels(_lib.ptr(r), n, dim, int(pyramid_levels[0]), int(pyramid_levels[-1]), 1 if len(pyramid_levels) == 5 else 0,
+                                           _lib.ptr(boxes), _lib.ptr(ints[0]), _lib.ptr(ints[1]), _lib.current_stream_ptr())
+        _lib.check(rc, "mdt_roi_levels")
+        return pyramid_crop_and_resize(list(feature_maps), boxes, ints[0], ints[1], pool_size)
     boxes = rois[:, :dim * 2].detach()
     batch_ixs = rois[:, dim * 2]
     h = boxes[:, 2] - boxes[:, 0]
@@ -386,6 +398,48 @@ def _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev, gt_dev=None):
     return g.px.float() / scale, g.cls, g.valid, g.gidx, g.counts
 
 
+def _detection_targets_fused(batch_proposals, scores, batch_gt_masks, cf, B, pc, P, pool_max, Nn, generator, g):
+    """detection_target_layer in ONE launch (mdt_detection_targets: overlaps, sampling, class / box targets) + the GT-mask crop; the same two
+    torch.rand draws as the tensor form ([B, pc] and [B, pool_max]), so both forms sample the same RoIs"""
+    L = _lib.lib()
+    dev = batch_proposals.device
+    dim = cf.dim
+    S = P + Nn
+    rois = batch_proposals.detach()
+    rois = rois if rois.is_contiguous() else rois.contiguous()
+    sc = scores.detach()
+    sc = sc if sc.is_contiguous() else sc.contiguous()
+    rand_pos = torch.rand((B, pc), device=dev, generator=generator)
+    rand_pool = torch.rand((B, pool_max), device=dev, generator=generator)
+    sample_indices = torch.empty(B * S, dtype=torch.int64, device=dev)
+    flags = torch.empty((2, B * S), dtype=torch.bool, device=dev)
+    tcls = torch.empty(B * S, dtype=torch.int64, device=dev)
+    tdel = torch.empty((B * S, 2 * dim), dtype=torch.float32, device=dev)
+    pos_rois = torch.empty((B * P, 2 * dim), dtype=torch.float32, device=dev)
+    box_ids = torch.empty(B * P, dtype=torch.int32, device=dev)
+    scale = mutils.const_tensor(cf.scale, torch.float32, dev)
+    std = mutils.const_tensor(cf.bbox_std_dev, torch.float32, dev)
+    pos_thr, neg_thr = (0.5, 0.1) if dim == 2 else (0.3, 0.01)
+    import ctypes
+    gvalid = g.valid if g.valid.is_contiguous() else g.valid.contiguous()
+    with torch.cuda.device(dev):
+        rc = L.mdt_detection_targets(_lib.ptr(rois), int(rois.shape[1]), _lib.ptr(sc), int(sc.shape[1]), _lib.ptr(g.px), _lib.ptr(scale),
+                                     _lib.ptr(g.cls), _lib.ptr(gvalid), _lib.ptr(g.gidx), _lib.ptr(rand_pos), _lib.ptr(rand_pool), _lib.ptr(std),
+                                     B, pc, int(g.px.shape[1]), dim, P, pool_max, Nn, int(cf.shem_poolsize),
+                                     ctypes.c_float(pos_thr), ctypes.c_float(neg_thr), ctypes.c_float(1.0 / cf.roi_positive_ratio),
+                                     _lib.ptr(sample_indices), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(tcls), _lib.ptr(tdel),
+                                     _lib.ptr(pos_rois), _lib.ptr(box_ids), None, _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_detection_targets")
+    target_masks = torch.zeros((B, S) + tuple(cf.mask_shape), dtype=torch.float32, device=dev)
+    if batch_gt_masks is not None and batch_gt_masks.shape[0] > 0:
+        ra = ra2D(cf.mask_shape[0], cf.mask_shape[1], 0) if dim == 2 else ra3D(cf.mask_shape[0], cf.mask_shape[1], cf.mask_shape[2], 0)
+        with torch.no_grad():
+            gm = batch_gt_masks if batch_gt_masks.dtype in (torch.uint8, torch.float32) else batch_gt_masks.float()
+            masks = ra(gm, pos_rois, box_ids).squeeze(1)
+            torch.round(masks.view((B, P) + tuple(cf.mask_shape)), out=target_masks[:, :P])
+    return sample_indices, flags[0], flags[1], tcls, tdel, target_masks.view((-1,) + tuple(cf.mask_shape))
+
+
 def detection_target_layer(batch_proposals, batch_mrcnn_class_scores, batch_gt_class_ids, batch_gt_boxes,
                            batch_gt_masks, cf, B, generator=None, gt_dev=None):
     """mrcnn.py:461-613 on fixed-size masked tensors.
@@ -397,6 +451,15 @@ def detection_target_layer(batch_proposals, batch_mrcnn_class_scores, batch_gt_c
     dim = cf.dim
     pc = batch_proposals.shape[0] // B
     scale = mutils.const_tensor(cf.scale, torch.float32, dev)
+    n_pos_max = int(cf.train_rois_per_image * cf.roi_positive_ratio)
+    n_neg_max = max(int((1.0 / cf.roi_positive_ratio) * n_pos_max - n_pos_max), 1)
+    Pq, pool_q = min(n_pos_max, pc), min(cf.shem_poolsize * n_neg_max, pc)
+    Nq = min(n_neg_max, pool_q)
+    if FUSED_GLUE and batch_proposals.is_cuda and batch_proposals.dtype == torch.float32 and batch_mrcnn_class_scores.dtype == torch.float32:
+        if gt_dev is None:
+            gt_dev = GtOnDevice(batch_gt_boxes, batch_gt_class_ids, dim, dev)
+        if _lib.lib().mdt_detection_targets_supported(pc, int(gt_dev.px.shape[1]), Pq, pool_q, Nq):
+            return _detection_targets_fused(batch_proposals, batch_mrcnn_class_scores, batch_gt_masks, cf, B, pc, Pq, pool_q, Nq, generator, gt_dev)
     gt_boxes, gt_cls, gt_valid, gt_gidx, counts = _pad_gt(batch_gt_boxes, batch_gt_class_ids, scale, dim, dev, gt_dev)
     proposals = batch_proposals[:, :2 * dim].detach().view(B, pc, 2 * dim)
     has_gt = gt_valid.any(1)                                                          # [B]
@@ -531,6 +594,78 @@ def refine_detections(rois, probs, deltas, batch_ixs, cf, B):
 ############################################################
 #  Loss functions (masked, fixed-size)
 ############################################################
+def _rpn_sample_fused(rpn_match, rpn_class_logits, n_pos_max, poolsize, generator):
+    """the sampling of compute_rpn_losses in two launches of csrc/glue.hip (mdt_rpn_sample) -- the SAME two torch.rand draws as the tensor
+    form below (shapes [B, A] and [B, kpool]), so both forms pick the same anchors"""
+    L = _lib.lib()
+    dev = rpn_match.device
+    B, A = rpn_match.shape
+    K = int(rpn_class_logits.shape[-1])
+    kpool = min(poolsize * n_pos_max, A)
+    rand_pos = torch.rand((B, A), device=dev, generator=generator)
+    rand_pool = torch.rand((B, kpool), device=dev, generator=generator)
+    idx = torch.empty((3, B, n_pos_max), dtype=torch.int64, device=dev)          # pidx, nidx, tgt_pos
+    flags = torch.empty((2, B, n_pos_max), dtype=torch.bool, device=dev)         # pvalid, nvalid
+    pos_count = torch.empty(B, dtype=torch.int64, device=dev)
+    wsb = L.mdt_rpn_sample_workspace_bytes(B, A, n_pos_max, kpool)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    logits = rpn_class_logits.detach()
+    if not logits.is_contiguous():
+        logits = logits.contiguous()
+    match = rpn_match if rpn_match.is_contiguous() else rpn_match.contiguous()
+    with torch.cuda.device(dev):
+        rc = L.mdt_rpn_sample(_lib.ptr(match), _lib.ptr(logits), K, _lib.ptr(rand_pos), _lib.ptr(rand_pool), B, A, n_pos_max, poolsize, kpool,
+                              _lib.ptr(idx[0]), _lib.ptr(flags[0]), _lib.ptr(idx[1]), _lib.ptr(flags[1]), _lib.ptr(pos_count), _lib.ptr(idx[2]),
+                              _lib.ptr(ws), wsb, _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_rpn_sample")
+    return idx[0], flags[0], idx[1], flags[1], pos_count, idx[2]
+
+
+def _rpn_losses_from_samples(samples, rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, anchors_f64, gt_boxes_list, cf, gt_dev, sparse_eval,
+                             n_pos_max):
+    """the loss terms of compute_rpn_losses on the anchors mdt_rpn_sample drew; box targets from mdt_anchor_delta_targets"""
+    pidx, pvalid, nidx, nvalid, pos_count, tgt_pos = samples
+    dev = rpn_class_logits.device
+    B, A = rpn_match.shape
+    dim = cf.dim
+    K = rpn_class_logits.shape[-1]
+    if sparse_eval is None:
+        logits_pos = torch.gather(rpn_class_logits, 1, pidx.unsqueeze(-1).expand(-1, -1, K))
+        logits_neg = torch.gather(rpn_class_logits, 1, nidx.unsqueeze(-1).expand(-1, -1, K))
+        pred = torch.gather(rpn_pred_deltas, 1, pidx.unsqueeze(-1).expand(-1, -1, 2 * dim))
+    else:
+        ls, ds = sparse_eval(torch.cat([pidx, nidx], 1))                       # ONE evaluation for positives and negatives
+        logits_pos, logits_neg, pred = ls[:, :n_pos_max], ls[:, n_pos_max:], ds[:, :n_pos_max]
+    # both cross-entropies in one call: rows [positives | negatives], targets [class id | 0]
+    tgt = torch.cat([tgt_pos, torch.zeros_like(tgt_pos)], 1)
+    ce = F.cross_entropy(torch.cat([logits_pos, logits_neg], 1).reshape(-1, K), tgt.view(-1), reduction="none").view(B, 2 * n_pos_max)
+    w = torch.cat([pvalid, nvalid], 1).to(ce.dtype)
+    sums = (ce * w).view(B, 2, n_pos_max).sum(2)                               # [B, 2]: positive / negative sums
+    cnt = w.view(B, 2, n_pos_max).sum(2).clamp(min=1)
+    class_loss = ((sums / cnt).sum(1) / 2).mean()
+    if gt_dev is not None:
+        gt_pad = gt_dev.px
+    else:
+        gmax = max(1, max(len(g) for g in gt_boxes_list))
+        gt_np = np.zeros((B, gmax, 2 * dim), dtype=np.float64)
+        for b, g in enumerate(gt_boxes_list):
+            if len(g) > 0:
+                gt_np[b, :len(g)] = np.asarray(g, dtype=np.float64)
+        gt_pad = torch.from_numpy(gt_np).to(dev, non_blocking=True)
+    tgt_d = torch.empty((B, n_pos_max, 2 * dim), dtype=torch.float32, device=dev)
+    std = mutils.const_tensor(cf.rpn_bbox_std_dev, torch.float64, dev)
+    argmax = rpn_argmax if (rpn_argmax.dtype == torch.int32 and rpn_argmax.is_contiguous()) else rpn_argmax.to(torch.int32).contiguous()
+    gt_pad = gt_pad if gt_pad.is_contiguous() else gt_pad.contiguous()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mdt_anchor_delta_targets(_lib.ptr(anchors_f64), _lib.ptr(gt_pad), _lib.ptr(argmax), _lib.ptr(pidx), _lib.ptr(pvalid), _lib.ptr(std),
+                                                 B, A, int(gt_pad.shape[1]), n_pos_max, dim, _lib.ptr(tgt_d), _lib.current_stream_ptr())
+    _lib.check(rc, "mdt_anchor_delta_targets")
+    sl1 = F.smooth_l1_loss(pred, tgt_d, reduction="none")
+    bbox_loss_b = (sl1 * pvalid.unsqueeze(-1)).sum((1, 2)) / (pos_count.clamp(min=1) * 2 * dim)
+    bbox_loss = bbox_loss_b.mean()
+    return class_loss, bbox_loss, (pidx, pvalid, nidx, nvalid)
+
+
 def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, anchors_f64, gt_boxes_list, cf, generator=None,
                        shem_poolsize=None, gt_dev=None, sparse_eval=None):
     """compute_rpn_class_loss (mrcnn.py:176-214) + compute_rpn_bbox_loss (:217-240), batched over B; with K-class
@@ -543,6 +678,15 @@ def compute_rpn_losses(rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas,
     B, A = rpn_match.shape
     dim = cf.dim
     n_pos_max = max(cf.rpn_train_anchors_per_image // 2, 1)
+    K = rpn_class_logits.shape[-1]
+    poolsize = cf.shem_poolsize if shem_poolsize is None else shem_poolsize
+    fused = None
+    if FUSED_GLUE and rpn_match.is_cuda and rpn_match.dtype == torch.int32 and rpn_class_logits.dtype == torch.float32 and \
+            _lib.lib().mdt_rpn_sample_supported(A, n_pos_max, min(poolsize * n_pos_max, A)):
+        fused = _rpn_sample_fused(rpn_match, rpn_class_logits, n_pos_max, poolsize, generator)
+    if fused is not None:
+        return _rpn_losses_from_samples(fused, rpn_match, rpn_argmax, rpn_class_logits, rpn_pred_deltas, anchors_f64, gt_boxes_list, cf, gt_dev, sparse_eval,
+                                        n_pos_max)
     pos = rpn_match > 0
     key = torch.where(pos, torch.rand(pos.shape, device=dev, generator=generator), torch.full(pos.shape, -1.0, device=dev))
     pkey, pidx = torch.topk(key, n_pos_max, dim=1)
