@@ -535,6 +535,16 @@ int mdt_detection_targets(const float *rois, int roi_stride, const float *scores
                           long long *sample_indices, unsigned char *valid, unsigned char *is_pos, long long *target_class_ids, float *target_deltas,
                           float *pos_rois, int *box_ids, long long *counts, void *stream);
 
+/* rpn_at_anchors (models/mrcnn.py; the reference's RPN, models/mrcnn.py:40-86, evaluated at the sampled anchors only): idx[s] = anchor index in the
+ * order of the concatenated pyramid levels ((y, x[, z], anchor) row-major per level), sample s belongs to batch element s / n_per_element.
+ * gather: patches [S, 3^dim, C] = the voxel's neighbourhood on its own level (channels-last maps [B, Y, X, (Z), C]; zero outside the map),
+ * k_anchor[s] = idx % anchors_per_voxel.  scatter_add: the adjoint -- adds grad_patches into the gradient maps (float atomics; the caller
+ * zero-fills them or passes maps that already hold another gradient).  C % 4 == 0, 16-byte aligned maps. */
+int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
+                         const long long *idx, int n_samples, int n_per_element, float *patches, long long *k_anchor, void *stream);
+int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps_cl, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
+                              const long long *idx, int n_samples, int n_per_element, const float *grad_patches, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

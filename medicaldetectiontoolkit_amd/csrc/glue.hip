@@ -386,6 +386,61 @@ __global__ __launch_bounds__(GL_THREADS) void detection_targets_kernel(DetTarget
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- RPN patches at sampled anchors
+// models/mrcnn.py rpn_at_anchors: the 3^dim x C neighbourhood of every sampled anchor's voxel, gathered from its own pyramid level
+// (channels-last maps: a voxel is C contiguous floats), zero outside the map (the convolution's padding).  Forward = one launch of 16-byte
+// copies; backward = one launch of float atomics into the (zero-filled) gradient maps -- a few thousand rows, collisions are rare.
+struct PatchParams {
+    const float *maps[8]; float *gmaps[8];
+    int Y[8], X[8], Z[8];
+    long long start[9];                 // first anchor index of every level (+ total)
+    int n_levels, dim, C, A, n_per_elem, S, T;
+    const long long *idx;               // [S] anchor index inside the element's concatenated levels
+    float *patches;                     // [S, T, C]
+    const float *gpatches;
+    long long *k_anchor;                // [S]
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(GL_THREADS) void rpn_patch_kernel(PatchParams p)
+{
+    const int C4 = p.C >> 2;
+    const long long total = (long long)p.S * p.T * C4;
+    for (long long e = (long long)blockIdx.x * GL_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * GL_THREADS) {
+        const int c4 = (int)(e % C4);
+        const long long r = e / C4;
+        const int t = (int)(r % p.T);
+        const int s = (int)(r / p.T);
+        const int b = s / p.n_per_elem;
+        const long long a = p.idx[s];
+        int l = 0;
+        while (l + 1 < p.n_levels && a >= p.start[l + 1]) ++l;
+        const long long local = a - p.start[l];
+        long long v = local / p.A;
+        if (!BWD && t == 0 && c4 == 0) p.k_anchor[s] = local - v * p.A;
+        const int Yl = p.Y[l], Xl = p.X[l], Zl = p.Z[l];
+        int y, x, z = 0;
+        if (p.dim == 3) { z = (int)(v % Zl); v /= Zl; }
+        x = (int)(v % Xl); y = (int)(v / Xl);
+        int ky, kx, kz = 0;
+        if (p.dim == 3) { ky = t / 9 - 1; kx = (t / 3) % 3 - 1; kz = t % 3 - 1; }
+        else { ky = t / 3 - 1; kx = t % 3 - 1; }
+        const int yy = y + ky, xx = x + kx, zz = z + kz;
+        const bool ok = yy >= 0 && yy < Yl && xx >= 0 && xx < Xl && zz >= 0 && zz < Zl;
+        const long long row = (((long long)b * Yl + yy) * Xl + xx) * Zl + zz;
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        if (!BWD) {
+            v4 val = {0.f, 0.f, 0.f, 0.f};
+            if (ok) val = *reinterpret_cast<const v4 *>(p.maps[l] + row * p.C + 4 * c4);
+            *reinterpret_cast<v4 *>(p.patches + (r * C4 + c4) * 4) = val;
+        } else if (ok) {
+            const v4 g = *reinterpret_cast<const v4 *>(p.gpatches + (r * C4 + c4) * 4);
+            float *dst = p.gmaps[l] + row * p.C + 4 * c4;
+            atomicAdd(dst + 0, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); atomicAdd(dst + 3, g.w);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -490,6 +545,57 @@ int mdt_detection_targets(const float *rois, int roi_stride, const float *scores
     p.pos_rois = pos_rois; p.box_ids = box_ids; p.counts = counts;
     (void)hipGetLastError();
     hipLaunchKernelGGL(detection_targets_kernel, dim3(B), dim3(GL_THREADS), (size_t)4 * pc * sizeof(float), (hipStream_t)stream, p);
+    return gl_check();
+}
+
+static int patch_params(PatchParams *p, int n_levels, int dim, int C, int A, const int *Y, const int *X, const int *Z, const long long *idx, int S, int n_per_elem)
+{
+    if (n_levels < 1 || n_levels > 8 || (dim != 2 && dim != 3) || C < 4 || (C & 3) || A < 1 || S < 0 || n_per_elem < 1 || (S % n_per_elem)) return MDT_ERR_INVALID_ARGUMENT;
+    p->n_levels = n_levels; p->dim = dim; p->C = C; p->A = A; p->S = S; p->n_per_elem = n_per_elem; p->T = dim == 3 ? 27 : 9; p->idx = idx;
+    long long run = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        p->Y[l] = Y[l]; p->X[l] = X[l]; p->Z[l] = dim == 3 ? Z[l] : 1;
+        if (p->Y[l] <= 0 || p->X[l] <= 0 || p->Z[l] <= 0) return MDT_ERR_INVALID_ARGUMENT;
+        p->start[l] = run;
+        run += (long long)p->Y[l] * p->X[l] * p->Z[l] * A;
+    }
+    p->start[n_levels] = run;
+    return MDT_OK;
+}
+
+int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
+                         const long long *idx, int n_samples, int n_per_element, float *patches, long long *k_anchor, void *stream)
+{
+    PatchParams p;
+    const int rc = patch_params(&p, n_levels, dim, channels, anchors_per_voxel, Y, X, Z, idx, n_samples, n_per_element);
+    if (rc != MDT_OK) return rc;
+    if (n_samples == 0) return MDT_OK;
+    for (int l = 0; l < n_levels; ++l) { p.maps[l] = maps_cl[l]; p.gmaps[l] = nullptr; if (((uintptr_t)maps_cl[l]) & 15) return MDT_ERR_UNSUPPORTED; }
+    if (((uintptr_t)patches) & 15) return MDT_ERR_UNSUPPORTED;
+    p.patches = patches; p.gpatches = nullptr; p.k_anchor = k_anchor;
+    const long long total = (long long)n_samples * p.T * (channels / 4);
+    long long blocks = (total + GL_THREADS - 1) / GL_THREADS;
+    if (blocks > 4096) blocks = 4096;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rpn_patch_kernel<false>, dim3((unsigned)blocks), dim3(GL_THREADS), 0, (hipStream_t)stream, p);
+    return gl_check();
+}
+
+int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps_cl, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
+                              const long long *idx, int n_samples, int n_per_element, const float *grad_patches, void *stream)
+{
+    PatchParams p;
+    const int rc = patch_params(&p, n_levels, dim, channels, anchors_per_voxel, Y, X, Z, idx, n_samples, n_per_element);
+    if (rc != MDT_OK) return rc;
+    if (n_samples == 0) return MDT_OK;
+    for (int l = 0; l < n_levels; ++l) { p.maps[l] = nullptr; p.gmaps[l] = grad_maps_cl[l]; }
+    if (((uintptr_t)grad_patches) & 15) return MDT_ERR_UNSUPPORTED;
+    p.patches = nullptr; p.gpatches = grad_patches; p.k_anchor = nullptr;
+    const long long total = (long long)n_samples * p.T * (channels / 4);
+    long long blocks = (total + GL_THREADS - 1) / GL_THREADS;
+    if (blocks > 4096) blocks = 4096;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rpn_patch_kernel<true>, dim3((unsigned)blocks), dim3(GL_THREADS), 0, (hipStream_t)stream, p);
     return gl_check();
 }
 

@@ -104,6 +104,57 @@ class _GatherRows(torch.autograd.Function):
         return out, None
 
 
+class _RpnPatches(torch.autograd.Function):
+    """the 3^dim x C neighbourhoods of the sampled anchors from channels-last pyramid maps: ONE gather launch (mdt_rpn_patch_gather) instead of
+    ~50 index-arithmetic / masked-gather tensor operations, ONE scatter launch backward (float atomics into zero-filled gradient maps)"""
+
+    @staticmethod
+    def forward(ctx, idx_flat, A, n_per_elem, *maps):
+        import ctypes
+        L = _lib.lib()
+        dim = maps[0].dim() - 2
+        C = int(maps[0].shape[1])
+        S = int(idx_flat.shape[0])
+        T = 3 ** dim
+        dev = maps[0].device
+        patches = torch.empty((S, T, C), dtype=torch.float32, device=dev)
+        k_anchor = torch.empty(S, dtype=torch.int64, device=dev)
+        Y = (ctypes.c_int * len(maps))(*[int(m.shape[2]) for m in maps])
+        X = (ctypes.c_int * len(maps))(*[int(m.shape[3]) for m in maps])
+        Z = (ctypes.c_int * len(maps))(*[int(m.shape[4]) if dim == 3 else 1 for m in maps])
+        ptrs = (ctypes.c_void_p * len(maps))(*[_lib.ptr(m) for m in maps])
+        with torch.cuda.device(dev):
+            rc = L.mdt_rpn_patch_gather(len(maps), ptrs, Y, X, Z, dim, C, int(A), _lib.ptr(idx_flat), S, int(n_per_elem), _lib.ptr(patches), _lib.ptr(k_anchor),
+                                        _lib.current_stream_ptr())
+        _lib.check(rc, "mdt_rpn_patch_gather")
+        ctx.save_for_backward(idx_flat)
+        ctx.meta = (int(A), int(n_per_elem), dim, C, [tuple(m.shape) for m in maps], (Y, X, Z))
+        ctx.mark_non_differentiable(k_anchor)
+        return patches, k_anchor
+
+    @staticmethod
+    def backward(ctx, g, _gk):
+        import ctypes
+        idx_flat, = ctx.saved_tensors
+        A, n_per_elem, dim, C, shapes, (Y, X, Z) = ctx.meta
+        mf = torch.channels_last_3d if dim == 3 else torch.channels_last
+        outs = [torch.empty(sh, dtype=torch.float32, device=g.device, memory_format=mf).zero_() for sh in shapes]
+        g = g.contiguous()
+        ptrs = (ctypes.c_void_p * len(outs))(*[_lib.ptr(o) for o in outs])
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().mdt_rpn_patch_scatter_add(len(outs), ptrs, Y, X, Z, dim, C, A, _lib.ptr(idx_flat), int(idx_flat.shape[0]), n_per_elem, _lib.ptr(g),
+                                                      _lib.current_stream_ptr())
+        _lib.check(rc, "mdt_rpn_patch_scatter_add")
+        return (None, None, None) + tuple(outs)
+
+
+def _rpn_patches_fused_ok(feature_maps, dim):
+    mf = torch.channels_last_3d if dim == 3 else torch.channels_last
+    C = int(feature_maps[0].shape[1])
+    return FUSED_GLUE and len(feature_maps) <= 8 and C % 4 == 0 and all(
+        m.is_cuda and m.dtype == torch.float32 and m.dim() == dim + 2 and int(m.shape[1]) == C and m.is_contiguous(memory_format=mf) for m in feature_maps)
+
+
 def rpn_at_anchors(rpn, feature_maps, idx, n_anchors_per_voxel):
     """The RPN (mrcnn.py:40-86) evaluated at CHOSEN anchors only: idx [B, n] indexes the anchors in the order of the concatenated pyramid
     levels, as RPN.forward lays them out ((y, x, z, anchor) row-major per level).  Returns class logits [B, n, 2] and box deltas
@@ -125,6 +176,10 @@ def rpn_at_anchors(rpn, feature_maps, idx, n_anchors_per_voxel):
     vox = [int(np.prod(sz)) for sz in sizes]
     starts = np.concatenate([[0], np.cumsum([v * A for v in vox])])
     idx = idx.long()
+    if _rpn_patches_fused_ok(feature_maps, dim):
+        S, T, C = B * n, 3 ** dim, conv.in_channels
+        patches, k_anchor = _RpnPatches.apply(idx.reshape(-1).contiguous(), A, n, *feature_maps)
+        return _rpn_heads_on_patches(rpn, conv, patches, k_anchor, B, n, S, T, C, A, dim)
     b_ix = torch.arange(B, device=dev)[:, None].expand(B, n).reshape(-1)
     flat_idx = idx.reshape(-1)
     S = B * n
@@ -161,6 +216,11 @@ def rpn_at_anchors(rpn, feature_maps, idx, n_anchors_per_voxel):
         flat = fm.permute(*perm).reshape(-1, C)                                # a view for channels-last maps
         g = _GatherRows.apply(flat, (row * m).reshape(-1)).view(S, T, C) * m.unsqueeze(-1).to(fm.dtype)
         patches = g if patches is None else patches + g
+    return _rpn_heads_on_patches(rpn, conv, patches, k_anchor, B, n, S, T, C, A, dim)
+
+
+def _rpn_heads_on_patches(rpn, conv, patches, k_anchor, B, n, S, T, C, A, dim):
+    """conv_shared as a matrix product over the gathered (tap, channel) patches, activation, the two 1x1 heads, the sampled anchor's rows"""
     wperm = (0, 2, 3, 1) if dim == 2 else (0, 2, 3, 4, 1)
     w = conv.weight.permute(*wperm).reshape(conv.out_channels, T * C)          # (tap, channel) order of the patches
     h = F.linear(patches.reshape(S, T * C), w, conv.bias)

@@ -7,6 +7,10 @@ if "torch" not in sys.modules and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE
     os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
     os.environ["MDT_GRAPH_ENV_BEFORE_HIP"] = "1"
 
+# MIOpen's exhaustive find skips the naive direct solvers (never the fastest for these layers, seconds per trial on 128^3 maps: the Retina
+# U-Net step at the benchmarked size took 7 min of find with them, ~1 min without) -- what bench.py sets for its child processes
+os.environ.setdefault("MDT_MIOPEN_SKIP_NAIVE", "1")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -148,3 +148,37 @@ def test_detection_target_layer_equals_the_tensor_form(dim, pc, rois_per_image, 
     assert torch.equal(tm[va], tm2[va2]) and float(tm[~ip].abs().max()) == 0.0
     S = va.numel() // B
     assert int(va.view(B, S)[2].sum()) == 1 and int(ip.view(B, S)[2].sum()) == 0       # element without GT: one negative, no positive
+
+
+@pytest.mark.parametrize("dim,patch", [(3, [64, 64, 32]), (2, [64, 64])])
+def test_rpn_at_anchors_fused_gather_equals_the_tensor_form(dim, patch, cuda):
+    """rpn_at_anchors through mdt_rpn_patch_gather / _scatter_add == the index-arithmetic tensor form: logits, deltas bit-equal (the same rows
+    enter the same matrix products), gradients w.r.t. the maps and the RPN parameters equal (scatter order differs: 1e-6)"""
+    B, n = 3, 40
+    cf = Configs(dim=dim, model="mrcnn", patch_size=patch, batch_size=B)
+    torch.manual_seed(0)
+    net = mrcnn.net(cf, device=cuda)
+    mf = torch.channels_last_3d if dim == 3 else torch.channels_last
+    g = torch.Generator(device=cuda).manual_seed(7)
+    shapes = [tuple(int(v) for v in s) for s in cf.backbone_shapes]
+    levels = [shapes[i] for i in cf.pyramid_levels]
+    A = len(cf.rpn_anchor_ratios) * (1 if dim == 2 else len(cf.rpn_anchor_scales["z"][0])) if False else None
+    n_a = net.anchors.shape[0] // sum(int(np.prod(s)) for s in levels)
+    total = sum(int(np.prod(s)) for s in levels) * n_a
+    idx = torch.randint(0, total, (B, n), device=cuda, generator=g)
+    idx[0, :4] = torch.tensor([0, n_a * int(np.prod(levels[0])) - 1, n_a * int(np.prod(levels[0])), total - 1], device=cuda)     # level borders, map corners
+    res = {}
+    for fused in (True, False):
+        mrcnn.FUSED_GLUE = fused
+        maps = [torch.randn((B, cf.end_filts) + s, device=cuda, generator=torch.Generator(device=cuda).manual_seed(50 + k)).contiguous(memory_format=mf).requires_grad_(True)
+                for k, s in enumerate(levels)]
+        net.zero_grad()
+        lg, dl = mrcnn.rpn_at_anchors(net.rpn, maps, idx, n_a)
+        wl = torch.randn(lg.shape, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
+        wd = torch.randn(dl.shape, device=cuda, generator=torch.Generator(device=cuda).manual_seed(4))
+        ((lg * wl).sum() + (dl * wd).sum()).backward()
+        res[fused] = (lg.detach(), dl.detach(), [m.grad.clone() for m in maps], [p.grad.clone() for p in net.rpn.parameters()])
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2] + res[True][3], res[False][2] + res[False][3]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max() + 1e-12)), float((a - b).abs().max())
+    assert all(float(gm.abs().sum()) > 0 for gm in res[True][2][:2])

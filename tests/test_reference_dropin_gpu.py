@@ -549,6 +549,7 @@ def test_reference_checkpoint_loads_and_gives_the_same_detections_wbc_and_ap(ref
     for cl in (1, 2):
         a_r = evaluator.get_roi_ap_from_df(df_r[df_r.pred_class == cl], 0.1, False)
         a_m = evaluator.get_roi_ap_from_df(df_m[df_m.pred_class == cl], 0.1, False)
-        assert a_r == a_m, (cl, a_r, a_m)
+        # (a class without a GT object in either volume has no AP: the mean over an empty list, NaN, in both)
+        assert a_r == a_m or (np.isnan(a_r) and np.isnan(a_m)), (cl, a_r, a_m)
         aps[cl] = a_r
-    assert n_raw >= 16 and any(0.0 < v <= 1.0 for v in aps.values()), aps
+    assert n_raw >= 16 and any(0.0 < v <= 1.0 for v in aps.values() if not np.isnan(v)), aps
