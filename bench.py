@@ -615,6 +615,9 @@ def main():
     ap.add_argument("--sparse-rpn-loss", type=int, default=1, help="1 (default): the RPN losses differentiate through the 48 sampled anchors only (models/mrcnn.rpn_at_anchors; the dense RPN forward carries no graph); 0: through the dense outputs like the reference (A/B)")
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
     ap.add_argument("--roialign-cl", type=int, default=1, help="1 (default): the RoI heads pool the channels-last pyramid maps as they are (mdt_pyramid_roi_align_forward_cl); 0: one row-major copy of the pyramid per forward (A/B)")
+    ap.add_argument("--fused-glue", type=int, default=1, help="1 (default): level rule, RPN sampling, box targets, detection target layer, refine_detections and the sampled-anchor gather as single launches of csrc/glue.hip; 0: chains of small tensor operations (A/B)")
+    ap.add_argument("--bias-grad-in-launch", type=int, default=1, help="1 (default): the bias gradient's second stage inside the backward epilogue's launch; 0: separate finish launch (A/B)")
+    ap.add_argument("--flip-batched", type=int, default=1, help="1 (default): all flipped filters of a step from one launch; 0: one launch per layer (A/B)")
     ap.add_argument("--pool-cl", type=int, default=1, help="1 (default): channels-last max pooling kernel of the stem (csrc/pool.hip); 0: torch (A/B)")
     ap.add_argument("--pin-cores", type=int, default=1, help="N > 1: 1 (default) pins every rank to its own slice of the cores of its GPU's NUMA node (utils/affinity.py); 0: only caps the intra-op threads")
     ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
@@ -692,6 +695,9 @@ def main():
     mrcnn.HEAD_AS_LINEAR = bool(args.head_as_linear)
     mrcnn.MERGE_RPN_HEADS = bool(args.merge_rpn_heads)
     mrcnn.SPARSE_RPN_LOSS = bool(args.sparse_rpn_loss)
+    mrcnn.FUSED_GLUE = bool(args.fused_glue)
+    fused_epilogue.BIAS_GRAD_IN_LAUNCH = bool(args.bias_grad_in_launch)
+    fused_epilogue.FLIP_BATCHED = bool(args.flip_batched)
 
     # MIOpen's immediate-mode heuristics pick naive 3D solvers for the 18/36/72-channel convolutions of this
     # backbone (3.2 s per step); the exhaustive find selects im2col+GEMM / CK kernels (42x faster, profiles/).

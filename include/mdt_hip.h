@@ -545,6 +545,19 @@ int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y
 int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps_cl, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
                               const long long *idx, int n_samples, int n_per_element, const float *grad_patches, void *stream);
 
+/* refine_detections (reference models/mrcnn.py:620-714) around the batched NMS.  pre: dets [B * fg, pc, 2 dim + 1] -- per (element, foreground
+ * class) the boxes decoded with that class's deltas x std_dev (utils/model_utils.py:318-370), x scale, clipped to `window`, rounded, sorted by
+ * score (stable, descending; scores < min_confidence carry key -1) -- the input of mdt_nms_{2,3}d_batched.  post: per element the M best
+ * survivors (keep [B * fg, pc] as the batched NMS wrote it) over its classes -> result [B * M, 2 dim + 3] = (box, batch index, class id, score),
+ * zero rows + valid = 0 for empty slots; when nothing in the whole batch is valid, row 0 = roi 0 of element 0 with class 1 (reference :708-709).
+ * std_dev / scale / window: HOST arrays of 2 dim floats.  any_valid_scratch: B device ints. */
+int mdt_refine_detections_supported(int pc, int n_classes, int M);
+int mdt_refine_detections_pre(const float *rois, const float *probs, const float *deltas, const float *std_dev_host, const float *scale_host,
+                              const float *window_host, float min_confidence, int B, int pc, int dim, int n_classes, float *dets, void *stream);
+int mdt_refine_detections_post(const float *rois, const float *probs, const float *deltas, const float *std_dev_host, const float *scale_host,
+                               const float *window_host, float min_confidence, int B, int pc, int dim, int n_classes, int M,
+                               const float *dets, const long long *keep, float *result, unsigned char *valid, int *any_valid_scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

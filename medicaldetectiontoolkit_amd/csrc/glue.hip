@@ -441,6 +441,133 @@ __global__ __launch_bounds__(GL_THREADS) void rpn_patch_kernel(PatchParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- refine_detections
+// models/mrcnn.py refine_detections (reference :620-714) around the batched NMS: (pre) per (element, foreground class) group the boxes
+// decoded with the class's deltas (utils/model_utils.py apply_box_deltas, x scale, clipped to the window, rounded) and sorted by score
+// (stable, descending; scores below model_min_confidence sort last with key -1); (post) per element the M best NMS survivors over its
+// classes in the result row layout (box, batch index, class id, score), zero rows for empty slots.
+struct RefineParams {
+    const float *rois;            // [B * pc, 2 dim] normalised proposals
+    const float *probs;           // [B * pc, n_classes]
+    const float *deltas;          // [B * pc, n_classes, 2 dim]
+    float std_dev[6], scale[6], window[6];
+    float min_conf;
+    int B, pc, dim, n_classes, M;
+    float *dets;                  // [B * fg, pc, 2 dim + 1] sorted
+    const long long *keep;        // [B * fg, pc] NMS survivors (positions in the sorted order), -1 = none
+    float *result;                // [B * M, 2 dim + 3]
+    unsigned char *valid;         // [B * M]
+    int *any_valid;               // [B]
+};
+
+__device__ __forceinline__ void decode_scale_clip_round(const float *b, const float *d, const RefineParams &p, float *o)
+{
+    const int dim = p.dim;
+    float height = b[2] - b[0], width = b[3] - b[1];
+    float cy = b[0] + 0.5f * height, cx = b[1] + 0.5f * width;
+    float v[6];
+    if (dim == 3) {
+        float depth = b[5] - b[4];
+        float cz = b[4] + 0.5f * depth;
+        cy = cy + (d[0] * p.std_dev[0]) * height;
+        cx = cx + (d[1] * p.std_dev[1]) * width;
+        cz = cz + (d[2] * p.std_dev[2]) * depth;
+        height = height * expf(d[3] * p.std_dev[3]);
+        width = width * expf(d[4] * p.std_dev[4]);
+        depth = depth * expf(d[5] * p.std_dev[5]);
+        const float y1 = cy - 0.5f * height, x1 = cx - 0.5f * width, z1 = cz - 0.5f * depth;
+        v[0] = y1; v[1] = x1; v[2] = y1 + height; v[3] = x1 + width; v[4] = z1; v[5] = z1 + depth;
+    } else {
+        cy = cy + (d[0] * p.std_dev[0]) * height;
+        cx = cx + (d[1] * p.std_dev[1]) * width;
+        height = height * expf(d[2] * p.std_dev[2]);
+        width = width * expf(d[3] * p.std_dev[3]);
+        const float y1 = cy - 0.5f * height, x1 = cx - 0.5f * width;
+        v[0] = y1; v[1] = x1; v[2] = y1 + height; v[3] = x1 + width;
+    }
+    // (the decode kernel's "no clip" window of the tensor form: min(max(v, -3e38), 3e38))
+    for (int k = 0; k < 2 * dim; ++k) v[k] = fminf(fmaxf(v[k], -3e38f), 3e38f) * p.scale[k];
+    const int lo[6] = {0, 1, 0, 1, 4, 4}, hi[6] = {2, 3, 2, 3, 5, 5};
+    for (int k = 0; k < 2 * dim; ++k) o[k] = rintf(fminf(fmaxf(v[k], p.window[lo[k]]), p.window[hi[k]]));
+}
+
+__global__ __launch_bounds__(GL_THREADS) void refine_pre_kernel(RefineParams p)
+{
+    extern __shared__ float s[];                 // [pc] keys | [pc * 2 dim] boxes
+    const int fg = p.n_classes - 1;
+    const int g = blockIdx.x, b = g / fg, c = g % fg + 1, t = threadIdx.x, w = 2 * p.dim, pc = p.pc;
+    float *s_key = s, *s_box = s + pc;
+    for (int i = t; i < pc; i += GL_THREADS) {
+        const long long r = (long long)b * pc + i;
+        decode_scale_clip_round(p.rois + r * w, p.deltas + (r * p.n_classes + c) * w, p, s_box + i * w);
+        const float sc = p.probs[r * p.n_classes + c];
+        s_key[i] = sc >= p.min_conf ? sc : -1.0f;
+    }
+    __syncthreads();
+    for (int i = t; i < pc; i += GL_THREADS) {
+        const float k = s_key[i];
+        int rank = 0;
+        for (int j = 0; j < pc; ++j) {
+            const float kj = s_key[j];
+            rank += (kj > k || (kj == k && j < i)) ? 1 : 0;
+        }
+        float *o = p.dets + ((long long)g * pc + rank) * (w + 1);
+        for (int q = 0; q < w; ++q) o[q] = s_box[i * w + q];
+        o[w] = k;
+    }
+}
+
+__global__ __launch_bounds__(GL_THREADS) void refine_post_kernel(RefineParams p)
+{
+    extern __shared__ float s[];                 // [fg * pc] candidate scores
+    __shared__ float s_red_v[GL_THREADS / 64];
+    __shared__ int s_red_i[GL_THREADS / 64];
+    __shared__ int s_any;
+    const int fg = p.n_classes - 1;
+    const int b = blockIdx.x, t = threadIdx.x, w = 2 * p.dim, pc = p.pc, n = fg * pc;
+    if (t == 0) s_any = 0;
+    for (int j = t; j < n; j += GL_THREADS) s[j] = -1.0f;
+    __syncthreads();
+    for (int j = t; j < n; j += GL_THREADS) {
+        const long long k = p.keep[(long long)b * n + j];                       // group b * fg + j / pc, survivor slot j % pc
+        if (k >= 0 && k < pc) {
+            const int c0 = j / pc;
+            const float sc = p.dets[((long long)(b * fg + c0) * pc + k) * (w + 1) + w];
+            if (sc >= p.min_conf) s[c0 * pc + (int)k] = sc;
+        }
+    }
+    __syncthreads();
+    const int row_w = w + 3;
+    block_select(s, n, p.M, s_red_v, s_red_i, [&](int r, float v, int slot) {
+        float *o = p.result + ((long long)b * p.M + r) * row_w;
+        if (v >= 0.0f) {
+            const int c0 = slot / pc, k = slot - c0 * pc;
+            const float *d = p.dets + ((long long)(b * fg + c0) * pc + k) * (w + 1);
+            for (int q = 0; q < w; ++q) o[q] = d[q];
+            o[w] = (float)b; o[w + 1] = (float)(c0 + 1); o[w + 2] = v;
+            p.valid[(long long)b * p.M + r] = 1;
+            s_any = 1;
+        } else {
+            for (int q = 0; q < row_w; ++q) o[q] = 0.0f;
+            p.valid[(long long)b * p.M + r] = 0;
+        }
+    });
+    if (t == 0) p.any_valid[b] = s_any;
+}
+
+// reference :708-709: nothing of the whole batch reached the confidence -> index 0 of its repeated arrays is kept (roi 0 of element 0, class 1)
+__global__ void refine_fallback_kernel(RefineParams p)
+{
+    if (threadIdx.x != 0) return;
+    for (int b = 0; b < p.B; ++b) if (p.any_valid[b]) return;
+    const int w = 2 * p.dim;
+    float box[6];
+    decode_scale_clip_round(p.rois, p.deltas + (long long)1 * w, p, box);
+    for (int q = 0; q < w; ++q) p.result[q] = box[q];
+    p.result[w] = 0.0f; p.result[w + 1] = 1.0f; p.result[w + 2] = p.probs[1];
+    p.valid[0] = 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -596,6 +723,53 @@ int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps_cl, const in
     if (blocks > 4096) blocks = 4096;
     (void)hipGetLastError();
     hipLaunchKernelGGL(rpn_patch_kernel<true>, dim3((unsigned)blocks), dim3(GL_THREADS), 0, (hipStream_t)stream, p);
+    return gl_check();
+}
+
+static int refine_params(RefineParams *p, const float *rois, const float *probs, const float *deltas, const float *std_dev, const float *scale,
+                         const float *window, float min_conf, int B, int pc, int dim, int n_classes, int M)
+{
+    if (B < 1 || pc < 1 || (dim != 2 && dim != 3) || n_classes < 2 || M < 1) return MDT_ERR_INVALID_ARGUMENT;
+    if (pc > 1024 || M > GL_MAX_K || (long long)(n_classes - 1) * pc > GL_MAX_CAND) return MDT_ERR_UNSUPPORTED;
+    p->rois = rois; p->probs = probs; p->deltas = deltas; p->min_conf = min_conf;
+    p->B = B; p->pc = pc; p->dim = dim; p->n_classes = n_classes; p->M = M;
+    for (int k = 0; k < 6; ++k) {
+        p->std_dev[k] = k < 2 * dim ? std_dev[k] : 1.0f;
+        p->scale[k] = k < 2 * dim ? scale[k] : 1.0f;
+        p->window[k] = k < 2 * dim ? window[k] : 0.0f;
+    }
+    return MDT_OK;
+}
+
+int mdt_refine_detections_supported(int pc, int n_classes, int M)
+{
+    return (pc >= 1 && pc <= 1024 && n_classes >= 2 && M >= 1 && M <= GL_MAX_K && (long long)(n_classes - 1) * pc <= GL_MAX_CAND) ? 1 : 0;
+}
+
+int mdt_refine_detections_pre(const float *rois, const float *probs, const float *deltas, const float *std_dev_host, const float *scale_host,
+                              const float *window_host, float min_confidence, int B, int pc, int dim, int n_classes, float *dets, void *stream)
+{
+    RefineParams p;
+    const int rc = refine_params(&p, rois, probs, deltas, std_dev_host, scale_host, window_host, min_confidence, B, pc, dim, n_classes, 1);
+    if (rc != MDT_OK) return rc;
+    p.dets = dets; p.keep = nullptr; p.result = nullptr; p.valid = nullptr; p.any_valid = nullptr;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(refine_pre_kernel, dim3(B * (n_classes - 1)), dim3(GL_THREADS), (size_t)pc * (2 * dim + 1) * sizeof(float), (hipStream_t)stream, p);
+    return gl_check();
+}
+
+int mdt_refine_detections_post(const float *rois, const float *probs, const float *deltas, const float *std_dev_host, const float *scale_host,
+                               const float *window_host, float min_confidence, int B, int pc, int dim, int n_classes, int M,
+                               const float *dets, const long long *keep, float *result, unsigned char *valid, int *any_valid_scratch, void *stream)
+{
+    RefineParams p;
+    const int rc = refine_params(&p, rois, probs, deltas, std_dev_host, scale_host, window_host, min_confidence, B, pc, dim, n_classes, M);
+    if (rc != MDT_OK) return rc;
+    p.dets = const_cast<float *>(dets); p.keep = keep; p.result = result; p.valid = valid; p.any_valid = any_valid_scratch;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(refine_post_kernel, dim3(B), dim3(GL_THREADS), (size_t)(n_classes - 1) * pc * sizeof(float), (hipStream_t)stream, p);
+    if (gl_check() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
+    hipLaunchKernelGGL(refine_fallback_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
     return gl_check();
 }
 

@@ -589,6 +589,42 @@ def detection_target_layer(batch_proposals, batch_mrcnn_class_scores, batch_gt_c
     return sample_indices, valid, is_pos, target_class_ids, target_deltas, target_masks
 
 
+def _refine_detections_fused(rois, probs, deltas, cf, B, pc, fg, std, M):
+    """refine_detections as decode + sort (one launch), the batched NMS, top-M + row assembly (two launches): csrc/glue.hip"""
+    import ctypes
+    L = _lib.lib()
+    dev = rois.device
+    dim = cf.dim
+    nc = int(probs.shape[1])
+    rois_c = rois.detach().contiguous()
+    probs_c = probs.detach().contiguous()
+    deltas_c = deltas.detach().contiguous()
+    G = B * fg
+    scale = np.ascontiguousarray(cf.scale, dtype=np.float32)
+    win = np.ascontiguousarray(cf.window, dtype=np.float32)
+    thr = ctypes.c_float(cf.model_min_confidence)
+    dets = torch.empty((G, pc, 2 * dim + 1), dtype=torch.float32, device=dev)
+    keep = torch.empty((G, pc), dtype=torch.int64, device=dev)
+    num = torch.empty(G + B, dtype=torch.int32, device=dev)              # NMS counts | any_valid scratch
+    wsb = G * L.mdt_nms_workspace_bytes(pc)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    result = torch.empty((B * M, 2 * dim + 3), dtype=torch.float32, device=dev)
+    valid = torch.empty(B * M, dtype=torch.bool, device=dev)
+    fn = L.mdt_nms_3d_batched if dim == 3 else L.mdt_nms_2d_batched
+    with torch.cuda.device(dev):
+        st = _lib.current_stream_ptr()
+        rc = L.mdt_refine_detections_pre(_lib.ptr(rois_c), _lib.ptr(probs_c), _lib.ptr(deltas_c), std.ctypes.data, scale.ctypes.data, win.ctypes.data, thr,
+                                         B, pc, dim, nc, _lib.ptr(dets), st)
+        _lib.check(rc, "mdt_refine_detections_pre")
+        rc = fn(_lib.ptr(dets), G, pc, ctypes.c_float(cf.detection_nms_threshold), _lib.NMS_RULE_GT, 0,
+                _lib.ptr(keep), pc, _lib.ptr(num), _lib.ptr(ws), wsb, st)
+        _lib.check(rc, "mdt_nms_batched")
+        rc = L.mdt_refine_detections_post(_lib.ptr(rois_c), _lib.ptr(probs_c), _lib.ptr(deltas_c), std.ctypes.data, scale.ctypes.data, win.ctypes.data, thr,
+                                          B, pc, dim, nc, M, _lib.ptr(dets), _lib.ptr(keep), _lib.ptr(result), _lib.ptr(valid), _lib.ptr(num[G:]), st)
+        _lib.check(rc, "mdt_refine_detections_post")
+    return result, valid
+
+
 def refine_detections(rois, probs, deltas, batch_ixs, cf, B):
     """mrcnn.py:620-714 on fixed-size tensors.  Returns detections [B*M, 2*dim+3] = (pixel box rounded, batch_ix,
     class_id, score) with M = model_max_instances_per_batch_element slots per element, and a validity mask.
@@ -601,6 +637,10 @@ def refine_detections(rois, probs, deltas, batch_ixs, cf, B):
     pc = n // B
     fg = cf.head_classes - 1
     std = np.asarray(cf.rpn_bbox_std_dev, dtype=np.float32)       # quirk 8: rpn_bbox_std_dev, not bbox_std_dev (:650)
+    M = cf.model_max_instances_per_batch_element
+    if FUSED_GLUE and rois.is_cuda and rois.dtype == torch.float32 and probs.dtype == torch.float32 and deltas.dtype == torch.float32 \
+            and L.mdt_refine_detections_supported(pc, int(probs.shape[1]), min(M, fg * pc)):
+        return _refine_detections_fused(rois, probs, deltas, cf, B, pc, fg, std, min(M, fg * pc))
     scale = mutils.const_tensor(cf.scale, torch.float32, dev)
     win = [float(v) for v in cf.window]
     no_clip = [-3e38, -3e38, 3e38, 3e38] + ([-3e38, 3e38] if dim == 3 else [])

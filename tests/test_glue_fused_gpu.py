@@ -182,3 +182,43 @@ def test_rpn_at_anchors_fused_gather_equals_the_tensor_form(dim, patch, cuda):
     for a, b in zip(res[True][2] + res[True][3], res[False][2] + res[False][3]):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max() + 1e-12)), float((a - b).abs().max())
     assert all(float(gm.abs().sum()) > 0 for gm in res[True][2][:2])
+
+
+@pytest.mark.parametrize("dim,pc,case", [(3, 75, "normal"), (3, 75, "nothing_confident"), (2, 500, "normal"), (3, 40, "one_element_empty")])
+def test_refine_detections_fused_equals_the_tensor_form(dim, pc, case, cuda):
+    """refine_detections through mdt_refine_detections_pre / the batched NMS / _post == the tensor form: same rows (as sets per element: top-k
+    order of equal scores aside there are none), same validity, incl. the reference's keep-index-0 quirk when nothing is confident"""
+    B = 3
+    rng = np.random.default_rng(pc + len(case))
+    patch = [64, 64, 32] if dim == 3 else [64, 64]
+    cf = Configs(dim=dim, model="mrcnn", patch_size=patch, batch_size=B)
+    rois = torch.from_numpy(_boxes(rng, B * pc, dim, 0.1, 0.9)).to(cuda)
+    logits = rng.standard_normal((B * pc, 3)).astype(np.float32) * 1.5
+    if case == "nothing_confident":
+        logits[:, 0] += 9.0
+    if case == "one_element_empty":
+        logits[pc:2 * pc, 0] += 9.0
+    probs = torch.softmax(torch.from_numpy(logits), 1).to(cuda)
+    deltas = torch.from_numpy((rng.standard_normal((B * pc, 3, 2 * dim)) * 0.5).astype(np.float32)).to(cuda)
+    bix = torch.arange(B, device=cuda, dtype=torch.float32).repeat_interleave(pc)
+    out = {}
+    for fused in (True, False):
+        mrcnn.FUSED_GLUE = fused
+        r, v = mrcnn.refine_detections(rois, probs, deltas, bix, cf, B)
+        out[fused] = (r.clone(), v.clone())
+    (rf, vf), (rt, vt) = out[True], out[False]
+    assert rf.shape == rt.shape and torch.equal(vf, vt)
+    M = rf.shape[0] // B
+    for b in range(B):
+        a = rf[b * M:(b + 1) * M][vf[b * M:(b + 1) * M]].cpu().numpy()
+        c = rt[b * M:(b + 1) * M][vt[b * M:(b + 1) * M]].cpu().numpy()
+        a = a[np.lexsort(a.T[::-1])]
+        c = c[np.lexsort(c.T[::-1])]
+        assert np.array_equal(a, c), (b, a[:3], c[:3])
+    assert float(rf[~vf].abs().max() if (~vf).any() else 0.0) == 0.0
+    if case == "nothing_confident":
+        assert int(vf.sum()) == 1 and bool(vf[0]) and float(rf[0, 2 * dim + 1]) == 1.0 and float(rf[0, 2 * dim + 2]) < cf.model_min_confidence
+    elif case == "one_element_empty":
+        assert int(vf[M:2 * M].sum()) == 0 and int(vf.sum()) > 0
+    else:
+        assert int(vf.sum()) >= B
