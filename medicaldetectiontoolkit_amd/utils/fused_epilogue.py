@@ -84,8 +84,15 @@ class _BiasAct(Function):
         gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
         wsb = (4096 * C * 4 + 256) if ctx.inner == 1 else L.mdt_bias_act_backward_workspace_bytes(n, C, ctx.inner)
         ws = _workspace(wsb, gy.device)
-        rc = L.mdt_bias_act_backward(gx.data_ptr(), gy.data_ptr(), y.data_ptr() if y is not None else None, gbias.data_ptr(), n, C, ctx.inner,
-                                     1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), _lib.raw_stream())
+        if ctx.inner == 1 and BIAS_GRAD_IN_LAUNCH:          # one launch: the last block folds the partial rows (see _bias_act_bwd)
+            tk = _TICKET.get(gy.device)
+            if tk is None:
+                tk = _TICKET[gy.device] = torch.zeros(1, dtype=torch.int32, device=gy.device)
+            rc = L.mdt_bias_act_backward_ticket(gx.data_ptr(), gy.data_ptr(), y.data_ptr() if y is not None else None, gbias.data_ptr(), n, C, ctx.inner,
+                                                1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), tk.data_ptr(), _lib.raw_stream())
+        else:
+            rc = L.mdt_bias_act_backward(gx.data_ptr(), gy.data_ptr(), y.data_ptr() if y is not None else None, gbias.data_ptr(), n, C, ctx.inner,
+                                         1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_bias_act_backward")
         return gx, gbias, (gx if ctx.has_res else None), None, None, None
