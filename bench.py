@@ -616,7 +616,7 @@ def main():
     ap.add_argument("--upsample-cl", type=int, default=1, help="1 (default): channels-last x2 (y, x) linear up-sampling kernel of the Retina U-Net decoder (csrc/upsample.hip); 0: torch (A/B)")
     ap.add_argument("--roialign-cl", type=int, default=1, help="1 (default): the RoI heads pool the channels-last pyramid maps as they are (mdt_pyramid_roi_align_forward_cl); 0: one row-major copy of the pyramid per forward (A/B)")
     ap.add_argument("--fused-glue", type=int, default=1, help="1 (default): level rule, RPN sampling, box targets, detection target layer, refine_detections and the sampled-anchor gather as single launches of csrc/glue.hip; 0: chains of small tensor operations (A/B)")
-    ap.add_argument("--bias-grad-in-launch", type=int, default=1, help="1 (default): the bias gradient's second stage inside the backward epilogue's launch; 0: separate finish launch (A/B)")
+    ap.add_argument("--bias-grad-in-launch", type=int, default=0, help="1: the bias gradient's second stage inside the backward epilogue's launch (measured slower, profiles/r06/r06_bias_grad_in_launch_probe.txt); 0 (default): separate finish launch")
     ap.add_argument("--flip-batched", type=int, default=1, help="1 (default): all flipped filters of a step from one launch; 0: one launch per layer (A/B)")
     ap.add_argument("--pool-cl", type=int, default=1, help="1 (default): channels-last max pooling kernel of the stem (csrc/pool.hip); 0: torch (A/B)")
     ap.add_argument("--pin-cores", type=int, default=1, help="N > 1: 1 (default) pins every rank to its own slice of the cores of its GPU's NUMA node (utils/affinity.py); 0: only caps the intra-op threads")

@@ -81,13 +81,21 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_fwd_kernel(float *y, cons
     }
 }
 
+// partial rows of the in-launch second stage: write-through (sc1) stores / sc1 loads = relaxed agent-scope atomics on gfx950
+__device__ __forceinline__ void store_partial(float *p, float v, bool through)
+{
+    if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+__device__ __forceinline__ float load_partial(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ---- backward, channels-last -----------------------------------------------------------------------------------
 // Thread t of a block owns channel slots; a block walks a contiguous range of pixels.  C < 256: ppb = 256 / C pixels are
 // processed side by side (thread t -> pixel lane t / C, channel t % C) and the lanes are folded in LDS in lane order;
 // C >= 256: thread t owns channels t, t + 256, ... of every pixel.  Per-block partials go to `partial[block][C]`.
-// ticket != null (round 6): the second stage runs INSIDE this launch -- every block publishes its partial row (agent-scope release), draws a
-// ticket, and the block that draws the last one folds all rows into gbias (agent-scope acquire first: per-XCD L2s are not coherent, the
-// recipe of cdna_hip_programming.md 6 G16 / MI355X_MICROARCH.md "inter-workgroup visibility") and resets the ticket to 0 for the next launch.
+// ticket != null (round 6): the second stage runs INSIDE this launch -- every block publishes its partial row with write-through (sc1) stores,
+// draws a ticket, and the block that draws the last one folds all rows into gbias with sc1 loads (per-XCD L2s are not coherent: the sc1 / sc1
+// form of cdna_hip_programming.md 6 G16 / MI355X_MICROARCH.md "inter-workgroup visibility") and resets the ticket to 0 for the next launch.
 // One launch instead of two per convolution layer (~60 per training step); still a fixed summation order (deterministic).
 template <bool RELU>
 __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__restrict__ gx, const float *__restrict__ gy,
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
         if (t < C) {
             float s = 0.0f;
             for (int l = 0; l < ppb; ++l) s = s + s_acc[l * C + t];     // fixed lane order
-            partial[(long long)blockIdx.x * C + t] = s;
+            store_partial(partial + (long long)blockIdx.x * C + t, s, ticket != nullptr);
         }
     } else {
         for (int k = 0; k < ktiles; ++k) {
@@ -156,35 +164,43 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
                     gx[i] = g;
                     acc = acc + g;
                 }
-                partial[(long long)blockIdx.x * C + c] = acc;
+                store_partial(partial + (long long)blockIdx.x * C + c, acc, ticket != nullptr);
             }
         }
     }
     if (ticket == nullptr) return;
-    // ---- publish this block's row, draw a ticket
+    // ---- publish this block's row, draw a ticket.  The row was written with write-through (sc1) stores: once they have drained
+    // (vmcnt(0)) they are in memory, and the relaxed agent-scope ticket add cannot overtake them.  NO release fence: an agent-scope release
+    // is an L2 write-back of everything the XCD has dirtied (buffer_wbl2) -- this kernel has just written the whole gx tensor, and 2048 blocks
+    // each flushing it made the launch 5x slower (827 us instead of 170 us on the C2 maps, profiles/r06).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int drawn = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_acc[EP_THREADS] = (drawn == (int)gridDim.x - 1) ? 1.0f : 0.0f;
     }
     __syncthreads();
     if (s_acc[EP_THREADS] == 0.0f) return;
-    // ---- last arriver: gbias[c] = sum over blocks of partial[block][c], rows read whole (coalesced), lanes folded in lane order
-    if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
-    }
-    __syncthreads();
+    // ---- last arriver: gbias[c] = sum over blocks of partial[block][c]; the rows are read with sc1 loads (served by memory / the fabric, never
+    // by this CU's L1 or a stale line of this XCD's L2), whole rows at a time, lanes folded in lane order
+    if (t == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this stream
     const long long nb = gridDim.x;
     if (ktiles == 1) {
         const int lanes = ppb * C;
         const int pl = t / C, c = t - pl * C;
         float acc = 0.0f;
-        if (t < lanes)
-            for (long long b = pl; b < nb; b += ppb) acc = acc + partial[b * C + c];
+        if (t < lanes) {
+            // eight independent sc1 loads in flight per lane (each is a ~2 us trip to memory; one at a time the 2048 rows cost 700 us)
+            long long b = pl;
+            for (; b + 7LL * ppb < nb; b += 8LL * ppb) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = load_partial(partial + (b + (long long)u * ppb) * C + c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = acc + v[u];
+            }
+            for (; b < nb; b += ppb) acc = acc + load_partial(partial + b * C + c);
+        }
         __syncthreads();
         s_acc[t] = acc;
         __syncthreads();
@@ -196,7 +212,15 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
     } else {
         for (int c = t; c < C; c += EP_THREADS) {
             float sum = 0.0f;
-            for (long long b = 0; b < nb; ++b) sum = sum + partial[b * C + c];
+            long long b = 0;
+            for (; b + 7 < nb; b += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = load_partial(partial + (b + u) * C + c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum = sum + v[u];
+            }
+            for (; b < nb; ++b) sum = sum + load_partial(partial + b * C + c);
             gbias[c] = sum;
         }
     }

@@ -384,7 +384,8 @@ def _stride1_grads(x, w, padding, gy, need_x, need_w):
     return gx, gw
 
 
-BIAS_GRAD_IN_LAUNCH = True      # module switch (A/B): the bias gradient's second stage inside the backward epilogue's launch (mdt_bias_act_backward_ticket)
+BIAS_GRAD_IN_LAUNCH = False     # module switch (A/B): the bias gradient's second stage inside the backward epilogue's launch (mdt_bias_act_backward_ticket).
+                                # MEASURED NEGATIVE (profiles/r06/r06_bias_grad_in_launch_probe.txt): the last block reads the partial rows at the cross-XCD rate
 _TICKET = {}                    # device -> int32[1], zero between launches
 
 

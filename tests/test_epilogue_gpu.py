@@ -58,7 +58,7 @@ def test_bias_grad_second_stage_inside_the_launch(shape, cuda):
     y = torch.randn(shape, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
     want = (gy.double() * (y > 0)).sum((0, 2, 3, 4))
     scale = (gy.double().abs() * (y > 0)).sum((0, 2, 3, 4)) + 1.0
-    assert fe.BIAS_GRAD_IN_LAUNCH
+    prev_flag, fe.BIAS_GRAD_IN_LAUNCH = fe.BIAS_GRAD_IN_LAUNCH, True
     first = None
     for it in range(20):
         gx, gb = fe._bias_act_bwd(gy, y, True, torch.channels_last_3d)
@@ -74,7 +74,7 @@ def test_bias_grad_second_stage_inside_the_launch(shape, cuda):
     try:
         _, gb2 = fe._bias_act_bwd(gy, y, True, torch.channels_last_3d)
     finally:
-        fe.BIAS_GRAD_IN_LAUNCH = True
+        fe.BIAS_GRAD_IN_LAUNCH = prev_flag
     assert float(((gb2.double() - first.double()).abs() / scale).max()) <= 2e-6
 
 

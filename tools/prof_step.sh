@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 STEPS=${1:-5}
 BENCH_ARGS=${BENCH_ARGS:-}
-mkdir -p $ROOT/gpurun_out
+mkdir -p $ROOT/gpurun_out $ROOT/gpurun_out/$(dirname ${OUT_NAME:-x}) $ROOT/gpurun_out/$(dirname ${GLUE_OUT:-x})
 cd /tmp && export TMPDIR=/tmp
 rm -rf $ROOT/gpurun_out/prof_step
 timeout ${2:-420} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_step -o step -- python $ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-h2d-leg --no-rccl-selftest --no-dense-rpn-leg $BENCH_ARGS > $ROOT/gpurun_out/prof_step.log 2>&1 < /dev/null
