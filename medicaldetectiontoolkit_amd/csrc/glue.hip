@@ -57,20 +57,26 @@ __global__ __launch_bounds__(GL_THREADS) void roi_levels_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------------------------------- block-wide selection
-// One round: every thread scans its strided slots of s[0 .. n) for the largest value (lower slot wins ties), the block reduces, the winner
-// is removed (marked -3).  Returns the winner through s_red; all threads leave with the same (value, slot).
+// The k best of s[0 .. n), best first.  Thread t owns the slots j = t (mod 256) and keeps the best of them in registers; a round reduces
+// these 256 candidates over the block (lower slot wins ties), the owner of the winner marks it removed (-3) and rescans ITS slots only --
+// nobody else reads them, so a round costs one block reduction (two barriers), not a pass over the buffer.
 struct Best { float v; int i; };
 
 __device__ __forceinline__ Best better(Best a, Best b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
 
-__device__ __forceinline__ Best block_argmax(const float *s, int n, float *s_red_v, int *s_red_i)
+__device__ __forceinline__ Best scan_own(const float *s, int n)
 {
-    const int t = threadIdx.x;
     Best m{-4.0f, 0x7fffffff};
-    for (int j = t; j < n; j += GL_THREADS) {
+    for (int j = threadIdx.x; j < n; j += GL_THREADS) {
         const float v = s[j];
         if (v > m.v) { m.v = v; m.i = j; }                   // ascending j: the first maximum stays
     }
+    return m;
+}
+
+__device__ __forceinline__ Best block_best(Best m, float *s_red_v, int *s_red_i)
+{
+    const int t = threadIdx.x;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         Best o;
@@ -88,17 +94,18 @@ __device__ __forceinline__ Best block_argmax(const float *s, int n, float *s_red
     return r;
 }
 
-// the k best of s[0 .. n), best first, into (out_v, out_i) through `emit(rank, value, slot)`; values < 0 count as "none": the remaining ranks
-// get (-1, slot 0).  s is consumed.
+// `emit(rank, value, slot)` for the k best (thread 0 calls it, in rank order); values < 0 count as "none": the remaining ranks get
+// emit(rank, -1, -1) from some thread.  s is consumed; callers must have synchronised after filling it.
 template <typename Emit>
 __device__ __forceinline__ void block_select(float *s, int n, int k, float *s_red_v, int *s_red_i, Emit emit)
 {
+    Best mine = scan_own(s, n);
     int r = 0;
     for (; r < k; ++r) {
-        const Best b = block_argmax(s, n, s_red_v, s_red_i);
+        const Best b = block_best(mine, s_red_v, s_red_i);
         if (!(b.v >= 0.0f)) break;
-        if (threadIdx.x == 0) { emit(r, b.v, b.i); s[b.i] = -3.0f; }
-        __syncthreads();
+        if (threadIdx.x == 0) emit(r, b.v, b.i);
+        if ((b.i % GL_THREADS) == (int)threadIdx.x) { s[b.i] = -3.0f; mine = scan_own(s, n); }
     }
     for (int q = r + threadIdx.x; q < k; q += GL_THREADS) emit(q, -1.0f, -1);
     __syncthreads();

@@ -89,6 +89,8 @@ struct V3Params {
     float inv_psum, inv_pd;            // 1 / psum, 1 / pd (division-free index math)
     int off_hdr, off_rbox, off_bb, off_misc;
     long long *ts;                     // tuning only (mdt_debug_bwd3): wall-clock stamps of scatter workgroup `dbg_wg`, or null
+    int accum;                         // 1: a LATER chunk of a launch series over more than V3_MAXR RoIs: no zero stores anywhere, every territory quad is
+                                       //    read-modify-written on top of what the earlier chunks left (round 6)
     int dbg, dbg_wg;                   // tuning only: bit0 scatter role returns at once, bit1 zero role returns at once, bit3 zero role skips its box loads, bit4 zero role stores non-temporally
     V3Level lev[V3_MAX_LEVELS];
 };
@@ -633,7 +635,7 @@ __device__ __forceinline__ void scatter_role(const V3Params &p, const unsigned b
                 const int Q = ufl(h[6]) + quad;                     // absolute 16-byte unit within the row
                 const int sg = (Q * 4) >> ufl(lv.S_shift);
                 const bool shared = ufl(h[13]) != 0;
-                bool rmw = false;
+                bool rmw = p.accum != 0;
                 if (shared) {
                     const int ssh = ufl(lv.S_shift);
 #pragma unroll 4
@@ -687,7 +689,7 @@ __device__ __forceinline__ void scatter_role(const V3Params &p, const unsigned b
     const v4f z4 = {0.f, 0.f, 0.f, 0.f};
     for (int li = 0; li < p.n_levels; ++li) {
         const V3Level &lv = slev[li];
-        if (!lv.merged) continue;
+        if (!lv.merged || p.accum) continue;
         const int cpr = (lv.upr + 7) >> 3;                          // runs per row
         const float inv_cpr = 1.0f / (float)cpr, inv_W = 1.0f / (float)lv.W;
         v4f *base = reinterpret_cast<v4f *>(lv.out + (long long)vol * lv.R * lv.L);
@@ -788,9 +790,32 @@ namespace mdt_ra {
 
 // Plans and launches the gather-form backward over n_levels maps.  MDT_ERR_UNSUPPORTED: the shape is outside this
 // kernel's budgets (the caller falls back to the round-2 territory kernel / the two-kernel form / the ordered kernel).
+static int launch_bwd_gather_chunk(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
+                                   int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
+                                   float *const *outs, hipStream_t s, int accum);
+
+// More than V3_MAXR RoIs (round 6; before: MDT_ERR_UNSUPPORTED and the ~15x slower exact-order kernel): a series of launches over chunks of
+// V3_MAXR RoIs -- the first writes every byte of the maps (zeros included), the later ones run without any zero role and read-modify-write
+// the quads their RoIs touch.  Same arithmetic per RoI; the sum over RoIs of different chunks is taken in chunk order (deterministic).
 int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
                       int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
                       float *const *outs, hipStream_t s)
+{
+    if (N <= V3_MAXR) return launch_bwd_gather_chunk(dim, n_levels, grads, boxes, batch_ix, level, N, B, C, H, W, D, ph, pw, pd, outs, s, 0);
+    if (dim != 2 && dim != 3) return MDT_ERR_INVALID_ARGUMENT;
+    const long long P = (long long)ph * pw * pd;                 // (2D callers pass pd = 1)
+    for (int n0 = 0; n0 < N; n0 += V3_MAXR) {
+        const int n = (N - n0 < V3_MAXR) ? (N - n0) : V3_MAXR;
+        const int rc = launch_bwd_gather_chunk(dim, n_levels, grads + (long long)n0 * C * P, boxes + (long long)n0 * 2 * dim, batch_ix + n0,
+                                               level ? level + n0 : nullptr, n, B, C, H, W, D, ph, pw, pd, outs, s, n0 > 0 ? 1 : 0);
+        if (rc != MDT_OK) return (n0 == 0) ? rc : MDT_ERR_LAUNCH_FAILED;      // (a shape outside the budgets fails on the FIRST chunk, before anything was written)
+    }
+    return MDT_OK;
+}
+
+static int launch_bwd_gather_chunk(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
+                                   int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
+                                   float *const *outs, hipStream_t s, int accum)
 {
     if (dim != 2 && dim != 3) return MDT_ERR_INVALID_ARGUMENT;
     if (n_levels < 1 || n_levels > V3_MAX_LEVELS) return MDT_ERR_UNSUPPORTED;
@@ -798,7 +823,7 @@ int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *bo
     if (N > V3_MAXR) return MDT_ERR_UNSUPPORTED;
     V3Params p;
     p.grads = grads; p.boxes = boxes; p.box_ind = batch_ix; p.level = level;
-    p.dim = dim; p.N = N; p.B = B; p.C = C; p.n_levels = n_levels;
+    p.dim = dim; p.N = N; p.B = B; p.C = C; p.n_levels = n_levels; p.accum = accum;
 #ifdef MDT_TUNING_HOOKS
     p.ts = g_v3_ts; p.dbg = g_v3_dbg; p.dbg_wg = g_v3_dbg_wg;
 #else
@@ -876,7 +901,7 @@ int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *bo
     long long big_rows_bytes = 0;
     for (int l = 0; l < n_levels; ++l) if (!p.lev[l].merged) big_rows_bytes += (long long)p.lev[l].R * p.lev[l].L;
     unsigned zrun = 0;
-    if (big_rows_bytes > 0) {
+    if (big_rows_bytes > 0 && !accum) {
         const int cus = cu_count();
         long long budget = (long long)resident_per_cu(lds) * cus - (long long)p.n_scatter;
         if (budget < cus / 2) budget = cus;

@@ -27,4 +27,9 @@ def cuda():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
+    # MIOpen reads its find-db / kernel-cache paths and solver switches ONCE, at its first convolution: point it at the repository's cache before
+    # any test runs one (a test module that convolved first used to leave every later `miopen_env.setup()` without effect -- the Retina U-Net
+    # step at the benchmarked size then spent 7.5 min in an uncached exhaustive find)
+    from medicaldetectiontoolkit_amd import miopen_env
+    miopen_env.setup()
     return torch.device("cuda:0")

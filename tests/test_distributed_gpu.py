@@ -168,3 +168,35 @@ def test_bench_rank_code_path_world4_gloo(cuda):
     assert rec["distributed"]["params_identical_across_ranks"] is True
     assert rec["distributed"]["grad_buckets"] == 4 and len(rec["distributed"]["devices"]) == 4
     assert rec["config"]["global_batch"] == 8 and rec["value"] > 0
+
+
+def test_bench_rank_path_world8_host_cpu_does_not_grow_with_the_rank_count(cuda):
+    """VERDICT r5 next 10 (multi-GPU readiness without the hardware): bench.py's own rank path at world 8 (gloo, the eight ranks share the one
+    GPU of the test box, each pinned to its slice of cores by utils/affinity.py) against world 1 on the same box, a small patch so that the
+    shared GPU is not what the ranks wait for.  What eight ranks on one host compete for is CPU: the line records, as the maximum over ranks,
+    the CPU time (all threads of a rank) spent issuing a step (`host_cpu_ms_per_step_max_over_ranks`).  Required: world 8 <= 1.3 x world 1
+    (+ 1 ms), identical parameters on all ranks, eight devices entries.  Eager steps (--graph 0): the launch-by-launch host path is the
+    expensive one; the graphed step needs ~4.5 ms of host work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if (os.cpu_count() or 1) < 16:
+        pytest.skip("fewer than 16 host cores: eight ranks cannot have two cores each")
+    env = dict(os.environ)
+    env["MDT_MIOPEN_SKIP_NAIVE"] = "1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--backend", "gloo", "--steps", "6", "--warmup", "3", "--patch", "32,32,16", "--batch", "2", "--graph", "0", "--no-secondary", "--no-cpu-baseline",
+              "--no-roofline", "--no-h2d-leg", "--no-exec-leg", "--no-eager-leg", "--no-graph-leg", "--no-dense-rpn-leg", "--no-rccl-selftest"]
+    recs = {}
+    for world in (1, 8):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world)] + common, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert r.returncode == 0 and lines, (world, r.returncode, r.stderr[-1500:])
+        recs[world] = json.loads(lines[-1])
+    d1, d8 = recs[1]["distributed"], recs[8]["distributed"]
+    assert recs[8]["n_gpus"] == 8 and d8["world"] == 8 and len(d8["devices"]) == 8 and d8["params_identical_across_ranks"] is True
+    assert d8["rank0_core_affinity"] and d8["rank0_core_affinity"].get("pinned"), d8["rank0_core_affinity"]
+    c1, c8 = d1["host_cpu_ms_per_step_max_over_ranks"], d8["host_cpu_ms_per_step_max_over_ranks"]
+    assert c1 > 0 and c8 <= 1.3 * c1 + 1.0, "host CPU per step: world 1 %.2f ms, world 8 (max over ranks) %.2f ms on %s cores" % (c1, c8, d8["host_cores"])
