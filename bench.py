@@ -763,6 +763,17 @@ def main():
             consumed[0] += len(r["logger_string"]) + len(r["boxes"]) + len(r["monitor_values"])
         return r
 
+    coll_cpu = [0.0]                   # issue-thread CPU seconds spent inside the gradient collective (launch + wait): reported apart -- with the gloo debug
+    if sync is not None:               # backend that is a CPU reduction of the 20 MB buffer, not a property of the RCCL path
+        for name in ("finish", "finish_all"):
+            def timed(_orig=getattr(sync, name)):
+                c0 = time.thread_time()
+                try:
+                    return _orig()
+                finally:
+                    coll_cpu[0] += time.thread_time() - c0
+            setattr(sync, name, timed)
+
     for i in range(max(args.warmup, 1 if use_graph else 0)):
         run_step(pool[i % len(pool)])
     barrier()
@@ -772,7 +783,9 @@ def main():
     else:
         _roi_align_impl.PROFILE = []          # the RoIAlign backward launches of the timed steps, event-timed (roofline in-step variant)
     counts = []                        # (valid, positive) sampled RoIs of every timed step: device scalars, read after the timed region
-    cpu0 = time.process_time()         # CPU seconds of ALL threads of this rank (issue thread, autograd engine, prefetcher): what N ranks on one host compete for
+    cpu0 = time.process_time()         # CPU seconds of ALL threads of this rank (issue thread, autograd engine, OpenMP / collective helper threads)
+    thr0 = time.thread_time()          # CPU seconds of the ISSUE thread alone: the Python + launch work of a step, what must not grow with the rank count
+    coll0 = coll_cpu[0]
     t0 = time.time()
     for i in range(args.steps):
         r_i = run_step(pool[i % len(pool)])
@@ -780,6 +793,8 @@ def main():
             counts.append(r_i["sample_counts"])
     host_issue = time.time() - t0      # the host has launched everything (it runs ahead of the GPU while the step is GPU-bound)
     host_cpu = time.process_time() - cpu0
+    host_thr = time.thread_time() - thr0
+    host_coll = coll_cpu[0] - coll0
     barrier()
     elapsed = time.time() - t0
     timed_batches = None
@@ -933,10 +948,10 @@ def main():
         except Exception as e:
             exec_eq = {"failed": repr(e)[:300]}
 
-    t = torch.tensor([elapsed, host_issue, host_cpu], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, host_issue, host_cpu, host_thr - host_coll, host_coll], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, host_issue_max, host_cpu_max = (float(v) for v in t.tolist())
+    elapsed, host_issue_max, host_cpu_max, host_thr_max, host_coll_max = (float(v) for v in t.tolist())
     # post-step parameters: one checksum per rank; identical weights on every rank <=> min == max
     with torch.no_grad():
         csum = torch.stack([p.detach().double().sum() for p in net.parameters()]).sum().reshape(1)
@@ -951,9 +966,13 @@ def main():
                 "param_checksum": float(cmin.item()), "params_identical_across_ranks": bool(cmin.item() == cmax.item()),
                 "grad_buckets": (len(sync.bucket_range) if sync is not None and sync.flat is not None else None),
                 "rank0_core_affinity": affinity_rec,
-                # max over ranks: wall time until a rank had issued its timed steps, and the CPU time (all threads) it burnt doing so -- with N ranks
-                # on one host the second must not grow with N (tests/test_distributed_gpu.py compares world 8 with world 1 on one box)
+                # max over ranks, per timed step: wall time until the rank had issued the step; CPU time of its ISSUE thread (Python + launches: the
+                # per-rank host work, which must not grow with N -- tests/test_distributed_gpu.py compares world 8 with world 1 on one box); CPU
+                # time of ALL its threads (includes OpenMP workers spinning in their pinned slice and, with the gloo debug backend, the collective's
+                # CPU reduction: not a property of the RCCL path)
                 "host_issue_ms_per_step_max_over_ranks": round(host_issue_max / args.steps * 1e3, 2),
+                "host_issue_thread_cpu_ms_per_step_max_over_ranks": round(host_thr_max / args.steps * 1e3, 2),        # (without the collective, next entry)
+                "collective_issue_thread_cpu_ms_per_step_max_over_ranks": round(host_coll_max / args.steps * 1e3, 2),
                 "host_cpu_ms_per_step_max_over_ranks": round(host_cpu_max / args.steps * 1e3, 2),
                 "host_cores": os.cpu_count()}
 
