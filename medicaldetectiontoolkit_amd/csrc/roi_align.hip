@@ -595,7 +595,7 @@ int launch_bwd(const float *grads, const float *boxes, const int *box_ind, int N
 
 // the single-launch gather kernel walks the RoIs of one batch element inside one workgroup: right for the training call sites (<= 6 RoIs
 // per element, mrcnn.py:1075; lidc configs.py:258); beyond this many RoIs the exact-order kernel takes over
-constexpr int BWD_GATHER_MAX_BOXES = 128;
+// (round 6: no RoI-count limit in the dispatch any more -- launch_bwd_gather chunks above 128 RoIs itself)
 
 }  // namespace
 
@@ -683,7 +683,7 @@ size_t mdt_crop_and_resize_backward_workspace_bytes(int dim, int num_boxes, int 
 }
 
 // ONE default backward (the round-3 gather kernel, roi_align_bwd_v3.hip: single launch, no workspace, deterministic) and the exact-order
-// kernel above for what is outside its budgets (more than 128 RoIs, very large pool extents): any shape, bit-exact against the
+// kernel above for what is outside its budgets (very large pool extents, map rows that are not a multiple of 8 floats): any shape, bit-exact against the
 // sequential oracle, slower.  The round-1 two-kernel form and the round-2 territory kernel are A/B history: libmdt_hip_ab.so.
 int mdt_crop_and_resize_3d_backward(const float *grads, const float *boxes, const int *box_ind,
                                     int num_boxes, int batch, int H, int W, int D,
@@ -691,7 +691,7 @@ int mdt_crop_and_resize_3d_backward(const float *grads, const float *boxes, cons
                                     float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
 {
     (void)workspace; (void)workspace_bytes;
-    if (num_boxes <= BWD_GATHER_MAX_BOXES) {
+    {       // any RoI count: beyond BWD_GATHER_MAX_BOXES the gather kernel runs as a series of chunk launches (roi_align_bwd_v3.hip, round 6)
         const int rg = launch_bwd_gather(3, 1, grads, boxes, box_ind, nullptr, num_boxes, batch, depth, &H, &W, &D, ch, cw, cd,
                                          &grads_image, (hipStream_t)stream);
         if (rg != MDT_ERR_UNSUPPORTED) return rg;
@@ -705,7 +705,7 @@ int mdt_crop_and_resize_2d_backward(const float *grads, const float *boxes, cons
                                     float *grads_image, void *workspace, size_t workspace_bytes, void *stream)
 {
     (void)workspace; (void)workspace_bytes;
-    if (num_boxes <= BWD_GATHER_MAX_BOXES) {
+    {
         const int one = 1;
         const int rg = launch_bwd_gather(2, 1, grads, boxes, box_ind, nullptr, num_boxes, batch, depth, &H, &W, &one, ch, cw, 1,
                                          &grads_image, (hipStream_t)stream);
@@ -736,7 +736,6 @@ int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, co
     if (dim != 2 && dim != 3) return MDT_ERR_INVALID_ARGUMENT;
     if (num_boxes < 0 || batch <= 0 || depth <= 0 || ch <= 0 || cw <= 0 || (dim == 3 && cd <= 0)) return MDT_ERR_INVALID_ARGUMENT;
     if (dim == 2) cd = 1;
-    if (num_boxes > BWD_GATHER_MAX_BOXES) return MDT_ERR_UNSUPPORTED;      // (the Python side then runs one default backward per level)
     return launch_bwd_gather(dim, n_levels, grads, boxes, batch_ix, level, num_boxes, batch, depth, H, W, D, ch, cw, cd, grads_images, s);
 }
 
