@@ -290,13 +290,14 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, in_step_prof48=None, lau
         head["traffic"] = None
         head["median_us"] = None
         try:        # PMC bytes of THIS launch in training steps with full RoI heads (tools/r05_instep_profile.sh, offline)
-            ti = json.load(open(os.path.join(ROOT, "profiles", "r05", "traffic_instep.json")))["in_training_step_heads_full"]
+            tdir = "r06" if os.path.exists(os.path.join(ROOT, "profiles", "r06", "traffic_instep.json")) else "r05"
+            ti = json.load(open(os.path.join(ROOT, "profiles", tdir, "traffic_instep.json")))["in_training_step_heads_full"]
             head["traffic"] = ti["hbm_bytes"]
             head["traffic_detail"] = {k: ti.get(k) for k in ("write_kb", "fetch_kb", "fill_write_kb_calibration", "algorithmic_bytes", "valid_rois",
                                                                 "rocprofv3_kernel_us_mean")}
-            instep_traffic_source = ("OFFLINE measurement, not part of this run: profiles/r05/traffic_instep.json -- rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in "
+            instep_traffic_source = ("OFFLINE measurement, not part of this run: profiles/" + tdir + "/traffic_instep.json -- rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE in "
                                      "separate passes over tools/instep_heads_full.py (training steps with full RoI heads, the mask head's pyramid backward launch), "
-                                     "FETCH_SIZE doubled (gfx950), WRITE_SIZE calibrated on a 150 994 944-byte fill of the same pass (tools/r05_instep_profile.sh)")
+                                     "FETCH_SIZE doubled (gfx950), WRITE_SIZE calibrated on a 150 994 944-byte fill of the same pass (tools/instep_profile.sh)")
         except Exception:
             instep_traffic_source = None
         kernel_desc = ("crop_bwd_gather_kernel (mdt_pyramid_roi_align_backward, csrc/roi_align_bwd_v3.hip) AS IT RAN INSIDE TRAINING STEPS: the mask head's "

@@ -9,11 +9,12 @@ import os
 import sys
 
 trace, wcsv, fcsv, out, steps, meta = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), sys.argv[6]
+ROUND = sys.argv[7] if len(sys.argv) > 7 else "r05"
 os.makedirs(out, exist_ok=True)
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
 bwd = [r for r in rows if "crop_bwd_gather_kernel" in r["Kernel_Name"]]
 bwd = bwd[-2 * steps:]                       # the profiled steps: two launches each (mask head first, classifier second)
-with open(os.path.join(out, "r05_instep_heads_full_roialign_bwd_launches.csv"), "w") as f:
+with open(os.path.join(out, "%s_instep_heads_full_roialign_bwd_launches.csv" % ROUND), "w") as f:
     f.write("# crop_bwd_gather_kernel launches of the last %d training steps of tools/instep_heads_full.py (RoI heads full), rocprofv3 --kernel-trace\n" % steps)
     f.write("step,which,duration_us,grid,workgroup,lds_bytes,vgprs\n")
     for i, r in enumerate(bwd):
