@@ -619,6 +619,7 @@ def main():
     ap.add_argument("--fused-glue", type=int, default=1, help="1 (default): level rule, RPN sampling, box targets, detection target layer, refine_detections and the sampled-anchor gather as single launches of csrc/glue.hip; 0: chains of small tensor operations (A/B)")
     ap.add_argument("--bias-grad-in-launch", type=int, default=0, help="1: the bias gradient's second stage inside the backward epilogue's launch (measured slower, profiles/r06/r06_bias_grad_in_launch_probe.txt); 0 (default): separate finish launch")
     ap.add_argument("--flip-batched", type=int, default=1, help="1 (default): all flipped filters of a step from one launch; 0: one launch per layer (A/B)")
+    ap.add_argument("--shared-pyramid-grad", type=int, default=1, help="1 (default): one gradient buffer per pyramid map for the two RoIAlign backward launches and the sampled-anchor RPN scatter (PyramidGradAccumulator); 0: three dense gradients added by autograd (A/B)")
     ap.add_argument("--pool-cl", type=int, default=1, help="1 (default): channels-last max pooling kernel of the stem (csrc/pool.hip); 0: torch (A/B)")
     ap.add_argument("--pin-cores", type=int, default=1, help="N > 1: 1 (default) pins every rank to its own slice of the cores of its GPU's NUMA node (utils/affinity.py); 0: only caps the intra-op threads")
     ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
@@ -697,6 +698,7 @@ def main():
     mrcnn.MERGE_RPN_HEADS = bool(args.merge_rpn_heads)
     mrcnn.SPARSE_RPN_LOSS = bool(args.sparse_rpn_loss)
     mrcnn.FUSED_GLUE = bool(args.fused_glue)
+    mrcnn.SHARED_PYRAMID_GRAD = bool(args.shared_pyramid_grad)
     fused_epilogue.BIAS_GRAD_IN_LAUNCH = bool(args.bias_grad_in_launch)
     fused_epilogue.FLIP_BATCHED = bool(args.flip_batched)
 

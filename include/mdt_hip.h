@@ -136,6 +136,12 @@ int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, co
                                    const int *level, int num_boxes, int batch, int depth, const int *H, const int *W,
                                    const int *D, int crop_height, int crop_width, int crop_zdepth,
                                    float *const *grads_images, void *stream);
+/* The same ON TOP of what the maps already hold (another RoI head's gradient written by an earlier launch): nothing is zero-filled, the quads the
+ * RoIs touch are read-modify-written.  Two heads pooling one pyramid cost one full write of the maps, not two plus a dense add. */
+int mdt_pyramid_roi_align_backward_accumulate(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix,
+                                              const int *level, int num_boxes, int batch, int depth, const int *H, const int *W,
+                                              const int *D, int crop_height, int crop_width, int crop_zdepth,
+                                              float *const *grads_images, void *stream);
 
 /* Exact-order form: gather kernel that adds, per voxel, the terms in exactly the order a
  * sequential out_idx loop would (corner order of crop_and_resize_kernel.cu:256-301), so the
@@ -539,10 +545,11 @@ int mdt_detection_targets(const float *rois, int roi_stride, const float *scores
  * order of the concatenated pyramid levels ((y, x[, z], anchor) row-major per level), sample s belongs to batch element s / n_per_element.
  * gather: patches [S, 3^dim, C] = the voxel's neighbourhood on its own level (channels-last maps [B, Y, X, (Z), C]; zero outside the map),
  * k_anchor[s] = idx % anchors_per_voxel.  scatter_add: the adjoint -- adds grad_patches into the gradient maps (float atomics; the caller
- * zero-fills them or passes maps that already hold another gradient).  C % 4 == 0, 16-byte aligned maps. */
+ * zero-fills them or passes maps that already hold another gradient; row_major = 1: the maps are [B, C, Y, X, (Z)] row-major, the layout the RoIAlign
+ * backward writes, so that both can land in one buffer).  C % 4 == 0, 16-byte aligned maps. */
 int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
                          const long long *idx, int n_samples, int n_per_element, float *patches, long long *k_anchor, void *stream);
-int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps_cl, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
+int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps, int row_major, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
                               const long long *idx, int n_samples, int n_per_element, const float *grad_patches, void *stream);
 
 /* refine_detections (reference models/mrcnn.py:620-714) around the batched NMS.  pre: dets [B * fg, pc, 2 dim + 1] -- per (element, foreground

@@ -402,6 +402,7 @@ struct PatchParams {
     int Y[8], X[8], Z[8];
     long long start[9];                 // first anchor index of every level (+ total)
     int n_levels, dim, C, A, n_per_elem, S, T;
+    int row_major;                      // backward only: gradient maps in [B, C, Y, X, Z] storage (the RoIAlign backward's) instead of channels-last
     const long long *idx;               // [S] anchor index inside the element's concatenated levels
     float *patches;                     // [S, T, C]
     const float *gpatches;
@@ -442,8 +443,14 @@ __global__ __launch_bounds__(GL_THREADS) void rpn_patch_kernel(PatchParams p)
             *reinterpret_cast<v4 *>(p.patches + (r * C4 + c4) * 4) = val;
         } else if (ok) {
             const v4 g = *reinterpret_cast<const v4 *>(p.gpatches + (r * C4 + c4) * 4);
-            float *dst = p.gmaps[l] + row * p.C + 4 * c4;
-            atomicAdd(dst + 0, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); atomicAdd(dst + 3, g.w);
+            if (!p.row_major) {
+                float *dst = p.gmaps[l] + row * p.C + 4 * c4;
+                atomicAdd(dst + 0, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); atomicAdd(dst + 3, g.w);
+            } else {
+                const long long vox = (long long)Yl * Xl * Zl;
+                float *dst = p.gmaps[l] + ((long long)b * p.C + 4 * c4) * vox + ((long long)yy * Xl + xx) * Zl + zz;
+                atomicAdd(dst, g.x); atomicAdd(dst + vox, g.y); atomicAdd(dst + 2 * vox, g.z); atomicAdd(dst + 3 * vox, g.w);
+            }
         }
     }
 }
@@ -706,7 +713,7 @@ int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y
     if (n_samples == 0) return MDT_OK;
     for (int l = 0; l < n_levels; ++l) { p.maps[l] = maps_cl[l]; p.gmaps[l] = nullptr; if (((uintptr_t)maps_cl[l]) & 15) return MDT_ERR_UNSUPPORTED; }
     if (((uintptr_t)patches) & 15) return MDT_ERR_UNSUPPORTED;
-    p.patches = patches; p.gpatches = nullptr; p.k_anchor = k_anchor;
+    p.patches = patches; p.gpatches = nullptr; p.k_anchor = k_anchor; p.row_major = 0;
     const long long total = (long long)n_samples * p.T * (channels / 4);
     long long blocks = (total + GL_THREADS - 1) / GL_THREADS;
     if (blocks > 4096) blocks = 4096;
@@ -715,16 +722,16 @@ int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y
     return gl_check();
 }
 
-int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps_cl, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
+int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps, int row_major, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
                               const long long *idx, int n_samples, int n_per_element, const float *grad_patches, void *stream)
 {
     PatchParams p;
     const int rc = patch_params(&p, n_levels, dim, channels, anchors_per_voxel, Y, X, Z, idx, n_samples, n_per_element);
     if (rc != MDT_OK) return rc;
     if (n_samples == 0) return MDT_OK;
-    for (int l = 0; l < n_levels; ++l) { p.maps[l] = nullptr; p.gmaps[l] = grad_maps_cl[l]; }
+    for (int l = 0; l < n_levels; ++l) { p.maps[l] = nullptr; p.gmaps[l] = grad_maps[l]; }
     if (((uintptr_t)grad_patches) & 15) return MDT_ERR_UNSUPPORTED;
-    p.patches = nullptr; p.gpatches = grad_patches; p.k_anchor = nullptr;
+    p.patches = nullptr; p.gpatches = grad_patches; p.k_anchor = nullptr; p.row_major = row_major ? 1 : 0;
     const long long total = (long long)n_samples * p.T * (channels / 4);
     long long blocks = (total + GL_THREADS - 1) / GL_THREADS;
     if (blocks > 4096) blocks = 4096;

@@ -739,4 +739,16 @@ int mdt_pyramid_roi_align_backward(int dim, int n_levels, const float *grads, co
     return launch_bwd_gather(dim, n_levels, grads, boxes, batch_ix, level, num_boxes, batch, depth, H, W, D, ch, cw, cd, grads_images, s);
 }
 
+int mdt_pyramid_roi_align_backward_accumulate(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix,
+                                              const int *level, int num_boxes, int batch, int depth, const int *H, const int *W,
+                                              const int *D, int ch, int cw, int cd, float *const *grads_images, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dim != 2 && dim != 3) return MDT_ERR_INVALID_ARGUMENT;
+    if (num_boxes < 0 || batch <= 0 || depth <= 0 || ch <= 0 || cw <= 0 || (dim == 3 && cd <= 0)) return MDT_ERR_INVALID_ARGUMENT;
+    if (dim == 2) cd = 1;
+    if (num_boxes == 0) return MDT_OK;
+    return launch_bwd_gather_acc(dim, n_levels, grads, boxes, batch_ix, level, num_boxes, batch, depth, H, W, D, ch, cw, cd, grads_images, s, 1);
+}
+
 }  // extern "C"

@@ -801,13 +801,23 @@ int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *bo
                       int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
                       float *const *outs, hipStream_t s)
 {
-    if (N <= V3_MAXR) return launch_bwd_gather_chunk(dim, n_levels, grads, boxes, batch_ix, level, N, B, C, H, W, D, ph, pw, pd, outs, s, 0);
+    return launch_bwd_gather_acc(dim, n_levels, grads, boxes, batch_ix, level, N, B, C, H, W, D, ph, pw, pd, outs, s, 0);
+}
+
+// accumulate = 1: the maps already hold a gradient (another RoI head's, written by an earlier launch of this kernel): nothing is zero-filled, the
+// quads the RoIs touch are read-modify-written.  Two heads that pool the same pyramid then cost ONE full write of the maps instead of two
+// plus a dense add (round 6, cuda_functions/_roi_align_impl.PyramidGradAccumulator).
+int launch_bwd_gather_acc(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
+                          int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
+                          float *const *outs, hipStream_t s, int accumulate)
+{
+    if (N <= V3_MAXR) return launch_bwd_gather_chunk(dim, n_levels, grads, boxes, batch_ix, level, N, B, C, H, W, D, ph, pw, pd, outs, s, accumulate ? 1 : 0);
     if (dim != 2 && dim != 3) return MDT_ERR_INVALID_ARGUMENT;
     const long long P = (long long)ph * pw * pd;                 // (2D callers pass pd = 1)
     for (int n0 = 0; n0 < N; n0 += V3_MAXR) {
         const int n = (N - n0 < V3_MAXR) ? (N - n0) : V3_MAXR;
         const int rc = launch_bwd_gather_chunk(dim, n_levels, grads + (long long)n0 * C * P, boxes + (long long)n0 * 2 * dim, batch_ix + n0,
-                                               level ? level + n0 : nullptr, n, B, C, H, W, D, ph, pw, pd, outs, s, n0 > 0 ? 1 : 0);
+                                               level ? level + n0 : nullptr, n, B, C, H, W, D, ph, pw, pd, outs, s, (n0 > 0 || accumulate) ? 1 : 0);
         if (rc != MDT_OK) return (n0 == 0) ? rc : MDT_ERR_LAUNCH_FAILED;      // (a shape outside the budgets fails on the FIRST chunk, before anything was written)
     }
     return MDT_OK;

@@ -106,6 +106,9 @@ inline int check_launch()
 int launch_bwd_gather(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
                       int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
                       float *const *outs, hipStream_t s);
+int launch_bwd_gather_acc(int dim, int n_levels, const float *grads, const float *boxes, const int *batch_ix, const int *level,
+                      int N, int B, int C, const int *H, const int *W, const int *D, int ph, int pw, int pd,
+                      float *const *outs, hipStream_t s, int accumulate);
 
 }  // namespace mdt_ra
 

@@ -312,6 +312,104 @@ def pyramid_backward(grads, boxes, batch_ix, level, shapes, outs=None):
     return outs
 
 
+def pyramid_backward_accumulate(grads, boxes, batch_ix, level, shapes, outs):
+    """adds the RoIs' gradient to maps that already hold one (mdt_pyramid_roi_align_backward_accumulate); outside the kernel's budgets: a
+    separate backward + add"""
+    dim = len(shapes[0]) - 2
+    L = _lib.lib()
+    grads = grads.contiguous()
+    if grads.dtype != torch.float32:
+        grads = grads.float()
+    n = grads.size(0)
+    if n == 0:
+        return outs
+    crop = tuple(grads.shape[2:])
+    H, W, D = _level_dims(shapes, dim)
+    with torch.cuda.device(grads.device):
+        rc = L.mdt_pyramid_roi_align_backward_accumulate(dim, len(shapes), _lib.ptr(grads), _lib.ptr(boxes), _lib.ptr(batch_ix), _lib.ptr(level), n,
+                                                         shapes[0][0], shapes[0][1], H, W, D, crop[0], crop[1], crop[2] if dim == 3 else 1,
+                                                         _ptr_array(outs), _lib.current_stream_ptr())
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        for o, extra in zip(outs, pyramid_backward(grads, boxes, batch_ix, level, shapes)):
+            o.add_(extra)
+        return outs
+    _lib.check(rc, "mdt_pyramid_roi_align_backward_accumulate")
+    return outs
+
+
+class PyramidGradAccumulator(object):
+    """ONE gradient buffer per pyramid map for all its consumers of a training step (round 6).
+
+    The FPN outputs are read by the classifier head's RoIAlign, the mask head's RoIAlign and the sampled-anchor RPN evaluation.  Left to
+    autograd, each hands back a dense gradient per level and the engine adds them: the P2 map (151 MB at 8 x 128^3) is written three times
+    and summed twice (one of the adds between a row-major and a channels-last tensor: 125 us).  With an accumulator -- installed by
+    models/mrcnn.train_forward_device around the consumers, found by their autograd Functions through `CURRENT` -- the first RoIAlign
+    backward writes every byte of the buffers once (zeros included, as always), the second one runs in the kernel's accumulate mode
+    (read-modify-write of the quads its RoIs touch), the RPN patches are scatter-added as a few thousand rows, and whoever arrives LAST
+    returns the buffers to autograd; the others return None.  Sparse contributions that arrive before a dense one are kept and applied
+    after it.  The result is row-major [B, C, *spatial] like every RoIAlign gradient of this package.
+
+    Every registered consumer's backward MUST run in the backward pass (true for the step: all three branches reach the loss);
+    `check()` after the backward raises if one did not (its gradients would be missing silently)."""
+
+    CURRENT = None
+
+    def __init__(self, maps):
+        self.maps = list(maps)
+        self.expected = 0
+        self.arrived = 0
+        self.bufs = None
+        self.pending = []
+
+    def matches(self, maps):
+        return len(maps) == len(self.maps) and all(a is b for a, b in zip(maps, self.maps))
+
+    def register(self):
+        self.expected += 1
+
+    def _alloc(self):
+        self.bufs = [torch.empty(tuple(m.shape), dtype=torch.float32, device=m.device) for m in self.maps]
+
+    def _done(self):
+        self.arrived += 1
+        if self.arrived < self.expected:
+            return None
+        if self.bufs is None:                       # only sparse consumers: zero maps + their rows
+            self._alloc()
+            for b in self.bufs:
+                b.zero_()
+        for fn in self.pending:
+            fn(self.bufs)
+        self.pending = []
+        out, self.bufs = self.bufs, None
+        return out
+
+    def dense(self, launch):
+        """launch(bufs, accumulate) writes (accumulate False: every byte) or adds (True) a dense consumer's gradient"""
+        if self.bufs is None:
+            self._alloc()
+            launch(self.bufs, False)
+            for fn in self.pending:
+                fn(self.bufs)
+            self.pending = []
+        else:
+            launch(self.bufs, True)
+        return self._done()
+
+    def sparse(self, add):
+        """add(bufs) adds a few rows; deferred until a dense consumer has written the buffers"""
+        if self.bufs is None:
+            self.pending.append(add)
+        else:
+            add(self.bufs)
+        return self._done()
+
+    def check(self):
+        if self.arrived != self.expected:
+            raise RuntimeError("PyramidGradAccumulator: %d of %d consumers of the pyramid maps ran their backward -- the gradient of the FPN outputs is "
+                               "incomplete (a branch did not reach the loss); run the step without the accumulator" % (self.arrived, self.expected))
+
+
 class _PyramidRoIAlign(Function):
     @staticmethod
     def forward(ctx, boxes, batch_ix, level, crop, *maps):
@@ -332,11 +430,29 @@ class _PyramidRoIAlign(Function):
         ctx.shapes = [tuple(m.shape) for m in maps_c]
         ctx.dtypes = [m.dtype for m in maps]
         ctx.save_for_backward(boxes, batch_ix, level)
+        acc = PyramidGradAccumulator.CURRENT
+        ctx.acc = None
+        if acc is not None and acc.matches(maps) and any(ctx.needs_input_grad[4:]) and all(dt == torch.float32 for dt in ctx.dtypes):
+            acc.register()
+            ctx.acc = acc
         return crops
 
     @staticmethod
     def backward(ctx, grad_outputs):
         boxes, batch_ix, level = ctx.saved_tensors
+        if ctx.acc is not None:
+            shapes = ctx.shapes
+
+            def launch(bufs, accumulate):
+                if not accumulate:
+                    res = pyramid_backward(grad_outputs, boxes, batch_ix, level, shapes, outs=bufs)
+                    for l, r in enumerate(res):          # (outside the one-launch kernel's budgets the per-level fallback returns fresh tensors)
+                        if r is not bufs[l]:
+                            bufs[l].copy_(r)
+                else:
+                    pyramid_backward_accumulate(grad_outputs, boxes, batch_ix, level, shapes, bufs)
+            outs = ctx.acc.dense(launch)
+            return (None, None, None, None) + (tuple(outs) if outs is not None else (None,) * len(shapes))
         outs = pyramid_backward(grad_outputs, boxes, batch_ix, level, ctx.shapes)
         outs = [o if o.dtype == dt else o.to(dt) for o, dt in zip(outs, ctx.dtypes)]
         return (None, None, None, None) + tuple(outs)

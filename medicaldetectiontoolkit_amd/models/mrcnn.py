@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
+from ..cuda_functions import _roi_align_impl as _rai_mod
 from ..cuda_functions._roi_align_impl import pyramid_crop_and_resize
 from ..cuda_functions.roi_align_2D.roi_align.crop_and_resize import CropAndResizeFunction as ra2D
 from ..cuda_functions.roi_align_3D.roi_align.crop_and_resize import CropAndResizeFunction as ra3D
@@ -34,6 +35,8 @@ from . import backbone as backbone_module
 ############################################################
 HEAD_AS_LINEAR = True    # module switch (A/B: bench.py --head-as-linear 0): classifier-head convolutions as matrix products
 MERGE_RPN_HEADS = True   # module switch (A/B: bench.py --merge-rpn-heads 0): conv_class and conv_bbox of the RPN as ONE 1x1 convolution
+SHARED_PYRAMID_GRAD = True   # module switch (A/B: bench.py --shared-pyramid-grad 0): the RoI heads' RoIAlign backward launches and the sampled-anchor RPN scatter write
+                             # ONE gradient buffer per pyramid map (cuda_functions/_roi_align_impl.PyramidGradAccumulator) instead of three that autograd adds
 FUSED_GLUE = True        # module switch (A/B: bench.py --fused-glue 0): level rule, RPN sampling, box targets and the detection target layer as single
                          # launches of csrc/glue.hip instead of chains of small tensor operations (same arithmetic, same random keys)
 SPARSE_RPN_LOSS = True   # module switch (A/B: bench.py --sparse-rpn-loss 0): RPN losses differentiate through the SAMPLED anchors only
@@ -130,6 +133,11 @@ class _RpnPatches(torch.autograd.Function):
         ctx.save_for_backward(idx_flat)
         ctx.meta = (int(A), int(n_per_elem), dim, C, [tuple(m.shape) for m in maps], (Y, X, Z))
         ctx.mark_non_differentiable(k_anchor)
+        acc = _rai_mod.PyramidGradAccumulator.CURRENT        # one gradient buffer per map for all consumers of the step (see there)
+        ctx.acc = None
+        if acc is not None and acc.matches(maps) and any(ctx.needs_input_grad[3:]):
+            acc.register()
+            ctx.acc = acc
         return patches, k_anchor
 
     @staticmethod
@@ -138,13 +146,19 @@ class _RpnPatches(torch.autograd.Function):
         idx_flat, = ctx.saved_tensors
         A, n_per_elem, dim, C, shapes, (Y, X, Z) = ctx.meta
         mf = torch.channels_last_3d if dim == 3 else torch.channels_last
-        outs = [torch.empty(sh, dtype=torch.float32, device=g.device, memory_format=mf).zero_() for sh in shapes]
         g = g.contiguous()
-        ptrs = (ctypes.c_void_p * len(outs))(*[_lib.ptr(o) for o in outs])
-        with torch.cuda.device(g.device):
-            rc = _lib.lib().mdt_rpn_patch_scatter_add(len(outs), ptrs, Y, X, Z, dim, C, A, _lib.ptr(idx_flat), int(idx_flat.shape[0]), n_per_elem, _lib.ptr(g),
-                                                      _lib.current_stream_ptr())
-        _lib.check(rc, "mdt_rpn_patch_scatter_add")
+
+        def scatter(outs, row_major):
+            ptrs = (ctypes.c_void_p * len(outs))(*[_lib.ptr(o) for o in outs])
+            with torch.cuda.device(g.device):
+                rc = _lib.lib().mdt_rpn_patch_scatter_add(len(outs), ptrs, 1 if row_major else 0, Y, X, Z, dim, C, A, _lib.ptr(idx_flat), int(idx_flat.shape[0]),
+                                                          n_per_elem, _lib.ptr(g), _lib.current_stream_ptr())
+            _lib.check(rc, "mdt_rpn_patch_scatter_add")
+        if ctx.acc is not None:         # into the step's shared (row-major) buffers, after a RoIAlign backward has written them
+            outs = ctx.acc.sparse(lambda bufs: scatter(bufs, True))
+            return (None, None, None) + (tuple(outs) if outs is not None else (None,) * len(shapes))
+        outs = [torch.empty(sh, dtype=torch.float32, device=g.device, memory_format=mf).zero_() for sh in shapes]
+        scatter(outs, False)
         return (None, None, None) + tuple(outs)
 
 
@@ -1075,6 +1089,21 @@ class net(nn.Module):
             img, with_masks=with_masks, rpn_graph=not sparse_rpn)
         if isinstance(gt_masks, mutils.StagedUpload):
             gt_masks = gt_masks.get()
+        acc = None
+        if SHARED_PYRAMID_GRAD and torch.is_grad_enabled() and sparse_rpn and self.rpn_feature_maps is not None and \
+                all(a is b for a, b in zip(self.mrcnn_feature_maps, self.rpn_feature_maps)) and all(m.requires_grad for m in self.mrcnn_feature_maps):
+            acc = _rai_mod.PyramidGradAccumulator(self.mrcnn_feature_maps)
+        self._pyramid_grad_acc = acc
+        _rai_mod.PyramidGradAccumulator.CURRENT = acc
+        try:
+            return self._train_forward_device_tail(img, gt_dev, gt_masks, B, sparse_rpn, rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid,
+                                                   detection_masks)
+        finally:
+            _rai_mod.PyramidGradAccumulator.CURRENT = None
+
+    def _train_forward_device_tail(self, img, gt_dev, gt_masks, B, sparse_rpn, rpn_class_logits, rpn_pred_deltas, proposal_boxes, detections, det_valid,
+                                   detection_masks):
+        cf = self.cf
         (mrcnn_class_logits, mrcnn_pred_deltas, mrcnn_pred_mask, target_class_ids, mrcnn_target_deltas, target_mask,
          sample_proposals, s_valid, s_pos) = self.loss_samples_forward(None, None, gt_masks, B, gt_dev=gt_dev)
 

@@ -458,6 +458,9 @@ def train_step(net, optimizer, batch, grad_sync=None, monitor=False):
     else:
         optimizer.zero_grad(set_to_none=True)
     results["torch_loss"].backward()
+    acc = getattr(net, "_pyramid_grad_acc", None)
+    if acc is not None:
+        acc.check()                      # every consumer of the pyramid maps handed its gradient to the shared buffers
     if grad_sync is not None:
         grad_sync.finish()
     optimizer.step()
@@ -556,6 +559,9 @@ class GraphedTrainStep(object):
             for p in self._params:
                 p.grad = None
         out["loss"].backward()
+        acc = getattr(net, "_pyramid_grad_acc", None)
+        if acc is not None:
+            acc.check()
         packed = net.monitor_pack(out) if self.monitor else None
         return out, packed
 

@@ -222,3 +222,38 @@ def test_refine_detections_fused_equals_the_tensor_form(dim, pc, case, cuda):
         assert int(vf[M:2 * M].sum()) == 0 and int(vf.sum()) > 0
     else:
         assert int(vf.sum()) >= B
+
+
+def test_shared_pyramid_gradient_equals_autograd_sum(cuda):
+    """PyramidGradAccumulator (round 6): the classifier head's and the mask head's RoIAlign backward and the sampled-anchor RPN scatter land in
+    ONE buffer per pyramid map (write once, accumulate, scatter) == the three dense gradients autograd adds.  Whole training step, both
+    forms from the same weights and batch: every loss term equal, every parameter gradient within fp32 summation order."""
+    from medicaldetectiontoolkit_amd.utils.synthetic_data import batch_with_gt_from_proposals, make_batch, to_device
+    patch, B = [64, 64, 32], 2
+    cf = Configs(dim=3, model="mrcnn", patch_size=patch, batch_size=B, channels_last=True)
+    torch.manual_seed(0)
+    net = mrcnn.net(cf, device=cuda)
+    b = batch_with_gt_from_proposals(net, cf, to_device(make_batch(patch, B, seed=5), cuda), cuda)
+    prev = mrcnn.SHARED_PYRAMID_GRAD
+    res = {}
+    try:
+        for shared in (True, False):
+            mrcnn.SHARED_PYRAMID_GRAD = shared
+            torch.manual_seed(11)
+            net.zero_grad(set_to_none=True)
+            out = net.train_forward(b, monitor=False)
+            out["torch_loss"].backward()
+            acc = net._pyramid_grad_acc
+            assert (acc is not None) == shared
+            if shared:
+                assert acc.expected == 3 and acc.arrived == 3
+                acc.check()
+            res[shared] = ({k: float(v) for k, v in out["loss_terms"].items()}, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+                           [int(v) for v in out["sample_counts"]])
+    finally:
+        mrcnn.SHARED_PYRAMID_GRAD = prev
+    assert res[True][0] == res[False][0] and res[True][2] == res[False][2] and res[True][2][1] > 0
+    assert set(res[True][1]) == set(res[False][1])
+    for n, g in res[True][1].items():
+        w = res[False][1][n]
+        assert torch.allclose(g, w, rtol=1e-4, atol=1e-6 * float(w.abs().max() + 1e-12)), (n, float((g - w).abs().max()), float(w.abs().max()))
