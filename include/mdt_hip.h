@@ -549,6 +549,12 @@ int mdt_detection_targets(const float *rois, int roi_stride, const float *scores
  * backward writes, so that both can land in one buffer).  C % 4 == 0, 16-byte aligned maps. */
 int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
                          const long long *idx, int n_samples, int n_per_element, float *patches, long long *k_anchor, void *stream);
+/* move_add: the deterministic way into maps that already hold a gradient -- a scatter_add (row_major = 0) first sums the rows into ZEROED channels-last
+ * side maps (exact for up to two rows per voxel, as a scatter into a fresh tensor always was), then this launch takes every touched voxel's sum out of the
+ * side maps by exchange with 0 (the first taker gets the sum, later ones 0; the side maps are all-zero again afterwards and can be kept for the next step)
+ * and adds it to the row-major maps: base + sum exactly once, independent of the launch order of the rows. */
+int mdt_rpn_patch_move_add(int n_levels, float *const *side_maps_cl, float *const *grad_maps_row_major, const int *Y, const int *X, const int *Z, int dim, int channels,
+                           int anchors_per_voxel, const long long *idx, int n_samples, int n_per_element, void *stream);
 int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps, int row_major, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
                               const long long *idx, int n_samples, int n_per_element, const float *grad_patches, void *stream);
 

@@ -398,11 +398,13 @@ __global__ __launch_bounds__(GL_THREADS) void detection_targets_kernel(DetTarget
 // (channels-last maps: a voxel is C contiguous floats), zero outside the map (the convolution's padding).  Forward = one launch of 16-byte
 // copies; backward = one launch of float atomics into the (zero-filled) gradient maps -- a few thousand rows, collisions are rare.
 struct PatchParams {
-    const float *maps[8]; float *gmaps[8];
+    const float *maps[8]; float *gmaps[8]; float *side[8];
     int Y[8], X[8], Z[8];
     long long start[9];                 // first anchor index of every level (+ total)
     int n_levels, dim, C, A, n_per_elem, S, T;
-    int row_major;                      // backward only: gradient maps in [B, C, Y, X, Z] storage (the RoIAlign backward's) instead of channels-last
+    int row_major;                      // backward only: 0 = add into channels-last maps; 1 = add into [B, C, Y, X, Z] row-major maps (the RoIAlign backward's layout);
+                                        // 2 = MOVE: take the sums a mode-0 launch left in the channels-last side maps (exchange with 0: whoever comes first gets the
+                                        // voxel's whole sum, the others get 0, the side maps end all-zero again) and add them to the row-major maps
     const long long *idx;               // [S] anchor index inside the element's concatenated levels
     float *patches;                     // [S, T, C]
     const float *gpatches;
@@ -442,14 +444,20 @@ __global__ __launch_bounds__(GL_THREADS) void rpn_patch_kernel(PatchParams p)
             if (ok) val = *reinterpret_cast<const v4 *>(p.maps[l] + row * p.C + 4 * c4);
             *reinterpret_cast<v4 *>(p.patches + (r * C4 + c4) * 4) = val;
         } else if (ok) {
-            const v4 g = *reinterpret_cast<const v4 *>(p.gpatches + (r * C4 + c4) * 4);
+            const v4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const v4 g = p.gpatches ? *reinterpret_cast<const v4 *>(p.gpatches + (r * C4 + c4) * 4) : zero4;
             if (!p.row_major) {
                 float *dst = p.gmaps[l] + row * p.C + 4 * c4;
                 atomicAdd(dst + 0, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); atomicAdd(dst + 3, g.w);
             } else {
+                v4 add = g;
+                if (p.row_major == 2) {
+                    float *src = p.side[l] + row * p.C + 4 * c4;
+                    add.x = atomicExch(src + 0, 0.0f); add.y = atomicExch(src + 1, 0.0f); add.z = atomicExch(src + 2, 0.0f); add.w = atomicExch(src + 3, 0.0f);
+                }
                 const long long vox = (long long)Yl * Xl * Zl;
                 float *dst = p.gmaps[l] + ((long long)b * p.C + 4 * c4) * vox + ((long long)yy * Xl + xx) * Zl + zz;
-                atomicAdd(dst, g.x); atomicAdd(dst + vox, g.y); atomicAdd(dst + 2 * vox, g.z); atomicAdd(dst + 3 * vox, g.w);
+                atomicAdd(dst, add.x); atomicAdd(dst + vox, add.y); atomicAdd(dst + 2 * vox, add.z); atomicAdd(dst + 3 * vox, add.w);
             }
         }
     }
@@ -711,7 +719,7 @@ int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y
     const int rc = patch_params(&p, n_levels, dim, channels, anchors_per_voxel, Y, X, Z, idx, n_samples, n_per_element);
     if (rc != MDT_OK) return rc;
     if (n_samples == 0) return MDT_OK;
-    for (int l = 0; l < n_levels; ++l) { p.maps[l] = maps_cl[l]; p.gmaps[l] = nullptr; if (((uintptr_t)maps_cl[l]) & 15) return MDT_ERR_UNSUPPORTED; }
+    for (int l = 0; l < n_levels; ++l) { p.maps[l] = maps_cl[l]; p.gmaps[l] = nullptr; p.side[l] = nullptr; if (((uintptr_t)maps_cl[l]) & 15) return MDT_ERR_UNSUPPORTED; }
     if (((uintptr_t)patches) & 15) return MDT_ERR_UNSUPPORTED;
     p.patches = patches; p.gpatches = nullptr; p.k_anchor = k_anchor; p.row_major = 0;
     const long long total = (long long)n_samples * p.T * (channels / 4);
@@ -722,6 +730,23 @@ int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y
     return gl_check();
 }
 
+int mdt_rpn_patch_move_add(int n_levels, float *const *side_maps_cl, float *const *grad_maps_row_major, const int *Y, const int *X, const int *Z, int dim, int channels,
+                           int anchors_per_voxel, const long long *idx, int n_samples, int n_per_element, void *stream)
+{
+    PatchParams p;
+    const int rc = patch_params(&p, n_levels, dim, channels, anchors_per_voxel, Y, X, Z, idx, n_samples, n_per_element);
+    if (rc != MDT_OK) return rc;
+    if (n_samples == 0) return MDT_OK;
+    for (int l = 0; l < n_levels; ++l) { p.maps[l] = nullptr; p.gmaps[l] = grad_maps_row_major[l]; p.side[l] = side_maps_cl[l]; }
+    p.patches = nullptr; p.gpatches = nullptr; p.k_anchor = nullptr; p.row_major = 2;
+    const long long total = (long long)n_samples * p.T * (channels / 4);
+    long long blocks = (total + GL_THREADS - 1) / GL_THREADS;
+    if (blocks > 4096) blocks = 4096;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rpn_patch_kernel<true>, dim3((unsigned)blocks), dim3(GL_THREADS), 0, (hipStream_t)stream, p);
+    return gl_check();
+}
+
 int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps, int row_major, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
                               const long long *idx, int n_samples, int n_per_element, const float *grad_patches, void *stream)
 {
@@ -729,7 +754,7 @@ int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps, int row_maj
     const int rc = patch_params(&p, n_levels, dim, channels, anchors_per_voxel, Y, X, Z, idx, n_samples, n_per_element);
     if (rc != MDT_OK) return rc;
     if (n_samples == 0) return MDT_OK;
-    for (int l = 0; l < n_levels; ++l) { p.maps[l] = nullptr; p.gmaps[l] = grad_maps[l]; }
+    for (int l = 0; l < n_levels; ++l) { p.maps[l] = nullptr; p.gmaps[l] = grad_maps[l]; p.side[l] = nullptr; }
     if (((uintptr_t)grad_patches) & 15) return MDT_ERR_UNSUPPORTED;
     p.patches = nullptr; p.gpatches = grad_patches; p.k_anchor = nullptr; p.row_major = row_major ? 1 : 0;
     const long long total = (long long)n_samples * p.T * (channels / 4);
