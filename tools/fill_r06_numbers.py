@@ -26,9 +26,10 @@ if "--print" in sys.argv:
 if "--tests" in sys.argv:
     i = sys.argv.index("--tests")
     vals["R6_NTESTS"], vals["R6_TSEC"] = sys.argv[i + 1], sys.argv[i + 2]
+import re
 for name in ("README.md", "DESIGN.md"):
     p = os.path.join(ROOT, name)
     s = open(p).read()
-    for k in sorted(vals, key=len, reverse=True):          # longest first: R6_EXEC_SYNC before R6_EXEC
-        s = s.replace(k, str(vals[k]))
+    for k, v in vals.items():          # idempotent: the value sits between invisible markers  <!--R6_X-->value<!--/-->
+        s = re.sub(r"<!--%s-->.*?<!--/-->" % k, "<!--%s-->%s<!--/-->" % (k, v), s)
     open(p, "w").write(s)
