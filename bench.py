@@ -738,9 +738,9 @@ def main():
     graph_rec["used_for_headline"] = use_graph
     # graphed headline: capture FIRST, before any eager step of this net (graph_preflight_main explains)
     exec_form = args.step_form == "exec"
-    # the read-out mode of the headline step: Mask R-CNN hands the packed read-out over with an asynchronous copy and the entries of step i
-    # are consumed while step i + 1 is queued ("deferred"); the Retina nets read back synchronously like the reference
-    mon_mode = False if not exec_form else ("deferred" if args.model == "mrcnn" else True)
+    # the read-out mode of the headline step: the packed read-out (for the Retina U-Net also the uint8 label map) travels with an asynchronous copy and
+    # the entries of step i are consumed while step i + 1 is queued ("deferred")
+    mon_mode = False if not exec_form else "deferred"
     if exec_form and args.model == "mrcnn":
         cf.run_detection_mask_head_in_training = True       # mrcnn.py:1046-1048: the reference runs it in every training step
     gstep = training.GraphedTrainStep(net, opt, grad_sync=sync, gmax=args.gmax, monitor=mon_mode, with_masks=exec_form) if use_graph else None
@@ -1008,7 +1008,7 @@ def main():
                                      + ("the mask head over the detections (mrcnn.py:1046-1048), the per-batch read-out exec.py:76-79 consumes (logger_string, box lists, "
                                         "monitor_values: ONE packed device->host copy per step, asynchronous, the entries of step i consumed while step i + 1 is queued) -- "
                                         if (args.model == "mrcnn" and args.step_form == "exec") else
-                                        ("the per-batch read-out exec.py:76-79 consumes (logger_string, box lists, seg_preds, monitor_values; synchronous) -- "
+                                        ("the per-batch read-out exec.py:76-79 consumes (logger_string, box lists, seg_preds, monitor_values: packed asynchronous copies, consumed one step late) -- "
                                          if args.step_form == "exec" else "WITHOUT the per-batch read-out (--step-form no-readout) -- "))
                                      + "zero_grad, backward, Adam (exec.py:68-74); every loss term and every parameter gradient of the reference step "
                                      "(tests/test_step_parity_gpu.py pins them against the reference at this configuration).  Batches resident in HBM when the timed region "

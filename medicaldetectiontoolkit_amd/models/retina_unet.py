@@ -112,9 +112,12 @@ def refine_detections(anchors, probs, deltas, B, cf):
     return out.view(-1, 2 * dim + 3), valid.view(-1)
 
 
-def get_results(cf, img_shape, detections, det_valid, seg_logits, box_results_list=None):
-    """retina_unet.py:275-335."""
-    det = detections.detach().cpu().numpy()[det_valid.detach().cpu().numpy()]
+def get_results(cf, img_shape, detections, det_valid, seg_logits, box_results_list=None, seg_preds=None):
+    """retina_unet.py:275-335.  detections / det_valid: device tensors or host arrays that were already read back; seg_preds: the label map already
+    computed (deferred read-out) instead of seg_logits."""
+    det_a = detections if isinstance(detections, np.ndarray) else detections.detach().cpu().numpy()
+    val_a = det_valid if isinstance(det_valid, np.ndarray) else det_valid.detach().cpu().numpy()
+    det = det_a[val_a.astype(bool)]
     dim = cf.dim
     if box_results_list is None:
         box_results_list = [[] for _ in range(img_shape[0])]
@@ -134,7 +137,9 @@ def get_results(cf, img_shape, detections, det_valid, seg_logits, box_results_li
                 box_results_list[ix].append({"box_coords": boxes[ix2], "box_score": scores[ix2], "box_type": "det",
                                              "box_pred_class_id": class_ids[ix2]})
     results_dict = {"boxes": box_results_list}
-    if seg_logits is None:
+    if seg_preds is not None:
+        results_dict["seg_preds"] = seg_preds
+    elif seg_logits is None:
         results_dict["seg_preds"] = np.zeros(img_shape)[:, 0][:, np.newaxis]
     else:
         results_dict["seg_preds"] = F.softmax(seg_logits, 1).argmax(1).cpu().numpy()[:, np.newaxis].astype("uint8")
@@ -241,6 +246,23 @@ class net(nn.Module):
                         "loss_terms": {"class": batch_class_loss.detach(), "bbox": batch_bbox_loss.detach(),
                                        "seg_dice": None if seg_dice is None else seg_dice.detach(),
                                        "seg_ce": None if seg_ce is None else seg_ce.detach()}}
+        if monitor == "deferred":
+            # the read-out one step late (mrcnn.net.train_forward has the same mode): the sampled anchors, detections and loss values packed into ONE
+            # buffer, the label map as uint8 computed on the device (soft-max + arg-max as get_results does) with its mean -- both travel with
+            # asynchronous copies into pinned memory; the entries returned now are those of the PREVIOUS call.  No host sync in the step.
+            vals = [loss, batch_class_loss, batch_bbox_loss] + ([seg_dice, seg_ce] if seg_logits is not None else [])
+            seg_u8 = None
+            if seg_logits is not None:
+                seg_u8 = F.softmax(seg_logits.detach(), 1).argmax(1).to(torch.uint8)
+                vals = vals + [seg_u8.float().mean()]
+            items = [("pidx", samples[0]), ("pvalid", samples[1]), ("nidx", samples[2]), ("nvalid", samples[3]), ("detections", detections),
+                     ("det_valid", det_valid), ("vals", torch.stack([x.detach().float() for x in vals]))]
+            if getattr(self, "_deferred", None) is None:
+                self._deferred = mutils.DeferredReadout()
+            prev = self._deferred.push(mutils.pack_for_readout(items), (batch, tuple(img.shape), seg_logits is not None), extra=seg_u8)
+            if prev is not None:
+                results_dict.update(self._resolve_deferred(prev))
+            return results_dict
         if monitor:
             box_results_list = [[] for _ in range(B)]
             for b in range(B):
@@ -263,6 +285,42 @@ class net(nn.Module):
                 ", seg dice: {0:.3f}, seg ce: {1:.3f}, mean pix. pr.: {2:.5f}".format(v[3], v[4], float(np.mean(results_dict["seg_preds"])))
                 if seg_logits is not None else "")
         return results_dict
+
+    def _resolve_deferred(self, entry):
+        packed, ctx = mutils.DeferredReadout.resolve(entry)
+        if isinstance(ctx, tuple) and len(ctx) == 2 and torch.is_tensor(ctx[1]):
+            (batch, img_shape, has_seg), seg_host = ctx
+        else:
+            (batch, img_shape, has_seg), seg_host = ctx, None
+        r = mutils.unpack_readout(packed)
+        B = img_shape[0]
+        box_results_list = [[] for _ in range(B)]
+        for b in range(B):
+            for ix in range(len(batch["bb_target"][b])):
+                box_results_list[b].append({"box_coords": batch["bb_target"][b][ix], "box_label": batch["roi_labels"][b][ix], "box_type": "gt"})
+        if getattr(self, "_anchors_host", None) is None:
+            self._anchors_host = self.anchors.cpu().numpy()
+        anchors_np = self._anchors_host
+        pidx, pvalid, nidx, nvalid = r["pidx"], r["pvalid"].astype(bool), r["nidx"], r["nvalid"].astype(bool)
+        for b in range(B):
+            for a in anchors_np[pidx[b][pvalid[b]]]:
+                box_results_list[b].append({"box_coords": a, "box_type": "pos_anchor"})
+            for a in anchors_np[nidx[b][nvalid[b]]]:
+                box_results_list[b].append({"box_coords": a, "box_type": "neg_anchor"})
+        seg_preds = seg_host.numpy()[:, np.newaxis].copy() if seg_host is not None else None      # (the pinned buffer is re-used two steps later)
+        res = get_results(self.cf, img_shape, r["detections"], r["det_valid"], None, box_results_list, seg_preds=seg_preds)
+        v = r["vals"]
+        res["monitor_values"] = {"loss": float(v[0]), "class_loss": float(v[1])}
+        res["logger_string"] = "loss: {0:.2f}, class: {1:.2f}, bbox: {2:.2f}".format(v[0], v[1], v[2]) + (
+            ", seg dice: {0:.3f}, seg ce: {1:.3f}, mean pix. pr.: {2:.5f}".format(v[3], v[4], float(v[5])) if has_seg else "")
+        res["monitor_of_previous_step"] = True
+        return res
+
+    def flush_deferred_monitor(self):
+        """read-out entries of the LAST train_forward(monitor="deferred") call, or None"""
+        d = getattr(self, "_deferred", None)
+        entry = d.flush() if d is not None else None
+        return self._resolve_deferred(entry) if entry is not None else None
 
     def test_forward(self, batch, **kwargs):
         """retina_unet.py:459-475."""

@@ -257,11 +257,14 @@ class DeferredReadout(object):
 
     def __init__(self):
         self.bufs = [None, None]
+        self.extra_bufs = [None, None]
         self.k = 0
         self.pending = None          # (event, host tensor, layout, context)
 
-    def push(self, packed, context):
-        """enqueue the copy of `packed` = (device int32 buffer, layout); returns what was pending before (or None)"""
+    def push(self, packed, context, extra=None):
+        """enqueue the copy of `packed` = (device int32 buffer, layout); returns what was pending before (or None).
+        extra: one more device tensor (any dtype, e.g. the Retina U-Net's uint8 label map) that travels the same way; `resolve` hands its
+        pinned host copy back inside the context tuple's place: context becomes (context, host_extra)."""
         buf, layout = packed
         prev = self.pending
         host = self.bufs[self.k]
@@ -269,6 +272,14 @@ class DeferredReadout(object):
             host = self.bufs[self.k] = torch.empty(int(buf.numel()), dtype=torch.int32).pin_memory()
         view = host[:buf.numel()]
         view.copy_(buf.detach(), non_blocking=True)
+        if extra is not None:
+            e = extra.detach().contiguous()
+            eh = self.extra_bufs[self.k]
+            if eh is None or eh.numel() < e.numel() or eh.dtype != e.dtype:
+                eh = self.extra_bufs[self.k] = torch.empty(int(e.numel()), dtype=e.dtype).pin_memory()
+            ev_view = eh[:e.numel()].view(e.shape)
+            ev_view.copy_(e, non_blocking=True)
+            context = (context, ev_view)
         ev = torch.cuda.Event()
         ev.record()
         self.pending = (ev, view, layout, context)

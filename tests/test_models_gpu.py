@@ -391,3 +391,41 @@ def test_deferred_monitor_readout_equals_synchronous_one_step_late(cuda):
                 assert np.array_equal(np.asarray(x["box_coords"]), np.asarray(want))
             for t in ("pos_anchor", "neg_anchor", "prop"):
                 assert sum(1 for x in bs if x["box_type"] == t) == sum(1 for x in bg if x["box_type"] == t), t
+
+
+@pytest.mark.parametrize("model,dim,patch", [("retina_unet", 3, [64, 64, 32]), ("retina_net", 2, [64, 64])])
+def test_retina_deferred_monitor_readout_equals_synchronous_one_step_late(model, dim, patch, cuda):
+    """the Retina nets' train_forward(monitor="deferred") (round 6: what bench.py's exec-form step of config 2 runs): at call i + 1 the entries of
+    call i -- loss values of the SAME pass exactly, the GT / sampled-anchor / detection boxes and, for the U-Net, the uint8 label map equal to the
+    synchronous form's on the same seed (label voxels may flip only where MIOpen's run-to-run noise meets a tie)"""
+    B = 2
+    cf = Configs(dim=dim, model=model, patch_size=patch, batch_size=B)
+    torch.manual_seed(0)
+    net = retina_unet.net(cf, device=cuda)
+    batches = [make_batch(patch, B, seed=s) for s in (3, 4, 5)]
+    sync = []
+    for i, b in enumerate(batches):
+        torch.manual_seed(50 + i)
+        sync.append(net.train_forward(b, monitor=True))
+    got, losses = [], []
+    for i, b in enumerate(batches):
+        torch.manual_seed(50 + i)
+        r = net.train_forward(b, monitor="deferred")
+        losses.append(float(r["torch_loss"]))
+        assert ("logger_string" in r) == (i > 0)
+        if i > 0:
+            assert r["monitor_of_previous_step"]
+            got.append(r)
+    got.append(net.flush_deferred_monitor())
+    assert net.flush_deferred_monitor() is None and len(got) == 3
+    for i, (s, g) in enumerate(zip(sync, got)):
+        assert g["monitor_values"]["loss"] == losses[i]
+        assert g["logger_string"].startswith("loss: {0:.2f}".format(losses[i]))
+        assert abs(s["monitor_values"]["loss"] - g["monitor_values"]["loss"]) <= 1e-4 * abs(losses[i])
+        for b_ix, (bs, bg) in enumerate(zip(s["boxes"], g["boxes"])):
+            for t in ("gt", "pos_anchor", "neg_anchor", "det"):
+                assert sum(1 for x in bs if x["box_type"] == t) == sum(1 for x in bg if x["box_type"] == t), (i, b_ix, t)
+        assert s["seg_preds"].shape == g["seg_preds"].shape
+        if model == "retina_unet":
+            assert g["seg_preds"].dtype == np.uint8 and float((s["seg_preds"] != g["seg_preds"]).mean()) <= 1e-4
+            assert "mean pix. pr." in g["logger_string"]
