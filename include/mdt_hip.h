@@ -507,6 +507,20 @@ int mdt_adam_flat_segments(float *param, const float *grad, float *exp_avg, floa
                            double beta1, double beta2, double eps, double weight_decay, double grad_div, void *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* Forward of the same layer family on the window trick (round 6, csrc/conv_s221.hip): y [B, Y/2, X/2, Z, c_out] (channels-last storage of
+ * [B, c_out, Y/2, X/2, Z]) = conv3d(x, w, stride (2, 2, 1), pad k / 2) (+ bias)(ReLU) for x [B, Y, X, Z, c_in] channels-last; wt = the filter as
+ * [ky][kx][kz][ci][co] (w.permute(2, 3, 4, 1, 0) contiguous).  fp32 MFMA, deterministic.  Supported: odd k, even c_in, k * c_in <= 128, c_out <= 32,
+ * Z % 64 == 0, (X / 2) % 4 == 0; otherwise MDT_ERR_UNSUPPORTED (the caller poses the space-to-depth problem to MIOpen).  What cuDNN computes for
+ * models/backbone.py:84 (C1 of the Retina U-Net). */
+int mdt_conv_s221_input_grad_supported(int Y, int X, int Z, int c_in, int c_out, int k);
+/* the layer's input gradient on the same machine: gx [B, Y, X, Z, c_in] channels-last from gy [B, Y/2, X/2, Z, c_out] channels-last; wd = the filter as
+ * [ky][kx][K-1-kz][co][ci] (w.flip(4).permute(2, 3, 4, 0, 1) contiguous); every element of gx is written.  Supported: odd k, even c_out, k * c_out <= 128,
+ * c_in <= 32, Z % 64 == 0, X % 4 == 0. */
+int mdt_conv_s221_input_grad(const float *gy, const float *wd, float *gx, int batch, int Y, int X, int Z, int c_in, int c_out, int k, void *stream);
+int mdt_conv_s221_forward_supported(int Y, int X, int Z, int c_in, int c_out, int k);
+int mdt_conv_s221_forward(const float *x, const float *wt, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_in, int c_out, int k,
+                          void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Loss / target glue of the training step (csrc/glue.hip, round 6)           */
 /* ------------------------------------------------------------------------- */

@@ -255,6 +255,220 @@ bool wgrad_plan(int B, int Y, int X, int Z, int Ci, int Co, int K, S221 &q)
     return true;
 }
 
+// ---- forward (round 6) ------------------------------------------------------------------------------------------------------------------
+// The same window trick with the roles turned: for one filter tap pair (ky, kx) and one output column (b, oy, ox)
+//     y[z][co] += sum over the window  x_col(2 oy + ky - P, 2 ox + kx - P)[(z - P) * Ci + k] * Wt[ky][kx][k][co],   k = (kz, ci) in [0, K * Ci)
+// is a [32 z x K Ci] x [K Ci x Co] product per 32 consecutive z: M = z, N = co (18 of 32), K = the window, 2 per v_mfma_f32_32x32x2_f32.
+// The A operand is a TOEPLITZ view of the input column -- row m is the column shifted by m * Ci floats -- so it is read straight out of an LDS
+// image of the column (lane l: element (m = l & 31) * Ci + 2 ks + (l >> 5); 18-float row stride = conflict-free over 64 banks): no im2col.
+// A workgroup of 4 waves owns 4 consecutive output columns ox of one (b, oy) and 64 z: per ky it stages the 2 * 4 + K - 2 input columns its
+// waves need (z halo of K - 1, zeros outside the volume) -- 65.5 KB, two workgroups per CU, so one stages while the other multiplies --
+// and every wave runs its K pairs x (K Ci / 2) K-steps x 2 M tiles with the pair's B fragments (K Ci / 2 registers) loaded from the
+// [ky][kx][k][co] filter image (444 KB: L2-resident).  Accumulators (2 tiles x 16 registers) live across all K x K pairs; bias and
+// ReLU ride in the epilogue.  405 M MFMA issues at 8 x 128^3 = 10.5 ms at the fp32 MFMA peak (MIOpen / CK on the space-to-depth problem: 33.4 ms).
+constexpr int F_WOX = 4;            // output columns (= waves) per workgroup
+constexpr int F_ZH = 64;            // output z per workgroup (2 M tiles)
+constexpr int F_MAXKS = 64;         // K-steps per pair (K * Ci / 2 <= 64)
+
+struct S221F {
+    int B, Y, X, Z, Ci, Co, K, P, OY, OX;
+    int KC, ksteps, ZR, ncol, oxg;      // K * Ci, KC / 2, F_ZH + K - 1, 2 * F_WOX + K - 2, OX / F_WOX
+    int relu;
+};
+
+// KSC > 0: the K-step count as a compile-time constant (63 for the 18-channel 7x7x7 layer): a straight-line block of KSC B loads and 2 KSC LDS reads /
+// MFMAs per pair; KSC == 0: run-time count (other shapes; the compiler then guards every K-step with a branch)
+template <int KSC, int KKC>
+__global__ __launch_bounds__(F_WOX * 64, 2) void conv_s221_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wt, const float *__restrict__ bias,
+                                                                      float *__restrict__ y, S221F q)
+{
+    extern __shared__ __attribute__((aligned(16))) float sA[];          // [ncol][ZR * Ci]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int oxb = (blockIdx.x % q.oxg) * F_WOX, zh0 = (blockIdx.x / q.oxg) * F_ZH, oy = blockIdx.y, b = blockIdx.z;
+    const int colf = q.ZR * q.Ci;                                       // floats per staged column
+    const int cn = min(col, q.Co - 1);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    for (int ky = 0; ky < q.K; ++ky) {
+        const int iy = 2 * oy + ky - q.P;
+        if (iy < 0 || iy >= q.Y) continue;                              // uniform over the workgroup: a zero-padding row contributes nothing
+        __syncthreads();                                                // everyone is done with the previous image
+        {   // stage: ncol columns x ZR rows x Ci floats, float2 at a time (Ci even: a pair never straddles a z row)
+            const int pairs_per_col = colf >> 1;
+            const long long rowbase = ((long long)b * q.Y + iy) * q.X;
+            for (int e = tid; e < q.ncol * pairs_per_col; e += F_WOX * 64) {
+                const int c = e / pairs_per_col, j = (e - c * pairs_per_col) * 2;
+                const int ix = 2 * oxb - q.P + c;
+                const int z = zh0 - q.P + j / q.Ci;
+                float2 v = make_float2(0.0f, 0.0f);
+                if (ix >= 0 && ix < q.X && z >= 0 && z < q.Z)
+                    v = *reinterpret_cast<const float2 *>(x + (rowbase + ix) * (long long)q.Z * q.Ci + (long long)(zh0 - q.P) * q.Ci + j);
+                *reinterpret_cast<float2 *>(sA + c * colf + j) = v;
+            }
+        }
+        __syncthreads();
+        if (KSC > 0) {
+            // the pair's B fragments (KSC registers) are loaded ONE PAIR AHEAD: the loads of pair kx + 1 are issued before the MFMA block of pair kx
+            // (sched_barrier keeps the compiler from sinking them to their uses -- it did, with a vmcnt(0) in front of every second MFMA)
+            constexpr int KS1 = KSC > 0 ? KSC : 1;
+            const int co2 = 2 * q.Co, hi = 32 * q.Ci;
+            float bf[2][KS1];
+            {
+                const float *Bp = wt + ((long long)(ky * q.K) * q.KC + half) * q.Co + cn;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) bf[0][ks] = Bp[ks * co2];
+            }
+#pragma unroll
+            for (int kx = 0; kx < KKC; ++kx) {
+                if (kx + 1 < KKC) {
+                    const float *Bn = wt + ((long long)(ky * q.K + kx + 1) * q.KC + half) * q.Co + cn;
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) bf[(kx + 1) & 1][ks] = Bn[ks * co2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float *Ac = sA + (2 * wave + kx) * colf + col * q.Ci + half;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    const float a0 = Ac[2 * ks];
+                    const float a1 = Ac[hi + 2 * ks];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[kx & 1][ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[kx & 1][ks], acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int kx = 0; kx < q.K; ++kx) {
+                const float *Ac = sA + (2 * wave + kx) * colf + col * q.Ci + half;
+                const float *Bp = wt + ((long long)(ky * q.K + kx) * q.KC + half) * q.Co + cn;
+                for (int ks = 0; ks < q.ksteps; ++ks) {
+                    const float bv = Bp[(long long)2 * ks * q.Co];
+                    const float a0 = Ac[2 * ks];
+                    const float a1 = Ac[32 * q.Ci + 2 * ks];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: (+ bias)(ReLU), rows = z, columns = co; lane (col, half) holds rows (r & 3) + 8 (r >> 2) + 4 half
+    if (col < q.Co) {
+        const float bv = bias ? bias[col] : 0.0f;
+        float *yo = y + ((((long long)b * q.OY + oy) * q.OX + oxb + wave) * q.Z + zh0) * q.Co + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v0 = acc0[r] + bv, v1 = acc1[r] + bv;
+            if (q.relu) { v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; }
+            yo[(long long)row * q.Co] = v0;
+            yo[(long long)(32 + row) * q.Co] = v1;
+        }
+    }
+}
+
+// ---- input gradient (round 6): the same machine on the output gradient --------------------------------------------------------------------
+//     gx[b, iy, ix, z, ci] = sum over the taps (ky, kx) with ky = iy + P, kx = ix + P (mod 2) of
+//                            sum over the window  gy_col((iy + P - ky) / 2, (ix + P - kx) / 2)[(z - P) * Co + (j, co)] * Wd[ky][kx][(j, co)][ci],   j = K - 1 - kz
+// i.e. the forward kernel with gy as the input, (K + 1) / 2 or (K - 1) / 2 taps per axis depending on the parity of the output voxel, and the filter
+// image Wd = w.flip(kz).permute(ky, kx, kz, co, ci).  A workgroup owns 4 consecutive ix of one (b, iy) and 64 z: its waves' taps read
+// (K + 1) / 2 + 2 source columns in all (6 for K = 7).  No space-to-depth problem, no padded copy of gy, no fold: MIOpen's forward convolution on the padded
+// output gradient takes 26.4 ms + 0.5 ms fold at 8 x 128^3.
+template <int KSC, int KTC>
+__global__ __launch_bounds__(F_WOX * 64, 2) void conv_s221_dgrad_kernel(const float *__restrict__ gy, const float *__restrict__ wd, float *__restrict__ gx, S221F q)
+{
+    extern __shared__ __attribute__((aligned(16))) float sA[];          // [ncol][ZR * Co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int ixg = q.X / F_WOX;
+    const int ix0 = (blockIdx.x % ixg) * F_WOX, zh0 = (blockIdx.x / ixg) * F_ZH, iy = blockIdx.y, b = blockIdx.z;
+    const int CW = q.Co, CN = q.Ci;                                     // window channels (the source's), output channels
+    const int colf = q.ZR * CW;
+    const int cn = min(col, CN - 1);
+    const int ncol = (q.K + 1) / 2 + 2;
+    const int ox_base = (ix0 + q.P - (q.K - 1)) >> 1;                   // arithmetic shift = floor, also for negative values
+    const int ix = ix0 + wave;
+    const int kx0 = (ix + q.P) & 1, nkx = (q.K - kx0 + 1) >> 1;         // this wave's taps: kx = kx0 + 2 t
+    const int ky0 = (iy + q.P) & 1, nky = (q.K - ky0 + 1) >> 1;
+    const int KCW = q.K * CW, co2 = 2 * CN, hi = 32 * CW;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    for (int ty = 0; ty < nky; ++ty) {
+        const int ky = ky0 + 2 * ty;
+        const int oy = (iy + q.P - ky) >> 1;
+        if (oy < 0 || oy >= q.OY) continue;
+        __syncthreads();
+        {
+            const int pairs_per_col = colf >> 1;
+            const long long rowbase = ((long long)b * q.OY + oy) * q.OX;
+            for (int e = tid; e < ncol * pairs_per_col; e += F_WOX * 64) {
+                const int c = e / pairs_per_col, j = (e - c * pairs_per_col) * 2;
+                const int ox = ox_base + c;
+                const int z = zh0 - q.P + j / CW;
+                float2 v = make_float2(0.0f, 0.0f);
+                if (ox >= 0 && ox < q.OX && z >= 0 && z < q.Z)
+                    v = *reinterpret_cast<const float2 *>(gy + (rowbase + ox) * (long long)q.Z * CW + (long long)(zh0 - q.P) * CW + j);
+                *reinterpret_cast<float2 *>(sA + c * colf + j) = v;
+            }
+        }
+        __syncthreads();
+        constexpr int KS1 = KSC > 0 ? KSC : 1;
+        if (KSC > 0) {
+            float bf[2][KS1];
+            {
+                const float *Bp = wd + ((long long)(ky * q.K + kx0) * KCW + half) * CN + cn;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) bf[0][ks] = Bp[ks * co2];
+            }
+#pragma unroll
+            for (int t = 0; t < KTC; ++t) {
+                if (t < nkx) {                                          // wave-uniform
+                    if (t + 1 < nkx) {
+                        const float *Bn = wd + ((long long)(ky * q.K + kx0 + 2 * (t + 1)) * KCW + half) * CN + cn;
+#pragma unroll
+                        for (int ks = 0; ks < KS1; ++ks) bf[(t + 1) & 1][ks] = Bn[ks * co2];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int c = ((ix + q.P - (kx0 + 2 * t)) >> 1) - ox_base;
+                    const float *Ac = sA + c * colf + col * CW + half;
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        const float a0 = Ac[2 * ks];
+                        const float a1 = Ac[hi + 2 * ks];
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[t & 1][ks], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[t & 1][ks], acc1, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            for (int t = 0; t < nkx; ++t) {
+                const int kx = kx0 + 2 * t;
+                const int c = ((ix + q.P - kx) >> 1) - ox_base;
+                const float *Ac = sA + c * colf + col * CW + half;
+                const float *Bp = wd + ((long long)(ky * q.K + kx) * KCW + half) * CN + cn;
+                for (int ks = 0; ks < (KCW >> 1); ++ks) {
+                    const float bv = Bp[(long long)ks * co2];
+                    const float a0 = Ac[2 * ks];
+                    const float a1 = Ac[hi + 2 * ks];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (col < CN) {
+        float *go = gx + ((((long long)b * q.Y + iy) * q.X + ix) * q.Z + zh0) * CN + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            go[(long long)row * CN] = acc0[r];
+            go[(long long)(32 + row) * CN] = acc1[r];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -315,6 +529,77 @@ int mdt_conv_s221_wgrad(const float *grad_out, const float *x, float *grad_weigh
     const int n = k * c_in * c_out;
     hipLaunchKernelGGL(conv_s221_wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)(k * k)), dim3(256), 0, s, ws, grad_weight, k, c_in, c_out,
                        q.waves_per_pair);
+    return s221_check();
+}
+
+int mdt_conv_s221_forward_supported(int Y, int X, int Z, int c_in, int c_out, int k)
+{
+    if (k < 3 || (k & 1) == 0 || c_in < 1 || c_out < 1 || c_out > 32 || ((k * c_in) & 1) || (c_in & 1) || k * c_in / 2 > F_MAXKS) return 0;
+    if (Y < 2 || X < 2 || (Y & 1) || (X & 1) || Z < F_ZH || Z % F_ZH) return 0;
+    if ((X / 2) % F_WOX) return 0;
+    const size_t lds = (size_t)(2 * F_WOX + k - 2) * (F_ZH + k - 1) * c_in * sizeof(float);
+    return lds <= 80 * 1024 ? 1 : 0;
+}
+
+/* y [B, Y/2, X/2, Z, c_out] (channels-last storage of [B, c_out, Y/2, X/2, Z]) = conv(x [B, Y, X, Z, c_in] channels-last, w, k x k x k, stride (2, 2, 1), pad k / 2)
+ * (+ bias)(ReLU); wt = the filter as [ky][kx][kz][ci][co] (w.permute(2, 3, 4, 1, 0) contiguous). */
+int mdt_conv_s221_forward(const float *x, const float *wt, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_in, int c_out, int k,
+                          void *stream)
+{
+    if (!x || !wt || !y || batch < 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (!mdt_conv_s221_forward_supported(Y, X, Z, c_in, c_out, k)) return MDT_ERR_UNSUPPORTED;
+    if (batch == 0) return MDT_OK;
+    if ((((uintptr_t)x) & 7) != 0) return MDT_ERR_UNSUPPORTED;
+    S221F q;
+    q.B = batch; q.Y = Y; q.X = X; q.Z = Z; q.Ci = c_in; q.Co = c_out; q.K = k; q.P = k / 2; q.OY = Y / 2; q.OX = X / 2;
+    q.KC = k * c_in; q.ksteps = q.KC / 2; q.ZR = F_ZH + k - 1; q.ncol = 2 * F_WOX + k - 2; q.oxg = q.OX / F_WOX; q.relu = relu ? 1 : 0;
+    const size_t lds = (size_t)q.ncol * q.ZR * c_in * sizeof(float);
+    static bool optin = false;
+    if (!optin) {
+        (void)hipFuncSetAttribute((const void *)conv_s221_fwd_kernel<63, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv_s221_fwd_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipGetLastError();
+        optin = true;
+    }
+    (void)hipGetLastError();
+    const dim3 grid(q.oxg * (Z / F_ZH), q.OY, batch), block(F_WOX * 64);
+    if (q.ksteps == 63 && k == 7) hipLaunchKernelGGL((conv_s221_fwd_kernel<63, 7>), grid, block, lds, (hipStream_t)stream, x, wt, bias, y, q);
+    else hipLaunchKernelGGL((conv_s221_fwd_kernel<0, 1>), grid, block, lds, (hipStream_t)stream, x, wt, bias, y, q);
+    return s221_check();
+}
+
+int mdt_conv_s221_input_grad_supported(int Y, int X, int Z, int c_in, int c_out, int k)
+{
+    if (k < 3 || (k & 1) == 0 || c_in < 1 || c_in > 32 || c_out < 2 || (c_out & 1) || k * c_out / 2 > F_MAXKS) return 0;
+    if (Y < 2 || X < 2 || (Y & 1) || (X & 1) || Z < F_ZH || Z % F_ZH) return 0;
+    if (X % F_WOX) return 0;
+    const size_t lds = (size_t)((k + 1) / 2 + 2) * (F_ZH + k - 1) * c_out * sizeof(float);
+    return lds <= 80 * 1024 ? 1 : 0;
+}
+
+/* gx [B, Y, X, Z, c_in] (channels-last storage of [B, c_in, Y, X, Z]) = the input gradient of conv3d(x, w, stride (2, 2, 1), pad k / 2) for gy [B, Y/2, X/2, Z, c_out]
+ * channels-last; wd = the filter as [ky][kx][K-1-kz][co][ci] (w.flip(4).permute(2, 3, 4, 0, 1) contiguous).  Every element of gx is written. */
+int mdt_conv_s221_input_grad(const float *gy, const float *wd, float *gx, int batch, int Y, int X, int Z, int c_in, int c_out, int k, void *stream)
+{
+    if (!gy || !wd || !gx || batch < 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (!mdt_conv_s221_input_grad_supported(Y, X, Z, c_in, c_out, k)) return MDT_ERR_UNSUPPORTED;
+    if (batch == 0) return MDT_OK;
+    if ((((uintptr_t)gy) & 7) != 0) return MDT_ERR_UNSUPPORTED;
+    S221F q;
+    q.B = batch; q.Y = Y; q.X = X; q.Z = Z; q.Ci = c_in; q.Co = c_out; q.K = k; q.P = k / 2; q.OY = Y / 2; q.OX = X / 2;
+    q.KC = k * c_out; q.ksteps = q.KC / 2; q.ZR = F_ZH + k - 1; q.ncol = (k + 1) / 2 + 2; q.oxg = X / F_WOX; q.relu = 0;
+    const size_t lds = (size_t)q.ncol * q.ZR * c_out * sizeof(float);
+    static bool optin = false;
+    if (!optin) {
+        (void)hipFuncSetAttribute((const void *)conv_s221_dgrad_kernel<63, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv_s221_dgrad_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipGetLastError();
+        optin = true;
+    }
+    (void)hipGetLastError();
+    const dim3 grid((X / F_WOX) * (Z / F_ZH), Y, batch), block(F_WOX * 64);
+    if (q.ksteps == 63 && k == 7) hipLaunchKernelGGL((conv_s221_dgrad_kernel<63, 4>), grid, block, lds, (hipStream_t)stream, gy, wd, gx, q);
+    else hipLaunchKernelGGL((conv_s221_dgrad_kernel<0, 1>), grid, block, lds, (hipStream_t)stream, gy, wd, gx, q);
     return s221_check();
 }
 

@@ -616,6 +616,56 @@ def s221_weight_grad(gy, x, w):
     return gw.permute(0, 4, 1, 2, 3)
 
 
+S221_FWD = True     # module switch (A/B: bench.py --conv-s221-fwd 0): the forward of the stride-(2, 2, 1) many-channel layer on this repo's fp32-MFMA kernel
+
+
+def s221_forward(x, w, bias=None, relu=False):
+    """mdt_conv_s221_forward (csrc/conv_s221.hip): the layer's forward straight from the channels-last input -- an LDS image of the input columns read as a
+    Toeplitz A operand, the (ky, kx) filter slices as B -- no space-to-depth copy; None when the shape is outside the kernel's budgets or x is not fp32
+    channels-last on the current device"""
+    if not (S221_FWD and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 5 and _on_current_device(x)
+            and x.is_contiguous(memory_format=torch.channels_last_3d) and not torch.is_autocast_enabled()):
+        return None
+    B, Ci, Y, X, Z = (int(v) for v in x.shape)
+    Co, k = int(w.shape[0]), int(w.shape[2])
+    L = _lib.lib()
+    if not L.mdt_conv_s221_forward_supported(Y, X, Z, Ci, Co, k):
+        return None
+    wt = w.detach().permute(2, 3, 4, 1, 0).contiguous()
+    y = torch.empty((B, Co, Y // 2, X // 2, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+    rc = L.mdt_conv_s221_forward(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, 1 if relu else 0, y.data_ptr(), B, Y, X, Z, Ci, Co, k,
+                                 _lib.raw_stream())
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        _lib.check(rc, "mdt_conv_s221_forward")
+    return y
+
+
+S221_DGRAD = True   # module switch (A/B: bench.py --conv-s221-dgrad 0): the layer's input gradient on this repo's fp32-MFMA kernel
+
+
+def s221_input_grad(gy, w, x_shape):
+    """mdt_conv_s221_input_grad: the input gradient straight from the channels-last output gradient (no padded copy, no space-to-depth problem, no fold);
+    None outside the kernel's budgets"""
+    if not (S221_DGRAD and gy.is_cuda and gy.dtype == torch.float32 and w.dtype == torch.float32 and gy.dim() == 5 and _on_current_device(gy)
+            and gy.is_contiguous(memory_format=torch.channels_last_3d) and not torch.is_autocast_enabled()):
+        return None
+    B, Ci, Y, X, Z = (int(v) for v in x_shape)
+    Co, k = int(w.shape[0]), int(w.shape[2])
+    L = _lib.lib()
+    if tuple(gy.shape) != (B, Co, Y // 2, X // 2, Z) or not L.mdt_conv_s221_input_grad_supported(Y, X, Z, Ci, Co, k):
+        return None
+    wd = w.detach().flip(4).permute(2, 3, 4, 0, 1).contiguous()
+    gx = torch.empty((B, Ci, Y, X, Z), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last_3d)
+    rc = L.mdt_conv_s221_input_grad(gy.data_ptr(), wd.data_ptr(), gx.data_ptr(), B, Y, X, Z, Ci, Co, k, _lib.raw_stream())
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        _lib.check(rc, "mdt_conv_s221_input_grad")
+    return gx
+
+
 class _ConvS2D221(Function):
     """k x k x k, stride (2, 2, 1), pad k // 2 convolution with MANY input channels (backbone.py:84: the Retina U-Net's C1 = 18 -> 18, k = 7
     on the full-resolution C0 output; 40 % of the config-2 step on MIOpen's direct problem: 39.6 ms forward, 58.1 ms input gradient, 45.9 ms
@@ -626,6 +676,9 @@ class _ConvS2D221(Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
+        y = s221_forward(x, w)
+        if y is not None:
+            return y
         return F.conv3d(s2d_input(x, int(w.shape[2])), s2d_filter(w), None, 1, 0)
 
     @staticmethod
@@ -637,7 +690,9 @@ class _ConvS2D221(Function):
             gy = gy.contiguous(memory_format=torch.channels_last_3d)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = s2d_input_grad_fold(s2d_input_grad_conv(gy, s2d_filter(w)), x.shape, k)
+            gx = s221_input_grad(gy, w, x.shape)
+            if gx is None:
+                gx = s2d_input_grad_fold(s2d_input_grad_conv(gy, s2d_filter(w)), x.shape, k)
         if ctx.needs_input_grad[1]:
             gw = s221_weight_grad(gy, x, w)
             if gw is None:

@@ -81,3 +81,49 @@ def test_c1_layer_dispatch_forward_and_gradients_equal_the_direct_convolution(Z,
         assert "ConvS2D221" not in type(fe._conv(conv, x).grad_fn).__name__
     finally:
         fe.S2D_GENERAL = old
+
+
+@pytest.mark.parametrize("B,Ci,Co,Y,X,Z,k,epi", [(2, 18, 18, 16, 16, 64, 7, None), (1, 18, 18, 12, 24, 128, 7, "bias_relu"), (1, 6, 5, 8, 8, 64, 3, "bias"),
+                                                (2, 10, 32, 4, 16, 64, 5, None), (1, 18, 18, 128, 8, 64, 7, None)])
+def test_forward_kernel_equals_the_direct_convolution(B, Ci, Co, Y, X, Z, k, epi, cuda):
+    """mdt_conv_s221_forward (round 6: fp32 MFMA, Toeplitz A operand out of an LDS image of the input columns) against F.conv3d of the direct
+    problem in float64 on the CPU: <= 1e-5 of the summed magnitudes (the sums are plain fp32 accumulations in a different order);
+    image borders in y, x (zero columns / skipped rows) and z (halo) included; deterministic"""
+    x = _rand((B, Ci, Y, X, Z), cuda, 11).contiguous(memory_format=CL)
+    w = _rand((Co, Ci, k, k, k), cuda, 12) * 0.1
+    bias = _rand((Co,), cuda, 13) if epi else None
+    y = fe.s221_forward(x, w, bias=bias, relu=(epi == "bias_relu"))
+    assert y is not None and y.shape == (B, Co, Y // 2, X // 2, Z) and y.is_contiguous(memory_format=CL)
+    xd, wd = x.double().cpu(), w.double().cpu()
+    ref = F.conv3d(xd, wd, bias.double().cpu() if bias is not None else None, (2, 2, 1), k // 2)
+    mag = F.conv3d(xd.abs(), wd.abs(), None, (2, 2, 1), k // 2) + 1.0
+    if epi == "bias_relu":
+        ref = torch.relu(ref)
+    err = ((y.double().cpu() - ref).abs() / mag).max()
+    assert float(err) <= 1e-5, float(err)
+    assert torch.equal(y, fe.s221_forward(x, w, bias=bias, relu=(epi == "bias_relu")))
+
+
+def test_forward_kernel_declines_what_it_does_not_cover(cuda):
+    w = _rand((18, 18, 7, 7, 7), cuda, 1)
+    assert fe.s221_forward(_rand((1, 18, 8, 8, 48), cuda, 2).contiguous(memory_format=CL), w) is None          # Z % 64
+    assert fe.s221_forward(_rand((1, 18, 8, 12, 64), cuda, 2).contiguous(memory_format=CL), w) is None         # (X / 2) % 4
+    assert fe.s221_forward(_rand((1, 18, 8, 8, 64), cuda, 2), w) is None                                       # not channels-last
+    assert fe.s221_forward(_rand((1, 20, 8, 8, 64), cuda, 2).contiguous(memory_format=CL), _rand((8, 20, 7, 7, 7), cuda, 3)) is None      # k * c_in > 128
+
+
+@pytest.mark.parametrize("B,Ci,Co,Y,X,Z,k", [(2, 18, 18, 16, 16, 64, 7), (1, 18, 18, 12, 24, 128, 7), (1, 5, 6, 8, 8, 64, 3), (2, 32, 10, 4, 16, 64, 5), (1, 18, 18, 128, 8, 64, 7)])
+def test_input_gradient_kernel_equals_the_direct_convolutions_gradient(B, Ci, Co, Y, X, Z, k, cuda):
+    """mdt_conv_s221_input_grad (round 6) against autograd of F.conv3d on the direct problem in float64: <= 1e-5 of the summed magnitudes; every element of gx
+    written (NaN pre-fill is not possible through the wrapper: a second call must be bit-equal and finite); both output parities, image borders, z halo"""
+    w = _rand((Co, Ci, k, k, k), cuda, 21) * 0.1
+    gy = _rand((B, Co, Y // 2, X // 2, Z), cuda, 22).contiguous(memory_format=CL)
+    gx = fe.s221_input_grad(gy, w, (B, Ci, Y, X, Z))
+    assert gx is not None and gx.shape == (B, Ci, Y, X, Z) and gx.is_contiguous(memory_format=CL) and bool(torch.isfinite(gx).all())
+    xd = torch.zeros((B, Ci, Y, X, Z), dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(F.conv3d(xd, w.double().cpu(), None, (2, 2, 1), k // 2), xd, gy.double().cpu())
+    xa = torch.zeros((B, Ci, Y, X, Z), dtype=torch.float64, requires_grad=True)
+    mag, = torch.autograd.grad(F.conv3d(xa, w.double().cpu().abs(), None, (2, 2, 1), k // 2), xa, gy.double().cpu().abs())
+    err = ((gx.double().cpu() - ref).abs() / (mag + 1.0)).max()
+    assert float(err) <= 1e-5, float(err)
+    assert torch.equal(gx, fe.s221_input_grad(gy, w, (B, Ci, Y, X, Z)))

@@ -132,8 +132,8 @@ _RETINA_BENCH = os.path.join(_GDIR, "step_reference_bench_retina.npz")
 def test_retina_unet_large_step_matches_reference_with_mfma_conv_kernels_dispatched(case, cuda):
     """Retina U-Net at 128 x 128 x 64, batch 1 (decoder up to P0 at full resolution) and -- round 6, VERDICT r5 next 2b -- AT THE BENCHMARKED
     CONFIGURATION (BASELINE config 2: 128^3, batch 8; golden = the reference's retina_unet.py step on the CPU, make_step_golden.py
-    bench-retina): same bars, same dispatch assertion, plus the C1 layer's own kernels (18 -> 18, 7x7x7, stride (2, 2, 1): space-to-depth
-    input + the fp32-MFMA weight gradient of csrc/conv_s221.hip)"""
+    bench-retina): same bars, same dispatch assertion, plus the C1 layer's own kernels (18 -> 18, 7x7x7, stride (2, 2, 1): forward, input
+    gradient and weight gradient on the fp32-MFMA kernels of csrc/conv_s221.hip)"""
     from medicaldetectiontoolkit_amd import _lib, miopen_env
     miopen_env.setup()
     from medicaldetectiontoolkit_amd.models import retina_unet
@@ -164,7 +164,8 @@ def test_retina_unet_large_step_matches_reference_with_mfma_conv_kernels_dispatc
         assert _ncalls(calls, name) >= MFMA_CALLS[name], (name, calls)
     # the C1 layer of models/backbone.py:54 runs in space-to-depth form with its weight gradient on this repo's kernel (round 5): a use-rule
     # that silently routed it back to MIOpen's direct strided problem must fail here
-    for name in (("mdt_s2d221_input", "mdt_conv_s221_wgrad", "mdt_s2d221_fold_input_grad") if case == "bench" else ()):
+    # (round 6, later: forward and input gradient of the layer run on own fp32-MFMA kernels too -- the space-to-depth plumbing is only reached outside their budgets)
+    for name in (("mdt_conv_s221_forward", "mdt_conv_s221_input_grad", "mdt_conv_s221_wgrad") if case == "bench" else ()):
         assert _ncalls(calls, name) >= 1, (name, {k: v for k, v in calls.items() if "s2" in k or "conv" in k})
     terms = {k: float(v) for k, v in res["loss_terms"].items()}
     for k in ("class", "bbox", "seg_dice", "seg_ce"):
