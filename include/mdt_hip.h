@@ -517,6 +517,12 @@ int mdt_conv_s221_input_grad_supported(int Y, int X, int Z, int c_in, int c_out,
  * [ky][kx][K-1-kz][co][ci] (w.flip(4).permute(2, 3, 4, 0, 1) contiguous); every element of gx is written.  Supported: odd k, even c_out, k * c_out <= 128,
  * c_in <= 32, Z % 64 == 0, X % 4 == 0. */
 int mdt_conv_s221_input_grad(const float *gy, const float *wd, float *gx, int batch, int Y, int X, int Z, int c_in, int c_out, int k, void *stream);
+/* the forward kernel at UNIT stride: y [B, Y, X, Z, c_out] = conv3d(x, w, stride 1, pad k / 2) (+ bias)(ReLU) for channels-last x, wt as above -- what cuDNN computes for
+ * the size-preserving few-channel 3x3x3 layers of NDConvGenerator (utils/model_utils.py:751-765; the 18 -> 18 ResBlock.conv2 of stage C2, models/backbone.py:186-190), and,
+ * on the flipped / transposed filter, for their input gradient.  Same conditions with the full-resolution extents (Z % 64 == 0, X % 4 == 0). */
+int mdt_conv_win_forward_supported(int Y, int X, int Z, int c_in, int c_out, int k);
+int mdt_conv_win_forward(const float *x, const float *wt, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_in, int c_out, int k,
+                         void *stream);
 int mdt_conv_s221_forward_supported(int Y, int X, int Z, int c_in, int c_out, int k);
 int mdt_conv_s221_forward(const float *x, const float *wt, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_in, int c_out, int k,
                           void *stream);

@@ -272,8 +272,9 @@ constexpr int F_MAXKS = 64;         // K-steps per pair (K * Ci / 2 <= 64)
 
 struct S221F {
     int B, Y, X, Z, Ci, Co, K, P, OY, OX;
-    int KC, ksteps, ZR, ncol, oxg;      // K * Ci, KC / 2, F_ZH + K - 1, 2 * F_WOX + K - 2, OX / F_WOX
+    int KC, ksteps, ZR, ncol, oxg;      // K * Ci, KC / 2, F_ZH + K - 1, S * (F_WOX - 1) + K, OX / F_WOX
     int relu;
+    int S;                              // (y, x) stride of the forward kernel: 2 (the layer this file is named after) or 1 (round 6: the size-preserving few-channel layers)
 };
 
 // KSC > 0: the K-step count as a compile-time constant (63 for the 18-channel 7x7x7 layer): a straight-line block of KSC B loads and 2 KSC LDS reads /
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(F_WOX * 64, 2) void conv_s221_fwd_kernel(const floa
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
     for (int ky = 0; ky < q.K; ++ky) {
-        const int iy = 2 * oy + ky - q.P;
+        const int iy = q.S * oy + ky - q.P;
         if (iy < 0 || iy >= q.Y) continue;                              // uniform over the workgroup: a zero-padding row contributes nothing
         __syncthreads();                                                // everyone is done with the previous image
         {   // stage: ncol columns x ZR rows x Ci floats, float2 at a time (Ci even: a pair never straddles a z row)
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(F_WOX * 64, 2) void conv_s221_fwd_kernel(const floa
             const long long rowbase = ((long long)b * q.Y + iy) * q.X;
             for (int e = tid; e < q.ncol * pairs_per_col; e += F_WOX * 64) {
                 const int c = e / pairs_per_col, j = (e - c * pairs_per_col) * 2;
-                const int ix = 2 * oxb - q.P + c;
+                const int ix = q.S * oxb - q.P + c;
                 const int z = zh0 - q.P + j / q.Ci;
                 float2 v = make_float2(0.0f, 0.0f);
                 if (ix >= 0 && ix < q.X && z >= 0 && z < q.Z)
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(F_WOX * 64, 2) void conv_s221_fwd_kernel(const floa
                     for (int ks = 0; ks < KS1; ++ks) bf[(kx + 1) & 1][ks] = Bn[ks * co2];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const float *Ac = sA + (2 * wave + kx) * colf + col * q.Ci + half;
+                const float *Ac = sA + (q.S * wave + kx) * colf + col * q.Ci + half;
 #pragma unroll
                 for (int ks = 0; ks < KS1; ++ks) {
                     const float a0 = Ac[2 * ks];
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(F_WOX * 64, 2) void conv_s221_fwd_kernel(const floa
             }
         } else {
             for (int kx = 0; kx < q.K; ++kx) {
-                const float *Ac = sA + (2 * wave + kx) * colf + col * q.Ci + half;
+                const float *Ac = sA + (q.S * wave + kx) * colf + col * q.Ci + half;
                 const float *Bp = wt + ((long long)(ky * q.K + kx) * q.KC + half) * q.Co + cn;
                 for (int ks = 0; ks < q.ksteps; ++ks) {
                     const float bv = Bp[(long long)2 * ks * q.Co];
@@ -532,31 +533,31 @@ int mdt_conv_s221_wgrad(const float *grad_out, const float *x, float *grad_weigh
     return s221_check();
 }
 
-int mdt_conv_s221_forward_supported(int Y, int X, int Z, int c_in, int c_out, int k)
+static int win_forward_supported(int Y, int X, int Z, int c_in, int c_out, int k, int S)
 {
     if (k < 3 || (k & 1) == 0 || c_in < 1 || c_out < 1 || c_out > 32 || ((k * c_in) & 1) || (c_in & 1) || k * c_in / 2 > F_MAXKS) return 0;
-    if (Y < 2 || X < 2 || (Y & 1) || (X & 1) || Z < F_ZH || Z % F_ZH) return 0;
-    if ((X / 2) % F_WOX) return 0;
-    const size_t lds = (size_t)(2 * F_WOX + k - 2) * (F_ZH + k - 1) * c_in * sizeof(float);
+    if (Y < S || X < S || (Y % S) || (X % S) || Z < F_ZH || Z % F_ZH) return 0;
+    if ((X / S) % F_WOX) return 0;
+    const size_t lds = (size_t)(S * (F_WOX - 1) + k) * (F_ZH + k - 1) * c_in * sizeof(float);
     return lds <= 80 * 1024 ? 1 : 0;
 }
 
-/* y [B, Y/2, X/2, Z, c_out] (channels-last storage of [B, c_out, Y/2, X/2, Z]) = conv(x [B, Y, X, Z, c_in] channels-last, w, k x k x k, stride (2, 2, 1), pad k / 2)
- * (+ bias)(ReLU); wt = the filter as [ky][kx][kz][ci][co] (w.permute(2, 3, 4, 1, 0) contiguous). */
-int mdt_conv_s221_forward(const float *x, const float *wt, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_in, int c_out, int k,
-                          void *stream)
+static int win_forward(const float *x, const float *wt, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_in, int c_out, int k, int S,
+                       void *stream)
 {
     if (!x || !wt || !y || batch < 0) return MDT_ERR_INVALID_ARGUMENT;
-    if (!mdt_conv_s221_forward_supported(Y, X, Z, c_in, c_out, k)) return MDT_ERR_UNSUPPORTED;
+    if (!win_forward_supported(Y, X, Z, c_in, c_out, k, S)) return MDT_ERR_UNSUPPORTED;
     if (batch == 0) return MDT_OK;
     if ((((uintptr_t)x) & 7) != 0) return MDT_ERR_UNSUPPORTED;
     S221F q;
-    q.B = batch; q.Y = Y; q.X = X; q.Z = Z; q.Ci = c_in; q.Co = c_out; q.K = k; q.P = k / 2; q.OY = Y / 2; q.OX = X / 2;
-    q.KC = k * c_in; q.ksteps = q.KC / 2; q.ZR = F_ZH + k - 1; q.ncol = 2 * F_WOX + k - 2; q.oxg = q.OX / F_WOX; q.relu = relu ? 1 : 0;
+    q.B = batch; q.Y = Y; q.X = X; q.Z = Z; q.Ci = c_in; q.Co = c_out; q.K = k; q.P = k / 2; q.OY = Y / S; q.OX = X / S; q.S = S;
+    q.KC = k * c_in; q.ksteps = q.KC / 2; q.ZR = F_ZH + k - 1; q.ncol = S * (F_WOX - 1) + k; q.oxg = q.OX / F_WOX; q.relu = relu ? 1 : 0;
     const size_t lds = (size_t)q.ncol * q.ZR * c_in * sizeof(float);
     static bool optin = false;
     if (!optin) {
         (void)hipFuncSetAttribute((const void *)conv_s221_fwd_kernel<63, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv_s221_fwd_kernel<27, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv_s221_fwd_kernel<54, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void *)conv_s221_fwd_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipGetLastError();
         optin = true;
@@ -564,8 +565,35 @@ int mdt_conv_s221_forward(const float *x, const float *wt, const float *bias, in
     (void)hipGetLastError();
     const dim3 grid(q.oxg * (Z / F_ZH), q.OY, batch), block(F_WOX * 64);
     if (q.ksteps == 63 && k == 7) hipLaunchKernelGGL((conv_s221_fwd_kernel<63, 7>), grid, block, lds, (hipStream_t)stream, x, wt, bias, y, q);
+    else if (q.ksteps == 27 && k == 3) hipLaunchKernelGGL((conv_s221_fwd_kernel<27, 3>), grid, block, lds, (hipStream_t)stream, x, wt, bias, y, q);
+    else if (q.ksteps == 54 && k == 3) hipLaunchKernelGGL((conv_s221_fwd_kernel<54, 3>), grid, block, lds, (hipStream_t)stream, x, wt, bias, y, q);
     else hipLaunchKernelGGL((conv_s221_fwd_kernel<0, 1>), grid, block, lds, (hipStream_t)stream, x, wt, bias, y, q);
     return s221_check();
+}
+
+int mdt_conv_s221_forward_supported(int Y, int X, int Z, int c_in, int c_out, int k)
+{
+    return win_forward_supported(Y, X, Z, c_in, c_out, k, 2);
+}
+
+/* y [B, Y/2, X/2, Z, c_out] (channels-last storage of [B, c_out, Y/2, X/2, Z]) = conv(x [B, Y, X, Z, c_in] channels-last, w, k x k x k, stride (2, 2, 1), pad k / 2)
+ * (+ bias)(ReLU); wt = the filter as [ky][kx][kz][ci][co] (w.permute(2, 3, 4, 1, 0) contiguous). */
+int mdt_conv_s221_forward(const float *x, const float *wt, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_in, int c_out, int k,
+                          void *stream)
+{
+    return win_forward(x, wt, bias, relu, y, batch, Y, X, Z, c_in, c_out, k, 2, stream);
+}
+
+/* the same kernel at unit stride (round 6): the size-preserving k x k x k, pad k / 2 convolution of a channels-last activation with few channels */
+int mdt_conv_win_forward_supported(int Y, int X, int Z, int c_in, int c_out, int k)
+{
+    return win_forward_supported(Y, X, Z, c_in, c_out, k, 1);
+}
+
+int mdt_conv_win_forward(const float *x, const float *wt, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_in, int c_out, int k,
+                         void *stream)
+{
+    return win_forward(x, wt, bias, relu, y, batch, Y, X, Z, c_in, c_out, k, 1, stream);
 }
 
 int mdt_conv_s221_input_grad_supported(int Y, int X, int Z, int c_in, int c_out, int k)
@@ -587,7 +615,7 @@ int mdt_conv_s221_input_grad(const float *gy, const float *wd, float *gx, int ba
     if ((((uintptr_t)gy) & 7) != 0) return MDT_ERR_UNSUPPORTED;
     S221F q;
     q.B = batch; q.Y = Y; q.X = X; q.Z = Z; q.Ci = c_in; q.Co = c_out; q.K = k; q.P = k / 2; q.OY = Y / 2; q.OX = X / 2;
-    q.KC = k * c_out; q.ksteps = q.KC / 2; q.ZR = F_ZH + k - 1; q.ncol = (k + 1) / 2 + 2; q.oxg = X / F_WOX; q.relu = 0;
+    q.KC = k * c_out; q.ksteps = q.KC / 2; q.ZR = F_ZH + k - 1; q.ncol = (k + 1) / 2 + 2; q.oxg = X / F_WOX; q.relu = 0; q.S = 2;
     const size_t lds = (size_t)q.ncol * q.ZR * c_out * sizeof(float);
     static bool optin = false;
     if (!optin) {

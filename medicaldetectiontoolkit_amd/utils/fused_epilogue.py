@@ -277,6 +277,9 @@ def _conv3_small_pays(cin, cout):
     return cin % 8 != 0 or cout % 8 != 0
 
 
+CONV_WIN = True     # module switch (A/B: bench.py --conv-win 0): the few-channel 3x3x3 layers on the unit-stride window kernel (mdt_conv_win_forward) where it is faster
+
+
 def conv3x3x3_small(x, w, bias=None, relu=False):
     """3x3x3 / stride 1 / pad 1 convolution of a channels_last_3d fp32 activation with a few-channel filter (C_in even <= 32,
     C_out <= 32, Z % 32 == 0) on the fp32-MFMA kernel of csrc/conv3x3x3_small.hip (MIOpen: 862 us for 18 -> 18 on 8 x 32x32x128),
@@ -294,6 +297,15 @@ def conv3x3x3_small(x, w, bias=None, relu=False):
         return None
     wt = w.permute(2, 3, 4, 1, 0).contiguous()                  # [27][C_in][C_out]
     y = torch.empty((B, cout, Y, X, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+    if CONV_WIN and L.mdt_conv_win_forward_supported(Y, X, Z, cin, cout, 3):
+        # round 6: the unit-stride instantiation of the window kernel of csrc/conv_s221.hip (z as the M dimension, Toeplitz A operand out of an LDS image of
+        # the input columns): 368 us against 404 us for 18 -> 18 on 8 x 32 x 32 x 128, 5.2 ms against 6.0 ms on 8 x 128^3 (tools/conv_win_probe.py)
+        rc = L.mdt_conv_win_forward(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, 1 if relu else 0, y.data_ptr(),
+                                    B, Y, X, Z, cin, cout, 3, _lib.raw_stream())
+        if rc == 0:
+            return y
+        if rc != _lib.MDT_ERR_UNSUPPORTED:
+            _lib.check(rc, "mdt_conv_win_forward")
     if bias is None and not relu:
         rc = L.mdt_conv3x3x3_small_forward(x.data_ptr(), wt.data_ptr(), y.data_ptr(), B, Y, X, Z, cin, cout, _lib.raw_stream())
     else:

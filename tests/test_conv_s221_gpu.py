@@ -127,3 +127,33 @@ def test_input_gradient_kernel_equals_the_direct_convolutions_gradient(B, Ci, Co
     err = ((gx.double().cpu() - ref).abs() / (mag + 1.0)).max()
     assert float(err) <= 1e-5, float(err)
     assert torch.equal(gx, fe.s221_input_grad(gy, w, (B, Ci, Y, X, Z)))
+
+
+@pytest.mark.parametrize("B,Ci,Co,Y,X,Z,k,epi", [(2, 18, 18, 8, 8, 64, 3, None), (1, 18, 18, 5, 12, 128, 3, "bias_relu"), (1, 36, 18, 4, 4, 64, 3, "bias"), (2, 6, 9, 3, 8, 64, 5, None)])
+def test_unit_stride_window_kernel_equals_the_direct_convolution(B, Ci, Co, Y, X, Z, k, epi, cuda):
+    """mdt_conv_win_forward (the forward kernel at stride 1; what utils/fused_epilogue.conv3x3x3_small dispatches for the 18 -> 18 layers) against F.conv3d in
+    float64: <= 1e-5 of the summed magnitudes, borders included, deterministic"""
+    from medicaldetectiontoolkit_amd import _lib
+    L = _lib.lib()
+    assert L.mdt_conv_win_forward_supported(Y, X, Z, Ci, Co, k) == 1
+    x = _rand((B, Ci, Y, X, Z), cuda, 31).contiguous(memory_format=CL)
+    w = _rand((Co, Ci, k, k, k), cuda, 32) * 0.1
+    bias = _rand((Co,), cuda, 33) if epi else None
+    wt = w.permute(2, 3, 4, 1, 0).contiguous()
+
+    def run():
+        y = torch.empty((B, Co, Y, X, Z), device=cuda).contiguous(memory_format=CL)
+        rc = L.mdt_conv_win_forward(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, 1 if epi == "bias_relu" else 0, y.data_ptr(),
+                                    B, Y, X, Z, Ci, Co, k, _lib.raw_stream())
+        assert rc == 0
+        return y
+    y = run()
+    xd, wd = x.double().cpu(), w.double().cpu()
+    ref = F.conv3d(xd, wd, bias.double().cpu() if bias is not None else None, 1, k // 2)
+    if epi == "bias_relu":
+        ref = torch.relu(ref)
+    mag = F.conv3d(xd.abs(), wd.abs(), None, 1, k // 2) + 1.0
+    assert float(((y.double().cpu() - ref).abs() / mag).max()) <= 1e-5
+    assert torch.equal(y, run())
+    if k == 3 and Ci == 18 and Co == 18 and B * Y * X * Z >= 65536:
+        assert torch.equal(fe.conv3x3x3_small(x, w, bias=bias, relu=(epi == "bias_relu")), y)        # the wrapper takes this kernel
