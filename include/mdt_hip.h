@@ -575,6 +575,12 @@ int mdt_rpn_patch_gather(int n_levels, const float *const *maps_cl, const int *Y
  * and adds it to the row-major maps: base + sum exactly once, independent of the launch order of the rows. */
 int mdt_rpn_patch_move_add(int n_levels, float *const *side_maps_cl, float *const *grad_maps_row_major, const int *Y, const int *X, const int *Z, int dim, int channels,
                            int anchors_per_voxel, const long long *idx, int n_samples, int n_per_element, void *stream);
+/* scatter_add_ordered: the DETERMINISTIC adjoint (what the model uses): every voxel has one writer -- the first row that lands on it adds the later rows with the
+ * same voxel in row order and read-modify-writes the voxel once; no atomics, works on zeroed maps and on maps that already hold a gradient, either layout.
+ * ids_workspace: n_samples * 3^dim int64 (device). */
+int mdt_rpn_patch_scatter_add_ordered(int n_levels, float *const *grad_maps, int row_major, const int *Y, const int *X, const int *Z, int dim, int channels,
+                                      int anchors_per_voxel, const long long *idx, int n_samples, int n_per_element, const float *grad_patches,
+                                      long long *ids_workspace, void *stream);
 int mdt_rpn_patch_scatter_add(int n_levels, float *const *grad_maps, int row_major, const int *Y, const int *X, const int *Z, int dim, int channels, int anchors_per_voxel,
                               const long long *idx, int n_samples, int n_per_element, const float *grad_patches, void *stream);
 

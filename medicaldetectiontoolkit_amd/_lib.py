@@ -87,6 +87,7 @@ _SIGNATURES = {
     "mdt_detection_targets": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 8 + [c_int] * 8 + [c_float] * 3 + [c_void_p] * 9),
     "mdt_rpn_patch_gather": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mdt_rpn_patch_move_add": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "mdt_rpn_patch_scatter_add_ordered": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mdt_rpn_patch_scatter_add": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mdt_refine_detections_supported": (c_int, [c_int, c_int, c_int]),
     "mdt_refine_detections_pre": (c_int, [c_void_p] * 6 + [c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -149,48 +149,20 @@ class _RpnPatches(torch.autograd.Function):
         g = g.contiguous()
 
         def scatter(outs, row_major):
+            # deterministic: one writer per voxel, rows that share a voxel added in row order (mdt_rpn_patch_scatter_add_ordered) -- float atomics made the
+            # step's gradients differ in the last bit from run to run (neighbourhoods of sampled anchors overlap)
             ptrs = (ctypes.c_void_p * len(outs))(*[_lib.ptr(o) for o in outs])
+            ids = torch.empty(int(idx_flat.shape[0]) * (3 ** dim), dtype=torch.int64, device=g.device)
             with torch.cuda.device(g.device):
-                rc = _lib.lib().mdt_rpn_patch_scatter_add(len(outs), ptrs, 1 if row_major else 0, Y, X, Z, dim, C, A, _lib.ptr(idx_flat), int(idx_flat.shape[0]),
-                                                          n_per_elem, _lib.ptr(g), _lib.current_stream_ptr())
-            _lib.check(rc, "mdt_rpn_patch_scatter_add")
-        if ctx.acc is not None:
-            # into the step's shared (row-major) buffers, after a RoIAlign backward has written them -- in two launches so that the result does not
-            # depend on the order in which rows that share a voxel arrive: sum the rows in persistent ZERO side maps (0 + a + b is exact either way,
-            # what the scatter into a fresh tensor always gave), then move every touched voxel's sum over (exchange with 0: the side maps are zero
-            # again for the next step) and add it to the buffers once
-            side = _rpn_side_maps(shapes, g.device, mf)
-
-            def move(bufs):
-                scatter(side, False)
-                sp = (ctypes.c_void_p * len(side))(*[_lib.ptr(o) for o in side])
-                bp = (ctypes.c_void_p * len(bufs))(*[_lib.ptr(o) for o in bufs])
-                with torch.cuda.device(g.device):
-                    rc = _lib.lib().mdt_rpn_patch_move_add(len(side), sp, bp, Y, X, Z, dim, C, A, _lib.ptr(idx_flat), int(idx_flat.shape[0]), n_per_elem,
-                                                           _lib.current_stream_ptr())
-                _lib.check(rc, "mdt_rpn_patch_move_add")
-            outs = ctx.acc.sparse(move)
+                rc = _lib.lib().mdt_rpn_patch_scatter_add_ordered(len(outs), ptrs, 1 if row_major else 0, Y, X, Z, dim, C, A, _lib.ptr(idx_flat),
+                                                                  int(idx_flat.shape[0]), n_per_elem, _lib.ptr(g), _lib.ptr(ids), _lib.current_stream_ptr())
+            _lib.check(rc, "mdt_rpn_patch_scatter_add_ordered")
+        if ctx.acc is not None:         # into the step's shared (row-major) buffers, after a RoIAlign backward has written them
+            outs = ctx.acc.sparse(lambda bufs: scatter(bufs, True))
             return (None, None, None) + (tuple(outs) if outs is not None else (None,) * len(shapes))
         outs = [torch.empty(sh, dtype=torch.float32, device=g.device, memory_format=mf).zero_() for sh in shapes]
         scatter(outs, False)
         return (None, None, None) + tuple(outs)
-
-
-_RPN_SIDE = {}
-
-
-def _rpn_side_maps(shapes, device, mf):
-    """persistent all-zero channels-last maps of the pyramid's shapes (one set per device and shape tuple; 173 MB at 8 x 128^3): the scratch the
-    sampled-anchor RPN gradient is summed in before it moves into the step's shared gradient buffers (mdt_rpn_patch_move_add leaves them zero)"""
-    key = (str(device), tuple(tuple(s) for s in shapes))
-    side = _RPN_SIDE.get(key)
-    if side is None:
-        if _lib.CAPTURING:
-            raise RuntimeError("the RPN side maps must exist before a hipGraph capture (the warm-up steps allocate them)")
-        if len(_RPN_SIDE) > 4:
-            _RPN_SIDE.clear()
-        side = _RPN_SIDE[key] = [torch.empty(tuple(s), dtype=torch.float32, device=device, memory_format=mf).zero_() for s in shapes]
-    return side
 
 
 def _rpn_patches_fused_ok(feature_maps, dim):

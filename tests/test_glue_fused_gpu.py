@@ -182,6 +182,17 @@ def test_rpn_at_anchors_fused_gather_equals_the_tensor_form(dim, patch, cuda):
     for a, b in zip(res[True][2] + res[True][3], res[False][2] + res[False][3]):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max() + 1e-12)), float((a - b).abs().max())
     assert all(float(gm.abs().sum()) > 0 for gm in res[True][2][:2])
+    # the scatter is deterministic (one writer per voxel, rows added in row order): a second backward gives the same bits although the 120 sampled
+    # neighbourhoods overlap heavily on the small upper levels
+    mrcnn.FUSED_GLUE = True
+    again = []
+    for _ in range(2):
+        maps = [torch.randn((B, cf.end_filts) + s, device=cuda, generator=torch.Generator(device=cuda).manual_seed(50 + k)).contiguous(memory_format=mf).requires_grad_(True)
+                for k, s in enumerate(levels)]
+        lg, dl = mrcnn.rpn_at_anchors(net.rpn, maps, idx, n_a)
+        ((lg * wl).sum() + (dl * wd).sum()).backward()
+        again.append([m.grad.clone() for m in maps])
+    assert all(torch.equal(a, b) for a, b in zip(*again)) and all(torch.equal(a, b) for a, b in zip(again[0], res[True][2]))
 
 
 @pytest.mark.parametrize("dim,pc,case", [(3, 75, "normal"), (3, 75, "nothing_confident"), (2, 500, "normal"), (3, 40, "one_element_empty")])
