@@ -132,8 +132,8 @@ class _FlipCache(object):
     change once per step (the optimizer), the ~60 flips of a step's backward are therefore ONE launch over a device table of
     {source, destination, shape} records -- issued by the first request of a backward, served from the persistent buffers for the rest.
     A filter is registered at its first request (single launch that time); dead weights (their nets were deleted) are dropped and the
-    table rebuilt.  Nothing is rebuilt while a hipGraph is being captured (the table upload is a host copy): requests that would need
-    it fall back to the single-filter launch."""
+    table rebuilt.  Eager steps only: inside a hipGraph capture flip_transpose_filter does not come here (a captured launch would keep the
+    address of a table that a later rebuild frees)."""
 
     def __init__(self, device):
         self.device = device
@@ -208,7 +208,9 @@ def flip_transpose_filter(w, mf):
     The returned tensor of the cached path is a persistent buffer: valid until the weights change (read it within the step)."""
     nd = w.dim() - 2
     if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous(memory_format=mf) and _on_current_device(w):
-        if FLIP_BATCHED and isinstance(w, torch.nn.Parameter):
+        # (never inside a hipGraph capture: the graph would bake the address of the record table, which is rebuilt -- and its old tensor freed -- as soon as
+        # another net registers filters; replays then read a stale table.  Captured steps keep one flip launch per layer, written into the graph's pool.)
+        if FLIP_BATCHED and not _lib.CAPTURING and isinstance(w, torch.nn.Parameter):
             cache = _FLIP.get(w.device)
             if cache is None:
                 cache = _FLIP[w.device] = _FlipCache(w.device)
