@@ -68,8 +68,8 @@ def test_graphed_step_reproduces_eager_step_bit_for_bit(cuda):
                 # step 0: same weights, only the run-to-run noise of MIOpen's atomics-based weight-gradient solvers; later steps: the two
                 # nets' weights have drifted apart by Adam's normalised updates of near-zero gradients (bounded below), which shows in the gradients
                 # later steps (round 6: bar 1e-2 instead of 5e-5): the two nets' weights differ by the ulp-level noise of step 0, and a DISCRETE
-                # decision of the step -- which negative anchor the SHEM pool's cut keeps, which RoI is drawn -- can flip on it: two of eight runs
-                # showed the same 8.85e-4 on the stem's weight gradient at k = 1 (one flipped sample), the others <= 1e-5.  The bit-level claim of
+                # decision of the step -- which negative anchor the SHEM pool's cut keeps, which RoI is drawn -- can flip on it: about half of the runs
+                # show 2.7e-4 .. 8.9e-4 on the stem's weight gradient at k = 1 or 2 (one flipped sample), the others <= 1e-5.  The bit-level claim of
                 # this test is step 0; the later steps show that replays follow the updated weights (a stale pointer is an O(1) error)
                 assert err <= (1e-5 if k == 0 else 1e-2) * float(grads_e[n].abs().max()) + 1e-12, (k, n, err)
         for (n, a), (_, b) in zip(net_e.named_parameters(), net_g.named_parameters()):
