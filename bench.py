@@ -609,6 +609,7 @@ def main():
     ap.add_argument("--conv-s221-fwd", type=int, default=1, help="1 (default): forward of the stride-(2, 2, 1) many-channel layer (the Retina U-Net's C1) on the fp32-MFMA kernel of csrc/conv_s221.hip; 0: MIOpen on the space-to-depth problem (A/B)")
     ap.add_argument("--conv-s221-dgrad", type=int, default=1, help="1 (default): input gradient of the same layer on this repo's fp32-MFMA kernel; 0: MIOpen forward convolution on the padded output gradient + fold (A/B)")
     ap.add_argument("--conv-win", type=int, default=1, help="1 (default): the few-channel 3x3x3 layers' forward / input gradient on the unit-stride window kernel where supported; 0: csrc/conv3x3x3_small.hip (A/B)")
+    ap.add_argument("--conv-win-wgrad", type=int, default=1, help="1 (default): weight gradient of the few-channel 3x3x3 layers on the unit-stride window kernel (mdt_conv_win_wgrad); 0: csrc/conv3x3x3_small.hip / MIOpen (A/B)")
     ap.add_argument("--conv3-small", type=int, default=1, help="1 (default): the few-channel 3x3x3 convolutions (18 -> 18 on the large maps) on the fp32-MFMA kernel (csrc/conv3x3x3_small.hip), forward and input gradient; 0: MIOpen (A/B)")
     ap.add_argument("--conv3-small-epilogue", type=int, default=int(os.environ.get("MDT_C3_EPILOGUE", "1")), help="1 (default): bias + ReLU of the few-channel 3x3x3 layers inside the convolution kernel's epilogue (utils/fused_epilogue._Conv3SmallBiasReLU); 0: separate epilogue pass (A/B)")
     ap.add_argument("--res-tap", type=int, default=1, help="1 (default): identity ResBlocks produce their input gradient already added to the residual gradient (utils/fused_epilogue._Conv1x1ResTap, csrc/epilogue.hip); 0: conv backward + autograd's accumulation pass (A/B)")
@@ -695,6 +696,7 @@ def main():
     fused_epilogue.S221_FWD = bool(args.conv_s221_fwd)
     fused_epilogue.S221_DGRAD = bool(args.conv_s221_dgrad)
     fused_epilogue.CONV_WIN = bool(args.conv_win)
+    fused_epilogue.CONV_WIN_WGRAD = bool(args.conv_win_wgrad)
     from medicaldetectiontoolkit_amd.configs import Configs
     from medicaldetectiontoolkit_amd.cuda_functions import _roi_align_impl
     from medicaldetectiontoolkit_amd.models import mrcnn, retina_unet

@@ -520,6 +520,12 @@ int mdt_conv_s221_input_grad(const float *gy, const float *wd, float *gx, int ba
 /* the forward kernel at UNIT stride: y [B, Y, X, Z, c_out] = conv3d(x, w, stride 1, pad k / 2) (+ bias)(ReLU) for channels-last x, wt as above -- what cuDNN computes for
  * the size-preserving few-channel 3x3x3 layers of NDConvGenerator (utils/model_utils.py:751-765; the 18 -> 18 ResBlock.conv2 of stage C2, models/backbone.py:186-190), and,
  * on the flipped / transposed filter, for their input gradient.  Same conditions with the full-resolution extents (Z % 64 == 0, X % 4 == 0). */
+/* ... and the weight gradient of those layers: mdt_conv_s221_wgrad's kernel at unit stride; gw in [c_out][ky][kx][kz][ci] memory order (channels_last_3d
+ * storage of the [c_out, c_in, k, k, k] gradient).  k * c_in <= 128, c_out <= 32, Z % 16 == 0. */
+int mdt_conv_win_wgrad_supported(int batch, int y, int x, int z, int c_in, int c_out, int k);
+size_t mdt_conv_win_wgrad_workspace_bytes(int batch, int y, int x, int z, int c_in, int c_out, int k);
+int mdt_conv_win_wgrad(const float *grad_out, const float *x, float *grad_weight, int batch, int y, int x_, int z, int c_in, int c_out, int k,
+                       void *workspace, size_t workspace_bytes, void *stream);
 int mdt_conv_win_forward_supported(int Y, int X, int Z, int c_in, int c_out, int k);
 int mdt_conv_win_forward(const float *x, const float *wt, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_in, int c_out, int k,
                          void *stream);

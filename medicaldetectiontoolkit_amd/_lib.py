@@ -50,6 +50,9 @@ _SIGNATURES = {
     "mdt_conv_s221_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "mdt_conv_s221_input_grad_supported": (c_int, [c_int] * 6),
     "mdt_conv_s221_input_grad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "mdt_conv_win_wgrad_supported": (c_int, [c_int] * 7),
+    "mdt_conv_win_wgrad_workspace_bytes": (c_size_t, [c_int] * 7),
+    "mdt_conv_win_wgrad": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "mdt_conv_win_forward_supported": (c_int, [c_int] * 6),
     "mdt_conv_win_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 7 + [c_void_p]),
     "mdt_conv_s221_forward_supported": (c_int, [c_int] * 6),

@@ -110,6 +110,7 @@ constexpr int G_SEG = 32;           // output columns per unit
 struct S221 {
     int B, Y, X, Z, Ci, Co, K, P, OY, OX;
     int waves_per_pair, nseg, units;        // units per pair = B * OY * nseg
+    int S;                                  // (y, x) stride: 2, or 1 (round 6: the size-preserving few-channel layers, mdt_conv_win_wgrad)
 };
 
 template <int MT>
@@ -135,25 +136,25 @@ __global__ __launch_bounds__(G_THREADS, 2) void conv_s221_wgrad_kernel(const flo
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     // output columns whose input column 2 ox + kx - P exists
-    const int d = q.P - kx;                                     // ix = 2 ox - d
-    const int ox_min = d > 0 ? (d + 1) / 2 : 0;
-    int ox_max = (q.X - 1 + d) >= 0 ? (q.X - 1 + d) / 2 : -1;   // FLOOR: C division truncates towards zero, (-1) / 2 == 0 would admit ox = 0 with ix >= X (X < K)
+    const int d = q.P - kx;                                     // ix = S ox - d
+    const int ox_min = d > 0 ? (d + q.S - 1) / q.S : 0;
+    int ox_max = (q.X - 1 + d) >= 0 ? (q.X - 1 + d) / q.S : -1;   // FLOOR: C division truncates towards zero, (-1) / 2 == 0 would admit ox = 0 with ix >= X (X < K)
     if (ox_max > q.OX - 1) ox_max = q.OX - 1;
     const int tpc = q.Z / (2 * G_UNROLL);                       // trips per column
 
     for (int unit = wi; unit < q.units; unit += q.waves_per_pair) {
         const int row = unit / q.nseg, seg = unit - row * q.nseg;
         const int b = row / q.OY, oy = row - b * q.OY;
-        const int iy = 2 * oy + ky - q.P;
+        const int iy = q.S * oy + ky - q.P;
         if (iy < 0 || iy >= q.Y) continue;
         const int lo = max(ox_min, seg * G_SEG), hi = min(ox_max, seg * G_SEG + G_SEG - 1);
         if (lo > hi) continue;
-        const float *xbase = x + (((long long)b * q.Y + iy) * q.X + (2 * lo - d)) * ZCi;            // next column: + 2 * ZCi
+        const float *xbase = x + (((long long)b * q.Y + iy) * q.X + (q.S * lo - d)) * ZCi;          // next column: + S * ZCi
         const float *gbase = gy + (((long long)b * q.OY + oy) * q.OX + lo) * ZCo;                  // next column: + ZCo
         const int total = (hi - lo + 1) * tpc;
 
         auto load = [&](int col, int tr, float (&a)[G_UNROLL][MT], float (&bb)[G_UNROLL]) {
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(xbase + (long long)col * 2 * ZCi), 0, ZCi * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(xbase + (long long)col * q.S * ZCi), 0, ZCi * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(gbase + (long long)col * ZCo), 0, ZCo * 4, 0x00020000);
             const int j0 = tr * (2 * G_UNROLL) * q.Ci * 4, g0 = tr * (2 * G_UNROLL) * q.Co * 4;
 #pragma unroll
@@ -233,13 +234,13 @@ __global__ __launch_bounds__(256) void conv_s221_wgrad_finish_kernel(const float
     gw[((long long)co * K * K + pair) * rows + m] = s;
 }
 
-bool wgrad_plan(int B, int Y, int X, int Z, int Ci, int Co, int K, S221 &q)
+bool wgrad_plan(int B, int Y, int X, int Z, int Ci, int Co, int K, S221 &q, int S = 2)
 {
     if (B <= 0 || Y <= 0 || X <= 0 || Z <= 0 || Ci <= 0 || Co <= 0 || K < 3 || (K & 1) == 0) return false;
-    if (K * Ci > 128 || Co > 32 || (Y & 1) || (X & 1) || Z % (2 * G_UNROLL) != 0) return false;
+    if (K * Ci > 128 || Co > 32 || (Y % S) || (X % S) || Z % (2 * G_UNROLL) != 0) return false;
     if ((long long)Z * Ci * 4 >= (1LL << 30)) return false;
-    q.B = B; q.Y = Y; q.X = X; q.Z = Z; q.Ci = Ci; q.Co = Co; q.K = K; q.P = K / 2;
-    q.OY = Y / 2; q.OX = X / 2;                   // (Y + 2 P - K) / 2 + 1 with P = K / 2, Y even
+    q.B = B; q.Y = Y; q.X = X; q.Z = Z; q.Ci = Ci; q.Co = Co; q.K = K; q.P = K / 2; q.S = S;
+    q.OY = Y / S; q.OX = X / S;                   // (Y + 2 P - K) / S + 1 with P = K / 2, S | Y
     q.nseg = (q.OX + G_SEG - 1) / G_SEG;
     const long long units = (long long)B * q.OY * q.nseg;
     if (units > (1LL << 30)) return false;
@@ -509,12 +510,41 @@ size_t mdt_conv_s221_wgrad_workspace_bytes(int batch, int y, int x_, int z, int 
     return (size_t)k * k * q.waves_per_pair * k * c_in * c_out * sizeof(float) + 256;
 }
 
+static int win_wgrad(const float *grad_out, const float *x, float *grad_weight, int batch, int y, int x_, int z, int c_in, int c_out, int k, int S,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 int mdt_conv_s221_wgrad(const float *grad_out, const float *x, float *grad_weight, int batch, int y, int x_, int z, int c_in, int c_out, int k,
                         void *workspace, size_t workspace_bytes, void *stream)
 {
+    return win_wgrad(grad_out, x, grad_weight, batch, y, x_, z, c_in, c_out, k, 2, workspace, workspace_bytes, stream);
+}
+
+/* the weight-gradient kernel at UNIT stride (round 6): gw [c_out][ky][kx][kz][ci] of the size-preserving k x k x k, pad k / 2 convolution */
+int mdt_conv_win_wgrad_supported(int batch, int y, int x_, int z, int c_in, int c_out, int k)
+{
+    S221 q;
+    return wgrad_plan(batch, y, x_, z, c_in, c_out, k, q, 1) ? 1 : 0;
+}
+
+size_t mdt_conv_win_wgrad_workspace_bytes(int batch, int y, int x_, int z, int c_in, int c_out, int k)
+{
+    S221 q;
+    if (!wgrad_plan(batch, y, x_, z, c_in, c_out, k, q, 1)) return 0;
+    return (size_t)k * k * q.waves_per_pair * k * c_in * c_out * sizeof(float) + 256;
+}
+
+int mdt_conv_win_wgrad(const float *grad_out, const float *x, float *grad_weight, int batch, int y, int x_, int z, int c_in, int c_out, int k,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    return win_wgrad(grad_out, x, grad_weight, batch, y, x_, z, c_in, c_out, k, 1, workspace, workspace_bytes, stream);
+}
+
+static int win_wgrad(const float *grad_out, const float *x, float *grad_weight, int batch, int y, int x_, int z, int c_in, int c_out, int k, int S,
+                     void *workspace, size_t workspace_bytes, void *stream)
+{
     S221 q;
     if (!grad_out || !x || !grad_weight) return MDT_ERR_INVALID_ARGUMENT;
-    if (!wgrad_plan(batch, y, x_, z, c_in, c_out, k, q)) return MDT_ERR_UNSUPPORTED;
+    if (!wgrad_plan(batch, y, x_, z, c_in, c_out, k, q, S)) return MDT_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < (size_t)k * k * q.waves_per_pair * k * c_in * c_out * sizeof(float)) return MDT_ERR_WORKSPACE_TOO_SMALL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *ws = static_cast<float *>(workspace);

@@ -318,6 +318,35 @@ def conv3x3x3_small(x, w, bias=None, relu=False):
     return y
 
 
+CONV_WIN_WGRAD = True     # module switch (A/B: bench.py --conv-win-wgrad 0)
+
+
+def conv_win_weight_grad(gy, x, w):
+    """weight gradient of a size-preserving k x k x k layer with k * C_in <= 128, C_out <= 32 on the window kernel of csrc/conv_s221.hip at unit stride
+    (mdt_conv_win_wgrad): M = the (kz, ci) window rows straight out of the channels-last input column, N = co, K = the voxels; None outside its budgets"""
+    if not (CONV_WIN_WGRAD and gy.is_cuda and gy.dtype == torch.float32 and x.dtype == torch.float32 and x.dim() == 5 and w.dim() == 5 and _on_current_device(gy)
+            and x.is_contiguous(memory_format=torch.channels_last_3d)):
+        return None
+    k = int(w.shape[2])
+    if tuple(int(v) for v in w.shape[2:]) != (k, k, k):
+        return None
+    B, Ci, Y, X, Z = (int(v) for v in x.shape)
+    Co = int(w.shape[0])
+    L = _lib.lib()
+    if int(w.shape[1]) != Ci or tuple(int(v) for v in gy.shape) != (B, Co, Y, X, Z) or not L.mdt_conv_win_wgrad_supported(B, Y, X, Z, Ci, Co, k):
+        return None
+    if not gy.is_contiguous(memory_format=torch.channels_last_3d):
+        gy = gy.contiguous(memory_format=torch.channels_last_3d)
+    ws = _workspace(L.mdt_conv_win_wgrad_workspace_bytes(B, Y, X, Z, Ci, Co, k), gy.device)
+    gw = torch.empty((Co, k, k, k, Ci), dtype=torch.float32, device=gy.device)
+    rc = L.mdt_conv_win_wgrad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), B, Y, X, Z, Ci, Co, k, ws.data_ptr(), ws.numel(), _lib.raw_stream())
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        _lib.check(rc, "mdt_conv_win_wgrad")
+    return gw.permute(0, 4, 1, 2, 3)
+
+
 def conv3x3x3_small_weight_grad(gy, x, w):
     """weight gradient of the few-channel 3x3x3 layer on the same MFMA machinery (csrc/conv3x3x3_small.hip; MIOpen: 1078 us for
     18 -> 18 on 8 x 32x32x128).  None when the shape is not of that form."""
@@ -327,6 +356,12 @@ def conv3x3x3_small_weight_grad(gy, x, w):
     B, cin, Y, X, Z = (int(v) for v in x.shape)
     cout = int(w.shape[0])
     L = _lib.lib()
+    if B * Y * X * Z >= 65536 and _conv3_small_pays(cin, cout):
+        # round 6: the window kernel at unit stride (mdt_conv_win_wgrad): 460 us against 598 us for 18 -> 18 on 8 x 32 x 32 x 128, 5.0 against 9.4 ms on 8 x 128^3,
+        # and 36 -> 18 / 36 -> 32 which the older kernel does not cover (2.6 ms against MIOpen's 3.9; tools/conv_win_probe.py)
+        gw = conv_win_weight_grad(gy, x, w)
+        if gw is not None:
+            return gw
     if not L.mdt_conv3x3x3_small_supported(Y, X, Z, cin, cout) or B * Y * X * Z < 65536 or not _conv3_small_pays(cin, cout) \
             or not x.is_contiguous(memory_format=torch.channels_last_3d):
         return None

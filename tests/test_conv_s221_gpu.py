@@ -157,3 +157,18 @@ def test_unit_stride_window_kernel_equals_the_direct_convolution(B, Ci, Co, Y, X
     assert torch.equal(y, run())
     if k == 3 and Ci == 18 and Co == 18 and B * Y * X * Z >= 65536:
         assert torch.equal(fe.conv3x3x3_small(x, w, bias=bias, relu=(epi == "bias_relu")), y)        # the wrapper takes this kernel
+
+
+@pytest.mark.parametrize("B,Ci,Co,Y,X,Z,k", [(2, 18, 18, 8, 8, 32, 3), (1, 18, 18, 5, 7, 48, 3), (1, 36, 18, 6, 6, 16, 3), (2, 6, 9, 3, 5, 32, 5), (1, 36, 32, 4, 4, 16, 3)])
+def test_unit_stride_weight_gradient_kernel_equals_aten(B, Ci, Co, Y, X, Z, k, cuda):
+    """mdt_conv_win_wgrad (the weight-gradient kernel at stride 1) against the float64 gradient of F.conv3d: <= 2e-5 of the maximum, deterministic"""
+    x = _rand((B, Ci, Y, X, Z), cuda, 41).contiguous(memory_format=CL)
+    w = _rand((Co, Ci, k, k, k), cuda, 42)
+    gy = _rand((B, Co, Y, X, Z), cuda, 43).contiguous(memory_format=CL)
+    gw = fe.conv_win_weight_grad(gy, x, w)
+    assert gw is not None and gw.shape == w.shape
+    wd = w.double().cpu().requires_grad_(True)
+    ref, = torch.autograd.grad(F.conv3d(x.double().cpu(), wd, None, 1, k // 2), wd, gy.double().cpu())
+    err = float((gw.double().cpu() - ref).abs().max())
+    assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, (err, float(ref.abs().max()))
+    assert torch.equal(gw, fe.conv_win_weight_grad(gy, x, w))

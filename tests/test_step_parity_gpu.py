@@ -42,7 +42,7 @@ def _batch(case="small"):
 # (round 6: forward and input gradient of these layers run on the unit-stride window kernel, mdt_conv_win_forward, where its shape conditions hold -- Z % 64 == 0,
 # X % 4 == 0 -- and on csrc/conv3x3x3_small.hip otherwise: either entry point counts; the forward's bias + ReLU epilogue is inside both)
 MFMA_CALLS = {"mdt_conv3x3x3_small_forward+mdt_conv3x3x3_small_forward_bias_act+mdt_conv_win_forward": 6,
-              "mdt_conv3x3x3_small_wgrad": 3, "mdt_conv1x1_wgrad": 6, "mdt_conv_stem_forward": 1, "mdt_conv_stem_wgrad": 1}
+              "mdt_conv3x3x3_small_wgrad+mdt_conv_win_wgrad": 3, "mdt_conv1x1_wgrad": 6, "mdt_conv_stem_forward": 1, "mdt_conv_stem_wgrad": 1}
 
 
 def _ncalls(calls, name):
@@ -162,7 +162,7 @@ def test_retina_unet_large_step_matches_reference_with_mfma_conv_kernels_dispatc
             _lib.count_calls(False)
     finally:
         torch.backends.cudnn.benchmark = prev
-    for name in ("mdt_conv3x3x3_small_forward+mdt_conv3x3x3_small_forward_bias_act+mdt_conv_win_forward", "mdt_conv3x3x3_small_wgrad", "mdt_conv1x1_wgrad"):
+    for name in ("mdt_conv3x3x3_small_forward+mdt_conv3x3x3_small_forward_bias_act+mdt_conv_win_forward", "mdt_conv3x3x3_small_wgrad+mdt_conv_win_wgrad", "mdt_conv1x1_wgrad"):
         assert _ncalls(calls, name) >= MFMA_CALLS[name], (name, calls)
     # the C1 layer of models/backbone.py:54 runs in space-to-depth form with its weight gradient on this repo's kernel (round 5): a use-rule
     # that silently routed it back to MIOpen's direct strided problem must fail here

@@ -45,3 +45,16 @@ for (B, C, Co, Y, X, Z) in [(8, 18, 18, 32, 32, 128), (8, 18, 18, 128, 128, 128)
     gf = 2.0 * B * Y * X * Z * C * Co * 27 / 1e9
     print("%s %d->%d: window kernel %.0f us (%.1f TF/s)   conv3x3x3_small %.0f us   MIOpen %.0f us   max |diff| %.3g of %.3g" % (
         (B, Y, X, Z), C, Co, t_win, gf / t_win * 1e3 / 1e3, t_small, t_mi, float((y - ref).abs().max()) if ok else float("nan"), float(ref.abs().max())), flush=True)
+
+for (B, C, Co, Y, X, Z) in [(8, 18, 18, 32, 32, 128), (8, 18, 18, 128, 128, 128), (8, 36, 18, 64, 64, 128), (8, 36, 32, 32, 32, 128)]:
+    x = torch.randn(B, C, Y, X, Z, device=dev).contiguous(memory_format=torch.channels_last_3d)
+    w = torch.randn(Co, C, 3, 3, 3, device=dev) * 0.1
+    gy = torch.randn(B, Co, Y, X, Z, device=dev).contiguous(memory_format=torch.channels_last_3d)
+    g1 = fe.conv_win_weight_grad(gy, x, w)
+    t_win = timed(lambda: fe.conv_win_weight_grad(gy, x, w)) if g1 is not None else float("nan")
+    g2 = fe.conv3x3x3_small_weight_grad(gy, x, w)
+    t_small = timed(lambda: fe.conv3x3x3_small_weight_grad(gy, x, w)) if g2 is not None else float("nan")
+    ref = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1, [False, True, False])[1]
+    t_mi = timed(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1, [False, True, False]), reps=5)
+    print("wgrad %s %d->%d: window kernel %.0f us   conv3x3x3_small_wgrad %.0f us   MIOpen %.0f us   max |diff| %.3g of %.3g" % (
+        (B, Y, X, Z), C, Co, t_win, t_small, t_mi, float((g1 - ref).abs().max()) if g1 is not None else float("nan"), float(ref.abs().max())), flush=True)
