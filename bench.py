@@ -498,7 +498,7 @@ def secondary_configs(timeout_s=240):
     env["MDT_MIOPEN_SKIP_NAIVE"] = "1"          # never let the find try the naive direct solvers on 128^3 decoder maps
     out = {}
     jobs = {
-        "config2_retina_unet_128_b8": [sys.executable, os.path.abspath(__file__), "--model", "retina_unet", "--steps", "3", "--warmup", "2",
+        "config2_retina_unet_128_b8": [sys.executable, os.path.abspath(__file__), "--model", "retina_unet", "--steps", "3", "--warmup", "2", "--settle", "2",
                                        "--no-cpu-baseline", "--no-h2d-leg", "--no-rccl-selftest", "--no-secondary", "--no-roofline"],
         "config1_toy2d_retina_net_64x64_b20": [sys.executable, os.path.join(ROOT, "tools", "bench_toy2d.py"), "--steps", "30", "--sizes", "64"],
         "config5_inference_512x512x256_bf16": [sys.executable, os.path.join(ROOT, "tools", "bench_inference.py"), "--amp", "bf16",
@@ -629,6 +629,7 @@ def main():
     ap.add_argument("--pin-cores", type=int, default=1, help="N > 1: 1 (default) pins every rank to its own slice of the cores of its GPU's NUMA node (utils/affinity.py); 0: only caps the intra-op threads")
     ap.add_argument("--backend", type=str, default="nccl", help="nccl (= RCCL, default) | gloo (debug: lets several ranks share one GPU)")
     ap.add_argument("--channels-last", type=int, default=1)
+    ap.add_argument("--settle", type=int, default=-1, help="untimed steps after the --warmup steps (default: as many as bring warm-up to 25 steps; 0 to switch off)")
     ap.add_argument("--step-form", type=str, default="exec", choices=["exec", "no-readout"],
                     help="exec (default): the step exec.py:68-79 runs -- train_forward WITH the per-batch read-out (logger_string, box lists, monitor_values; one "
                          "packed asynchronous device->host copy, consumed every step) and the mask head over the detections (mrcnn.py:1046-1048), backward, Adam; "
@@ -787,6 +788,12 @@ def main():
             setattr(sync, name, timed)
 
     for i in range(max(args.warmup, 1 if use_graph else 0)):
+        run_step(pool[i % len(pool)])
+    # settle steps (untimed, the same fixed count on every rank): the FIRST process on a fresh box runs its steps 5 .. 25 at 34.9 ms instead of 31.8 (measured:
+    # three bench runs in a row on one fresh box gave 229.6 / 249.2 / 251.8 patches/s for --warmup 5, 251.5 for --warmup 25; the later legs of the first run were at
+    # full speed) -- box-level warm-up (MIOpen's kernel cache being written, clocks), not part of the step.  K steps are timed exactly, after W + settle untimed ones.
+    settle = max(0, 25 - args.warmup) if args.settle < 0 else args.settle
+    for i in range(settle):
         run_step(pool[i % len(pool)])
     barrier()
     prof = None
@@ -1006,7 +1013,7 @@ def main():
         out = {
             "metric": "3D patches/sec (train), %s %s" % ("^3".join([str(patch[0]), ""]) if len(set(patch)) == 1 else "x".join(map(str, patch)),
                                                        "Mask R-CNN" if args.model == "mrcnn" else "Retina U-Net"), "value": round(patches / elapsed, 3), "unit": "patches/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "host_issue_ms_per_step": round(host_issue / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host numpy batches, PCIe inclusive)" if args.host_batches else " (resident in HBM)"),
             "config": {"workload": "LIDC-shape 3D %s, %s fp32 patches, batch %d per GPU, random-init weights, Adam lr 1e-4" % (

@@ -135,7 +135,7 @@ def test_bench_refuses_more_gpus_than_present(cuda):
     n = torch.cuda.device_count() + 1
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--settle", "0"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode != 0
     assert "requested but this node exposes" in r.stderr
@@ -156,7 +156,7 @@ def test_bench_rank_code_path_world4_gloo(cuda):
     env["MDT_MIOPEN_SKIP_NAIVE"] = "1"
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--patch", "64,64,32",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--settle", "0", "--patch", "64,64,32",
            "--batch", "2", "--graph", "1", "--no-secondary", "--no-cpu-baseline", "--no-roofline", "--no-h2d-leg", "--no-exec-leg", "--no-eager-leg",
            "--no-graph-preflight", "--no-rccl-selftest"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -188,7 +188,7 @@ def test_bench_rank_path_world8_host_work_does_not_grow_with_the_rank_count(cuda
     env["MDT_MIOPEN_SKIP_NAIVE"] = "1"
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    common = ["--backend", "gloo", "--steps", "6", "--warmup", "3", "--patch", "32,32,16", "--batch", "2", "--graph", "0", "--no-secondary", "--no-cpu-baseline",
+    common = ["--backend", "gloo", "--steps", "6", "--warmup", "3", "--settle", "0", "--patch", "32,32,16", "--batch", "2", "--graph", "0", "--no-secondary", "--no-cpu-baseline",
               "--no-roofline", "--no-h2d-leg", "--no-exec-leg", "--no-eager-leg", "--no-graph-leg", "--no-dense-rpn-leg", "--no-rccl-selftest"]
     recs = {}
     for world in (1, 8):

@@ -7,7 +7,7 @@ BENCH_ARGS=${BENCH_ARGS:-}
 mkdir -p $ROOT/gpurun_out $ROOT/gpurun_out/$(dirname ${OUT_NAME:-x}) $ROOT/gpurun_out/$(dirname ${GLUE_OUT:-x})
 cd /tmp && export TMPDIR=/tmp
 rm -rf $ROOT/gpurun_out/prof_step
-timeout ${2:-420} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_step -o step -- python $ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-h2d-leg --no-rccl-selftest --no-dense-rpn-leg $BENCH_ARGS > $ROOT/gpurun_out/prof_step.log 2>&1 < /dev/null
+timeout ${2:-420} rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_step -o step -- python $ROOT/bench.py --steps $STEPS --warmup 3 --settle 0 --no-cpu-baseline --no-h2d-leg --no-rccl-selftest --no-dense-rpn-leg $BENCH_ARGS > $ROOT/gpurun_out/prof_step.log 2>&1 < /dev/null
 LINE=$(grep '^{"metric"' $ROOT/gpurun_out/prof_step.log | tail -1)
 echo "$LINE" | cut -c1-300
 MS=$(echo "$LINE" | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
