@@ -218,6 +218,8 @@ size_t mdt_bias_act_backward_workspace_bytes(long long n, int channels, long lon
 int mdt_bias_act_backward(float *gx, const float *gy, const float *y, float *gbias,
                           long long n, int channels, long long inner, int relu,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* relu == 0: gx may be NULL -- the input gradient IS gy then and nothing is stored (round 6: the bias-only layers' backward was
+ * writing a copy of gy, 151 MB on the FPN's P2 map). */
 /* The same in ONE launch for channels-last storage (inner == 1): the block that draws the last ticket folds the per-block partials into gbias
  * inside the launch (agent-scope release / acquire around the ticket).  `ticket`: one device int the CALLER owns, 0 on entry, left 0 on exit
  * (launches that share a ticket must be ordered on one stream).  inner != 1 runs the two-launch form.  The summation order differs from
@@ -225,6 +227,27 @@ int mdt_bias_act_backward(float *gx, const float *gy, const float *y, float *gbi
 int mdt_bias_act_backward_ticket(float *gx, const float *gy, const float *y, float *gbias,
                                  long long n, int channels, long long inner, int relu,
                                  void *workspace, size_t workspace_bytes, int *ticket, void *stream);
+
+/*
+ * y = x + bias[c] + coarse[b][y / sy][x / sx][z / sz][c] on channels-last fp32 storage ([batch][Y][X][Z][channels], channels % 4 == 0;
+ * coarse: [batch][Y / sy][X / sx][Z / sz][channels]); y may alias x.  The FPN's top-down step (models/backbone.py:147-153:
+ * P_conv1(c) + F.interpolate(p, scale_factor=2), mode 'nearest') without materialising the up-sampled map.  2D maps: Z = 1, sz = 1.
+ * Same value as mdt_bias_act_forward on the materialised residual (same order of the two additions).
+ */
+int mdt_bias_act_forward_upsampled_supported(int channels, long long n);
+int mdt_bias_act_forward_upsampled(float *y, const float *x, const float *bias, const float *coarse, int batch, int Y, int X, int Z, int channels,
+                                   int sy, int sx, int sz, void *stream);
+
+/*
+ * Backward of a bias-only epilogue whose output gradient arrives ROW-MAJOR ([batch][channels][inner]) while the layer runs channels-last:
+ * gx[b][v][c] = gy[b][c][v] and gbias[c] = sum of gy over channel c in one pass (fixed summation order).  channels <= 48.
+ * Replaces tensor.contiguous(memory_format=channels_last_3d) + mdt_bias_act_backward in front of the FPN's P_conv2 layers
+ * (models/backbone.py:155-160), whose output gradients come from the RoIAlign backward's row-major maps.
+ */
+int mdt_bias_grad_to_channels_last_supported(int channels);
+size_t mdt_bias_grad_to_channels_last_workspace_bytes(int batch, int channels, long long inner);
+int mdt_bias_grad_to_channels_last(float *gx, const float *gy, float *gbias, int batch, int channels, long long inner,
+                                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- */
 /* Non-maximum suppression                                                    */

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (RELU) g[u] = (v[u] > 0.0f) ? g[u] : 0.0f;
-                    gx[(p + (long long)u * ppb) * C + c] = g[u];
+                    if (RELU || gx != nullptr) gx[(p + (long long)u * ppb) * C + c] = g[u];
                     acc = acc + g[u];
                 }
             }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
                 const long long i = p * C + c;
                 float g = gy[i];
                 if (RELU) g = (y[i] > 0.0f) ? g : 0.0f;
-                gx[i] = g;
+                if (RELU || gx != nullptr) gx[i] = g;
                 acc = acc + g;
             }
         }
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (RELU) g[u] = (v[u] > 0.0f) ? g[u] : 0.0f;
-                        gx[(p + u) * C + c] = g[u];
+                        if (RELU || gx != nullptr) gx[(p + u) * C + c] = g[u];
                         acc = acc + g[u];
                     }
                 }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
                     const long long i = p * C + c;
                     float g = gy[i];
                     if (RELU) g = (y[i] > 0.0f) ? g : 0.0f;
-                    gx[i] = g;
+                    if (RELU || gx != nullptr) gx[i] = g;
                     acc = acc + g;
                 }
                 store_partial(partial + (long long)blockIdx.x * C + c, acc, ticket != nullptr);
@@ -226,6 +226,75 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
     }
 }
 
+// ---- forward with the residual UP-SAMPLED on the fly (round 6) ---------------------------------------------------------------------
+// y = x + bias[c] + coarse[b][y / sy][x / sx][z / sz][c] on channels-last storage: the FPN's top-down step (models/backbone.py:147-153:
+// P_conv1(c) + F.interpolate(p_coarser, scale_factor=2)) without materialising the up-sampled map (a 151 MB write + read on P2 at the
+// benchmark patch).  Thread = 4 consecutive channels of one voxel (C % 4 == 0); index math is 32-bit.
+__global__ __launch_bounds__(EP_THREADS) void bias_act_fwd_up_kernel(float *y, const float *x, const float *__restrict__ bias, const float *__restrict__ coarse,
+                                                                     unsigned n4, unsigned q, unsigned Y, unsigned X, unsigned Z, unsigned sy, unsigned sx, unsigned sz)
+{
+    const unsigned Yc = Y / sy, Xc = X / sx, Zc = Z / sz;
+    const unsigned stride = gridDim.x * EP_THREADS;
+    for (unsigned i4 = blockIdx.x * EP_THREADS + threadIdx.x; i4 < n4; i4 += stride) {
+        const unsigned vox = i4 / q, cq = i4 - vox * q;
+        const unsigned r = vox / Z, zz = vox - r * Z;
+        const unsigned r2 = r / X, xx = r - r2 * X;
+        const unsigned b = r2 / Y, yy = r2 - b * Y;
+        const unsigned cv = ((b * Yc + yy / sy) * Xc + xx / sx) * Zc + zz / sz;
+        v4f v = reinterpret_cast<const v4f *>(x)[i4];
+        float bb[4];                                                  // (scalar loads: a bias inside a flat parameter buffer is only 4-byte aligned)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bb[k] = bias[cq * 4 + k];
+        const v4f rr = reinterpret_cast<const v4f *>(coarse)[(unsigned long long)cv * q + cq];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] + bb[k] + rr[k];      // the order of mdt_bias_act_forward with a residual
+        reinterpret_cast<v4f *>(y)[i4] = v;
+    }
+}
+
+// ---- backward of a bias-only epilogue whose output gradient arrives ROW-MAJOR while the layer runs channels-last (round 6) ----------
+// gx[b][v][c] = gy[b][c][v], gbias[c] = sum of gy over channel c, one pass: the P_conv2 layers of the FPN receive their output gradient
+// from the RoIAlign backward / the RPN patch scatter (row-major maps, cuda_functions/_roi_align_impl.PyramidGradAccumulator) and hand it
+// to a channels-last convolution backward -- a layout copy (302 MB of traffic on P2) followed by the bias reduction (151 MB) before.
+// Block = 256 voxels of one batch element: thread = voxel reads its C values (a wave reads 256 contiguous bytes per channel) into an
+// LDS tile [voxel][C | 1]; then thread = (voxel lane, channel) streams the tile out as one contiguous run of 256 * C floats, summing its
+// channel on the way; lanes are folded in lane order, per-block partials go to bias_grad_finish_kernel (fixed order, deterministic).
+constexpr int TR_TV = 256;
+__global__ __launch_bounds__(EP_THREADS) void bias_grad_to_cl_kernel(float *__restrict__ gx, const float *__restrict__ gy, float *__restrict__ partial,
+                                                                     long long V, int C, int ppb, int tiles_per_elem)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_t[];      // [TR_TV][C | 1], then [EP_THREADS]
+    const int CS = C | 1;
+    float *s_acc = s_t + TR_TV * CS;
+    const int t = threadIdx.x;
+    const int b = blockIdx.x / tiles_per_elem, tile = blockIdx.x - b * tiles_per_elem;
+    const long long v0 = (long long)tile * TR_TV;
+    const int nv = (int)min((long long)TR_TV, V - v0);
+    if (t < nv) {
+        const float *src = gy + (long long)b * C * V + v0 + t;
+#pragma unroll 6
+        for (int c = 0; c < C; ++c) s_t[t * CS + c] = src[(long long)c * V];
+    }
+    __syncthreads();
+    const int pl = t / C, c = t - pl * C;
+    float acc = 0.0f;
+    if (pl < ppb) {
+        float *dst = gx + ((long long)b * V + v0) * C + c;
+        for (int p = pl; p < nv; p += ppb) {
+            const float g = s_t[p * CS + c];
+            dst[(long long)p * C] = g;
+            acc = acc + g;
+        }
+    }
+    s_acc[t] = acc;
+    __syncthreads();
+    if (t < C) {
+        float sum = 0.0f;
+        for (int l = 0; l < ppb; ++l) sum = sum + s_acc[l * C + t];
+        partial[(long long)blockIdx.x * C + t] = sum;
+    }
+}
+
 // ---- backward, contiguous NC(D)HW: one block per chunk of one (n, c) row ---------------------------------------
 template <bool RELU>
 __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_nc_kernel(float *__restrict__ gx, const float *__restrict__ gy,
@@ -243,7 +312,7 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_nc_kernel(float *__re
         const long long i = row * inner + e;
         float g = gy[i];
         if (RELU) g = (y[i] > 0.0f) ? g : 0.0f;
-        gx[i] = g;
+        if (RELU || gx != nullptr) gx[i] = g;
         acc = acc + g;
     }
     s_acc[threadIdx.x] = acc;
@@ -439,7 +508,7 @@ static int bias_act_backward_impl(float *gx, const float *gy, const float *y, fl
                                   void *workspace, size_t workspace_bytes, int *ticket, void *stream)
 {
     if (n < 0 || channels <= 0 || inner <= 0 || (n % ((long long)channels * inner)) != 0) return MDT_ERR_INVALID_ARGUMENT;
-    if (relu && y == nullptr) return MDT_ERR_INVALID_ARGUMENT;
+    if (relu && (y == nullptr || gx == nullptr)) return MDT_ERR_INVALID_ARGUMENT;      // (relu == 0: gx may be null -- the input gradient IS gy, nothing is stored)
     hipStream_t s = (hipStream_t)stream;
     if (workspace == nullptr || workspace_bytes < mdt_bias_act_backward_workspace_bytes(n, channels, inner)) return MDT_ERR_WORKSPACE_TOO_SMALL;
     float *partial = reinterpret_cast<float *>(workspace);
@@ -484,6 +553,59 @@ static int bias_act_backward_impl(float *gx, const float *gy, const float *y, fl
     // partial[(n * C + c) * chunks + k]: channel stride chunks, chunk stride 1, batch groups stride C * chunks
     hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(fin_blocks), dim3(EP_THREADS), 0, s, gbias, partial, channels, chunks, chunks, 1LL,
                        rows / channels, (long long)channels * chunks);
+    return ep_check();
+}
+
+int mdt_bias_act_forward_upsampled_supported(int channels, long long n)
+{
+    return (channels >= 4 && (channels & 3) == 0 && n > 0 && n / 4 < 0x7fffffffLL) ? 1 : 0;
+}
+
+int mdt_bias_act_forward_upsampled(float *y, const float *x, const float *bias, const float *coarse, int batch, int Y, int X, int Z, int channels,
+                                   int sy, int sx, int sz, void *stream)
+{
+    if (!y || !x || !bias || !coarse || batch < 0 || Y <= 0 || X <= 0 || Z <= 0 || sy <= 0 || sx <= 0 || sz <= 0) return MDT_ERR_INVALID_ARGUMENT;
+    if ((Y % sy) || (X % sx) || (Z % sz)) return MDT_ERR_INVALID_ARGUMENT;
+    const long long n = (long long)batch * Y * X * Z * channels;
+    if (n == 0) return MDT_OK;
+    if (!mdt_bias_act_forward_upsampled_supported(channels, n)) return MDT_ERR_UNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)coarse)) & 15) != 0) return MDT_ERR_UNSUPPORTED;
+    const long long n4 = n / 4;
+    long long blocks = (n4 + EP_THREADS - 1) / EP_THREADS;
+    if (blocks > 8192) blocks = 8192;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(bias_act_fwd_up_kernel, dim3((unsigned)blocks), dim3(EP_THREADS), 0, (hipStream_t)stream, y, x, bias, coarse, (unsigned)n4,
+                       (unsigned)(channels / 4), (unsigned)Y, (unsigned)X, (unsigned)Z, (unsigned)sy, (unsigned)sx, (unsigned)sz);
+    return ep_check();
+}
+
+int mdt_bias_grad_to_channels_last_supported(int channels) { return (channels >= 1 && channels <= 48) ? 1 : 0; }
+
+size_t mdt_bias_grad_to_channels_last_workspace_bytes(int batch, int channels, long long inner)
+{
+    if (batch <= 0 || channels <= 0 || inner <= 0) return 256;
+    return (size_t)batch * (size_t)((inner + TR_TV - 1) / TR_TV) * channels * sizeof(float) + 256;
+}
+
+int mdt_bias_grad_to_channels_last(float *gx, const float *gy, float *gbias, int batch, int channels, long long inner,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!gx || !gy || !gbias || batch < 0 || channels <= 0 || inner < 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (!mdt_bias_grad_to_channels_last_supported(channels)) return MDT_ERR_UNSUPPORTED;
+    if (workspace == nullptr || workspace_bytes < mdt_bias_grad_to_channels_last_workspace_bytes(batch, channels, inner)) return MDT_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = reinterpret_cast<float *>(workspace);
+    (void)hipGetLastError();
+    const long long tiles = (inner + TR_TV - 1) / TR_TV;
+    const long long blocks = (long long)batch * tiles;
+    if (blocks > 0x7fffffffLL || tiles > 0x7fffffffLL) return MDT_ERR_UNSUPPORTED;
+    if (blocks > 0) {
+        const size_t lds = ((size_t)TR_TV * (channels | 1) + EP_THREADS) * sizeof(float);
+        hipLaunchKernelGGL(bias_grad_to_cl_kernel, dim3((unsigned)blocks), dim3(EP_THREADS), lds, s, gx, gy, partial, inner, channels, EP_THREADS / channels,
+                           (int)tiles);
+        if (ep_check() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
+    }
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(channels), dim3(EP_THREADS), 0, s, gbias, partial, channels, blocks, 1LL, (long long)channels, 1LL, 0LL);
     return ep_check();
 }
 

@@ -10,6 +10,13 @@ from ..utils import fused_epilogue
 from ..utils.fused_epilogue import ConvBias
 
 
+def _lateral_up(conv, x, coarse):
+    """P_conv1(x) + F.interpolate(coarse, scale_factor=2) (backbone.py:147-153): add AND nearest up-sampling inside the conv's epilogue"""
+    if isinstance(conv, ConvBias):
+        return fused_epilogue.conv_bias_add_upsampled(conv, x, coarse, 2)
+    return conv(x) + fused_epilogue.upsample_nearest(coarse, 2)
+
+
 def _lateral(conv, x, top_down):
     """P_conv1(x) + upsampled coarser level (backbone.py:147-153): the add rides the conv's fused epilogue"""
     if isinstance(conv, ConvBias):
@@ -161,12 +168,12 @@ class FPN(nn.Module):
         if self.sixth_pooling:
             c6_out, c5_out = self._stage(self.C6, c5_out)
             p6_pre_out = self.P6_conv1(c6_out)
-            p5_pre_out = _lateral(self.P5_conv1, c5_out, fused_epilogue.upsample_nearest(p6_pre_out, 2))
+            p5_pre_out = _lateral_up(self.P5_conv1, c5_out, p6_pre_out)
         else:
             p5_pre_out = self.P5_conv1(c5_out)
-        p4_pre_out = _lateral(self.P4_conv1, c4_out, fused_epilogue.upsample_nearest(p5_pre_out, 2))
-        p3_pre_out = _lateral(self.P3_conv1, c3_out, fused_epilogue.upsample_nearest(p4_pre_out, 2))
-        p2_pre_out = _lateral(self.P2_conv1, c2_out, fused_epilogue.upsample_nearest(p3_pre_out, 2))
+        p4_pre_out = _lateral_up(self.P4_conv1, c4_out, p5_pre_out)
+        p3_pre_out = _lateral_up(self.P3_conv1, c3_out, p4_pre_out)
+        p2_pre_out = _lateral_up(self.P2_conv1, c2_out, p3_pre_out)
         out_list = [self.P2_conv2(p2_pre_out), self.P3_conv2(p3_pre_out), self.P4_conv2(p4_pre_out), self.P5_conv2(p5_pre_out)]
         if self.sixth_pooling:
             out_list.append(self.P6_conv2(p6_pre_out))

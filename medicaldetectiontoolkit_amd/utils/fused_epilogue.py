@@ -77,10 +77,15 @@ class _BiasAct(Function):
     def backward(ctx, gy):
         y = ctx.saved_tensors[0] if ctx.relu else None
         if not gy.is_contiguous(memory_format=ctx.mf):
+            if not ctx.relu and ctx.inner == 1:
+                r = bias_grad_to_channels_last(gy, ctx.mf)       # row-major gradient of a channels-last layer: converted and reduced in ONE pass
+                if r is not None:
+                    return r[0], r[1], (r[0] if ctx.has_res else None), None, None, None
             gy = gy.contiguous(memory_format=ctx.mf)
         L = _lib.lib()
         n, C = gy.numel(), gy.shape[1]
-        gx = torch.empty_like(gy)
+        # no activation: the input gradient IS gy -- returned as it is, the kernel only reduces (round 6; it used to store a copy)
+        gx = torch.empty_like(gy) if (ctx.relu or not BIAS_BWD_NO_COPY) else None
         gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
         wsb = (4096 * C * 4 + 256) if ctx.inner == 1 else L.mdt_bias_act_backward_workspace_bytes(n, C, ctx.inner)
         ws = _workspace(wsb, gy.device)
@@ -88,14 +93,110 @@ class _BiasAct(Function):
             tk = _TICKET.get(gy.device)
             if tk is None:
                 tk = _TICKET[gy.device] = torch.zeros(1, dtype=torch.int32, device=gy.device)
-            rc = L.mdt_bias_act_backward_ticket(gx.data_ptr(), gy.data_ptr(), y.data_ptr() if y is not None else None, gbias.data_ptr(), n, C, ctx.inner,
-                                                1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), tk.data_ptr(), _lib.raw_stream())
+            rc = L.mdt_bias_act_backward_ticket(gx.data_ptr() if gx is not None else None, gy.data_ptr(), y.data_ptr() if y is not None else None,
+                                                gbias.data_ptr(), n, C, ctx.inner, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), tk.data_ptr(), _lib.raw_stream())
         else:
-            rc = L.mdt_bias_act_backward(gx.data_ptr(), gy.data_ptr(), y.data_ptr() if y is not None else None, gbias.data_ptr(), n, C, ctx.inner,
-                                         1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), _lib.raw_stream())
+            rc = L.mdt_bias_act_backward(gx.data_ptr() if gx is not None else None, gy.data_ptr(), y.data_ptr() if y is not None else None, gbias.data_ptr(),
+                                         n, C, ctx.inner, 1 if ctx.relu else 0, ws.data_ptr(), ws.numel(), _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_bias_act_backward")
+        if gx is None:
+            gx = gy
         return gx, gbias, (gx if ctx.has_res else None), None, None, None
+
+
+BIAS_BWD_NO_COPY = True        # module switch (A/B: bench.py --bias-bwd-no-copy 0): bias-only layers' backward returns gy itself as the input gradient
+BIAS_GRAD_TRANSPOSE = True     # module switch (A/B: bench.py --bias-grad-transpose 0): row-major output gradients of channels-last bias-only layers in one pass
+LATERAL_UPSAMPLE_FUSED = True  # module switch (A/B: bench.py --lateral-upsample-fused 0): the FPN's top-down add reads the coarser map directly
+
+
+def bias_grad_to_channels_last(gy, mf):
+    """(gx, gbias) for a bias-only layer on channels-last storage whose output gradient gy is a dense ROW-MAJOR tensor: gx = gy in channels-last
+    storage, gbias = per-channel sum, one pass (csrc/epilogue.hip bias_grad_to_cl_kernel).  None when the case is not the kernel's."""
+    if not (BIAS_GRAD_TRANSPOSE and gy.is_cuda and gy.dtype == torch.float32 and gy.is_contiguous() and gy.dim() >= 4 and _on_current_device(gy)):
+        return None
+    L = _lib.lib()
+    B, C = int(gy.shape[0]), int(gy.shape[1])
+    if not L.mdt_bias_grad_to_channels_last_supported(C):
+        return None
+    inner = int(gy.shape[2:].numel())
+    gx = torch.empty_like(gy, memory_format=mf)
+    gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
+    ws = _workspace(L.mdt_bias_grad_to_channels_last_workspace_bytes(B, C, inner), gy.device)
+    rc = L.mdt_bias_grad_to_channels_last(gx.data_ptr(), gy.data_ptr(), gbias.data_ptr(), B, C, inner, ws.data_ptr(), ws.numel(), _lib.raw_stream())
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        _lib.check(rc, "mdt_bias_grad_to_channels_last")
+    return gx, gbias
+
+
+class _BiasAddUpsampled(Function):
+    """y = x + bias + nearest-up-sampled coarse map, in place on x (channels-last fp32): the FPN's top-down step (models/backbone.py:147-153) with the
+    up-sampling folded into the lateral's epilogue -- the up-sampled map (151 MB on P2 at the benchmark patch) is never written.  Backward: the
+    input gradient is gy itself, the bias gradient its per-channel sum, the coarse map's gradient the sum of gy over each voxel's replicas (the
+    strided sum _UpsampleNearestCL.backward runs)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, coarse, scale, mf):
+        if not _on_current_device(x):
+            raise RuntimeError("fused epilogue: tensor is not on the current device (one process per GPU)")
+        nd = x.dim() - 2
+        sp = [int(v) for v in x.shape[2:]]
+        Y, X, Z = (sp[0], sp[1], sp[2]) if nd == 3 else (sp[0], sp[1], 1)
+        sy, sx, sz = (scale[0], scale[1], scale[2]) if nd == 3 else (scale[0], scale[1], 1)
+        rc = _lib.lib().mdt_bias_act_forward_upsampled(x.data_ptr(), x.data_ptr(), bias.data_ptr(), coarse.data_ptr(), int(x.shape[0]), Y, X, Z,
+                                                       int(x.shape[1]), sy, sx, sz, _lib.raw_stream())
+        if rc != 0:
+            _lib.check(rc, "mdt_bias_act_forward_upsampled")
+        ctx.mark_dirty(x)
+        ctx.scale, ctx.mf, ctx.coarse_shape = scale, mf, tuple(coarse.shape)
+        return x
+
+    @staticmethod
+    def backward(ctx, gy):
+        gx = gbias = None
+        if not gy.is_contiguous(memory_format=ctx.mf):
+            r = bias_grad_to_channels_last(gy, ctx.mf)
+            if r is not None:
+                gx, gbias = r
+            else:
+                gy = gy.contiguous(memory_format=ctx.mf)
+        if gx is None:
+            L = _lib.lib()
+            n, C = gy.numel(), gy.shape[1]
+            gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
+            ws = _workspace(4096 * C * 4 + 256, gy.device)
+            rc = L.mdt_bias_act_backward(None, gy.data_ptr(), None, gbias.data_ptr(), n, C, 1, 0, ws.data_ptr(), ws.numel(), _lib.raw_stream())
+            if rc != 0:
+                _lib.check(rc, "mdt_bias_act_backward")
+            gx = gy
+        nd = gx.dim() - 2
+        perm = (0,) + tuple(range(2, 2 + nd)) + (1,)
+        B, C = ctx.coarse_shape[0], ctx.coarse_shape[1]
+        shp, red = [B], []
+        for d in range(nd):
+            shp += [ctx.coarse_shape[2 + d], ctx.scale[d]]
+            red.append(2 + 2 * d)
+        gs = gx.permute(*perm).reshape(*shp, C).sum(tuple(red))        # [B, *coarse spatial, C]
+        inv = (0, nd + 1) + tuple(range(1, nd + 1))
+        return gx, gbias, gs.permute(*inv), None, None
+
+
+def conv_bias_add_upsampled(conv, x, coarse, scale_factor=2):
+    """conv(x) + bias + F.interpolate(coarse, scale_factor) (nearest) -- the lateral of the FPN's top-down path; the add and the up-sampling ride
+    the convolution's epilogue where that applies (channels-last fp32 on the GPU, channels % 4 == 0), torch ops otherwise"""
+    h = _conv(conv, x)
+    nd = h.dim() - 2
+    sc = tuple(scale_factor) if isinstance(scale_factor, (tuple, list)) else (scale_factor,) * nd
+    mf = torch.channels_last_3d if nd == 3 else torch.channels_last if nd == 2 else None
+    if ENABLED and LATERAL_UPSAMPLE_FUSED and mf is not None and h.is_cuda and h.dtype == torch.float32 and conv.bias is not None and conv.bias.dtype == torch.float32 \
+            and coarse.dtype == torch.float32 and all(float(v) == int(v) and int(v) >= 1 for v in sc) and not torch.is_autocast_enabled() \
+            and h.is_contiguous(memory_format=mf) and not h.is_contiguous() and coarse.is_contiguous(memory_format=mf) and not coarse.is_contiguous() \
+            and coarse.shape[:2] == h.shape[:2] and all(int(c) * int(v) == int(o) for c, v, o in zip(coarse.shape[2:], sc, h.shape[2:])) \
+            and (h.data_ptr() | coarse.data_ptr()) % 16 == 0 and _lib.lib().mdt_bias_act_forward_upsampled_supported(int(h.shape[1]), h.numel()):
+        return _BiasAddUpsampled.apply(h, conv.bias, coarse, tuple(int(v) for v in sc), mf)
+    return bias_act(h, conv.bias, upsample_nearest(coarse, scale_factor), False)
 
 
 def bias_act(x, bias, residual=None, relu=False):
@@ -445,7 +546,7 @@ def _bias_act_bwd(gy, y, relu, mf):
     L = _lib.lib()
     n, C = gy.numel(), int(gy.shape[1])
     inner = 1 if mf != torch.contiguous_format else int(gy.shape[2:].numel())
-    g = torch.empty_like(gy)
+    g = torch.empty_like(gy) if (relu or not BIAS_BWD_NO_COPY) else None       # no activation: the kernel only reduces, g is gy
     gbias = torch.empty(C, dtype=torch.float32, device=gy.device)
     wsb = (4096 * C * 4 + 256) if inner == 1 else L.mdt_bias_act_backward_workspace_bytes(n, C, inner)
     if inner == 1 and BIAS_GRAD_IN_LAUNCH:
@@ -455,17 +556,17 @@ def _bias_act_bwd(gy, y, relu, mf):
         if tk is None:
             tk = _TICKET[gy.device] = torch.zeros(1, dtype=torch.int32, device=gy.device)
         ws = _workspace(wsb, gy.device)
-        rc = L.mdt_bias_act_backward_ticket(g.data_ptr(), gy.data_ptr(), y.data_ptr() if relu else None, gbias.data_ptr(), n, C, inner, 1 if relu else 0,
-                                            ws.data_ptr(), ws.numel(), tk.data_ptr(), _lib.raw_stream())
+        rc = L.mdt_bias_act_backward_ticket(g.data_ptr() if g is not None else None, gy.data_ptr(), y.data_ptr() if relu else None, gbias.data_ptr(), n, C, inner,
+                                            1 if relu else 0, ws.data_ptr(), ws.numel(), tk.data_ptr(), _lib.raw_stream())
         if rc != 0:
             _lib.check(rc, "mdt_bias_act_backward_ticket")
-        return g, gbias
+        return (g if g is not None else gy), gbias
     ws = _workspace(wsb, gy.device)
-    rc = L.mdt_bias_act_backward(g.data_ptr(), gy.data_ptr(), y.data_ptr() if relu else None, gbias.data_ptr(), n, C, inner, 1 if relu else 0,
-                                 ws.data_ptr(), ws.numel(), _lib.raw_stream())
+    rc = L.mdt_bias_act_backward(g.data_ptr() if g is not None else None, gy.data_ptr(), y.data_ptr() if relu else None, gbias.data_ptr(), n, C, inner,
+                                 1 if relu else 0, ws.data_ptr(), ws.numel(), _lib.raw_stream())
     if rc != 0:
         _lib.check(rc, "mdt_bias_act_backward")
-    return g, gbias
+    return (g if g is not None else gy), gbias
 
 
 CONV3_SMALL_EPILOGUE = True   # module switch: bias + ReLU of the few-channel 3x3x3 layers inside the convolution kernel

@@ -628,3 +628,112 @@ def test_resblock_residual_tap_equals_plain_autograd(cuda):
     for n in res[0][1]:
         a, b = res[0][1][n], res[1][1][n]
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-9), (n, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("shape,scale", [((2, 36, 8, 12, 6), 2), ((1, 36, 4, 4, 8), (2, 2, 1)), ((3, 8, 6, 10), 2), ((2, 36, 16, 16, 8), (1, 2, 2))])
+def test_lateral_with_the_upsampling_inside_the_epilogue(shape, scale, cuda):
+    """conv_bias_add_upsampled (the FPN's top-down step, models/backbone.py:147-153) against conv + F.interpolate + add: forward bit-equal
+    (same two additions in the same order), input / coarse-map gradients bit-equal to the materialised form's, bias gradient to
+    summation-order rounding; the up-sampled map is never allocated"""
+    nd = len(shape) - 2
+    sc = (scale,) * nd if isinstance(scale, int) else scale
+    mf = torch.channels_last_3d if nd == 3 else torch.channels_last
+    g = torch.Generator(device=cuda).manual_seed(5 + len(shape))
+    cin = 12
+    x0 = torch.randn((shape[0], cin) + shape[2:], device=cuda, generator=g).contiguous(memory_format=mf)
+    coarse0 = torch.randn(shape[:2] + tuple(s // k for s, k in zip(shape[2:], sc)), device=cuda, generator=g).contiguous(memory_format=mf)
+    conv = (fe.ConvBias3d if nd == 3 else fe.ConvBias2d)(cin, shape[1], 1).to(cuda).to(memory_format=mf)
+    flat = torch.zeros(shape[1] + 1, device=cuda)
+    flat[1:].copy_(conv.bias.detach())
+    conv.bias.data = flat[1:]              # a bias inside a flat parameter buffer (training.FlatAdam): 4-byte aligned only
+    gy = torch.randn(shape, device=cuda, generator=g).contiguous(memory_format=mf)
+
+    def run(fused):
+        fe.LATERAL_UPSAMPLE_FUSED = fused
+        try:
+            conv.zero_grad()
+            x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            c = coarse0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            torch.cuda.reset_peak_memory_stats()
+            m0 = torch.cuda.memory_allocated()
+            y = fe.conv_bias_add_upsampled(conv, x, c * 1.0, sc)
+            peak = torch.cuda.max_memory_allocated() - m0
+            y.backward(gy)
+            return y.detach().clone(), x.grad.clone(), c.grad.clone(), conv.bias.grad.clone(), conv.weight.grad.clone(), peak
+        finally:
+            fe.LATERAL_UPSAMPLE_FUSED = True
+
+    yf, gxf, gcf, gbf, gwf, peak_f = run(True)
+    yr, gxr, gcr, gbr, gwr, peak_r = run(False)
+    ref = F.conv3d(x0, conv.weight, conv.bias) if nd == 3 else F.conv2d(x0, conv.weight, conv.bias)
+    ref = ref + F.interpolate(coarse0, scale_factor=tuple(float(v) for v in sc))
+    assert torch.equal(yf, yr)
+    ref = ref.detach()
+    assert float((yf - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert torch.equal(gxf, gxr) and torch.equal(gcf, gcr)
+    assert float((gwf - gwr).abs().max()) <= 1e-5 * float(gwr.abs().max())      # (MIOpen's 2D weight gradient is not run-to-run bit-stable)
+    assert float((gbf - gbr).abs().max()) <= 1e-5 * float(gy.abs().sum(dim=[0] + list(range(2, 2 + nd))).max())
+    assert peak_f < peak_r       # no up-sampled copy of the coarse map
+
+
+@pytest.mark.parametrize("shape", [(2, 36, 8, 8, 16), (1, 36, 5, 7, 3), (3, 18, 9, 11), (2, 48, 4, 4, 4), (8, 36, 32, 32, 16)])
+def test_row_major_output_gradient_of_a_channels_last_bias_layer(shape, cuda):
+    """mdt_bias_grad_to_channels_last: the layout change is exact, the bias gradient equals a float64 sum to fp32 rounding and is run-to-run
+    identical; inside autograd a row-major gradient into a channels-last ConvBias layer gives what the two-pass form gives"""
+    nd = len(shape) - 2
+    mf = torch.channels_last_3d if nd == 3 else torch.channels_last
+    g = torch.Generator(device=cuda).manual_seed(11 + shape[1] + shape[0])
+    gy = torch.randn(shape, device=cuda, generator=g)                     # row-major
+    gx, gb = fe.bias_grad_to_channels_last(gy, mf)
+    assert gx.is_contiguous(memory_format=mf) and torch.equal(gx, gy)
+    ref = gy.double().sum(dim=[0] + list(range(2, 2 + nd)))
+    bound = 1e-6 * float(gy.double().abs().sum(dim=[0] + list(range(2, 2 + nd))).max())
+    assert float((gb.double() - ref).abs().max()) <= bound
+    gx2, gb2 = fe.bias_grad_to_channels_last(gy, mf)
+    assert torch.equal(gb, gb2)
+    # inside autograd
+    cin = 8
+    conv = (fe.ConvBias3d if nd == 3 else fe.ConvBias2d)(cin, shape[1], 1).to(cuda).to(memory_format=mf)
+    x0 = torch.randn((shape[0], cin) + shape[2:], device=cuda, generator=g).contiguous(memory_format=mf)
+
+    def run(on):
+        fe.BIAS_GRAD_TRANSPOSE = on
+        try:
+            conv.zero_grad()
+            x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            conv(x).backward(gy)
+            return x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()
+        finally:
+            fe.BIAS_GRAD_TRANSPOSE = True
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0])
+    assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(b[1].abs().max())      # (MIOpen's 2D weight gradient is not run-to-run bit-stable)
+    assert float((a[2] - b[2]).abs().max()) <= bound
+
+
+def test_bias_only_backward_returns_the_output_gradient_itself(cuda):
+    """no activation: the input gradient is gy -- the kernel reduces and stores nothing (gx == NULL in the C-ABI); same numbers as the copying form"""
+    g = torch.Generator(device=cuda).manual_seed(3)
+    shape = (2, 36, 8, 8, 16)
+    x0 = torch.randn(shape, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+    b0 = torch.randn(36, device=cuda, generator=g)
+    gy = torch.randn(shape, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d)
+
+    def run(on):
+        fe.BIAS_BWD_NO_COPY = on
+        try:
+            x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            b = b0.clone().requires_grad_(True)
+            fe.bias_act(x * 1.0, b, None, False).backward(gy)
+            return x.grad.clone(), b.grad.clone()
+        finally:
+            fe.BIAS_BWD_NO_COPY = True
+
+    a, c = run(True), run(False)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(a[0], gy)
+    # relu without an output buffer is an argument error, not a silent skip
+    from medicaldetectiontoolkit_amd import _lib
+    ws = torch.empty(4096 * 36 + 64, device=cuda)
+    rc = _lib.lib().mdt_bias_act_backward(None, gy.data_ptr(), x0.data_ptr(), b0.data_ptr(), gy.numel(), 36, 1, 1, ws.data_ptr(), ws.numel() * 4, _lib.raw_stream())
+    assert rc == -1          # MDT_ERR_INVALID_ARGUMENT (include/mdt_hip.h)
