@@ -493,6 +493,18 @@ int mdt_conv_stem_forward_supported(int OY, int OX, int OZ, int c_out, int k, in
 int mdt_conv_stem_forward(const float *x_padded, const float *weight, const float *bias, float *out, int batch, int OY, int OX, int OZ,
                           int c_out, int k, int sy, int sx, int YP, int XP, int ZP, int relu, void *stream);
 
+/*
+ * 1x1(x1) convolution forward WITH its epilogue on channels-last fp32 rows (csrc/conv1x1_fwd.hip):
+ *   out[v][n] = act((sum_k x[v][k] * w[n][k] + bias[n]) (+ res[v][n])),  act = ReLU when relu != 0;  w: [c_out][c_in] (the module's filter, 1x1 taps dropped).
+ * The bottleneck layers of the reference's ResBlock (models/backbone.py:197-206: conv1 + ReLU, conv3 + residual + ReLU) in ONE pass over their operands
+ * instead of a convolution plus mdt_bias_act_forward; fp32 MFMA (exact products, fixed order).  Shapes: (c_in, c_out) in {(18, 72), (72, 18), (36, 144)}
+ * -- the C2 / C3 stages of the LIDC backbone; everything else: MDT_ERR_UNSUPPORTED (the caller keeps MIOpen + the epilogue kernel).
+ * res may be NULL; out must not alias x (it may alias res).  x 16-byte aligned.
+ */
+int mdt_conv1x1_forward_supported(int c_in, int c_out);
+int mdt_conv1x1_forward(const float *x, const float *w, const float *bias, const float *res, float *out, long long n_voxels, int c_in, int c_out, int relu,
+                        void *stream);
+
 /* ---- input gradient of a 1x1(x1) convolution added to another gradient of the same tensor (csrc/epilogue.hip, round 4) ------------------
  * out[v][ci] = res[v][ci] + sum_co gy[v][co] * w[co][ci] over n_voxels channels-last rows (res may be NULL: plain input gradient).
  * What autograd does in two steps for a ResBlock input (models/backbone.py:197-205: x feeds conv1 and the residual add): the

@@ -1,0 +1,207 @@
+// conv1x1_fwd.hip -- 1x1(x1) convolution forward WITH its epilogue, for the bottleneck layers of the ResNet backbone on the large maps (gfx950).
+//
+//   out[v][n] = act( (sum_k x[v][k] * w[n][k] + bias[n]) (+ res[v][n]) )          channels-last rows, k ascending
+//
+// The reference's ResBlock (models/backbone.py:197-206) runs conv1 (1x1, C -> C/4) + ReLU, conv2 (3x3) + ReLU, conv3 (1x1, C/4 -> C) + residual + ReLU.
+// With the 1x1 layers on MIOpen / CK and the bias / residual / ReLU in mdt_bias_act_forward, conv3 of a C2 block at the benchmark patch (8 x 128^3:
+// 131072 voxels x 8, 18 -> 72 channels) is a 111 us convolution that writes 302 MB and a 157 us epilogue that reads it back with the 302 MB residual
+// and writes it again: 1.28 GB of traffic for a layer whose operands are 75 + 302 MB in and 302 MB out.  Here the product runs on the matrix cores
+// inside the pass that streams the operands once: the input rows of 32 voxels go through the wave's LDS slot (one contiguous run, 16-byte loads),
+// the filter lives in registers for the wave's lifetime, bias / residual / ReLU are applied to the accumulators on their way out.
+// HBM-bound (2 * K MACs per output float at K = 18 .. 72 is 2-9 % of the fp32 MFMA peak at the HBM rate); fp32 MFMA: exact products, fixed order.
+//
+// The accumulator layout of v_mfma_f32_32x32x2_f32 (column = lane & 31 = output channel, 16 rows per lane) makes every wave-level load of the residual
+// and store of the result two 128-byte row segments -- the same data path as conv1x1_dgrad_add_mfma_kernel (epilogue.hip), whose shape this is.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "mdt_hip.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+inline int c1_check()
+{
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return MDT_OK;
+    if (getenv("MDT_VERBOSE")) fprintf(stderr, "libmdt_hip: HIP error %d (%s)\n", (int)e, hipGetErrorString(e));
+    return MDT_ERR_LAUNCH_FAILED;
+}
+
+// KS: K-steps of two input channels (K = 2 KS), NT: 32-column tiles of output channels (N <= 32 NT), WPB: waves per block (LDS: WPB slots of 32 x (K + 1)),
+// BL: the filter lives in LDS instead of registers (36 -> 144: 90 filter registers beside 80 residual registers left ONE wave per SIMD, 66 us; LDS bandwidth is
+// nowhere near a limit at 23 KB of fragment reads per tile)
+template <int KS, int NT, int WPB, bool BL, bool RES, bool RELU>
+__global__ __launch_bounds__(64 * WPB) void conv1x1_fwd_mfma_kernel(float *__restrict__ out, const float *__restrict__ x, const float *__restrict__ w,
+                                                                    const float *__restrict__ bias, const float *res, long long V, int N)
+{
+    constexpr int K = 2 * KS;
+    constexpr int ASTR = K + 1;                          // odd row stride: the 32 rows of a fragment read hit 32 different banks
+    __shared__ float s_a[WPB][32 * ASTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    constexpr int NB = NT * 32;                          // (NB % 64 == 32 at NT = 5: the two half-waves of a fragment read hit disjoint banks)
+    __shared__ float s_b[BL ? K * NB : 1];
+    float bfrag[BL ? 1 : KS][BL ? 1 : NT], bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 32 + col;
+        bv[nt] = n < N ? bias[n] : 0.0f;
+        if (!BL) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bfrag[ks][nt] = n < N ? w[(long long)n * K + 2 * ks + half] : 0.0f;
+        }
+    }
+    if (BL) {
+        for (int e = threadIdx.x; e < K * NB; e += 64 * WPB) {
+            const int k = e / NB, n = e - k * NB;
+            s_b[e] = n < N ? w[(long long)n * K + k] : 0.0f;
+        }
+        __syncthreads();
+    }
+    const long long tiles = (V + 31) / 32;
+    float *sa = s_a[wave];
+    for (long long tile = (long long)blockIdx.x * WPB + wave; tile < tiles; tile += (long long)gridDim.x * WPB) {
+        const long long v0 = tile * 32;
+        const int nv = (int)min((long long)32, V - v0);
+        // A: the tile's input rows, one contiguous run of nv * K floats -> LDS (row stride ASTR); 16-byte loads (32 * K floats per tile: the run starts
+        // 16-byte aligned).  Full tiles: the input run AND the residual rows are requested together, before anything waits -- a wave has its whole
+        // tile (2.3 + 9.2 KB at 18 -> 72) in flight at once; requested one after the other the layer was latency-bound (237 us, 2.9 TB/s).
+        const v4f *src = reinterpret_cast<const v4f *>(x + v0 * K);
+        float rv[NT][16];
+        if (nv == 32) {
+            constexpr int NA = (8 * K + 63) / 64;        // 16-byte loads per lane
+            v4f areg[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int e4 = lane + 64 * i;
+                areg[i] = (e4 < 8 * K) ? src[e4] : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+            if (RES) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = nt * 32 + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        rv[nt][r] = (n < N) ? res[(v0 + row) * N + n] : 0.0f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int e4 = lane + 64 * i;
+                if (e4 < 8 * K) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = e4 * 4 + j, m = e / K, k = e - m * K;
+                        sa[m * ASTR + k] = areg[i][j];
+                    }
+                }
+            }
+        } else {
+            const int n4 = (nv * K) >> 2;                // K is even: a 2-float tail is handled below
+            for (int e4 = lane; e4 < n4; e4 += 64) {
+                const v4f v = src[e4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e4 * 4 + j, m = e / K, k = e - m * K;
+                    sa[m * ASTR + k] = v[j];
+                }
+            }
+            for (int e = n4 * 4 + lane; e < 32 * K; e += 64) {
+                const int m = e / K, k = e - m * K;
+                sa[m * ASTR + k] = e < nv * K ? x[v0 * K + e] : 0.0f;
+            }
+            if (RES) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = nt * 32 + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        rv[nt][r] = (n < N && row < nv) ? res[(v0 + row) * N + n] : 0.0f;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float afrag[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) afrag[ks] = sa[col * ASTR + 2 * ks + half];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + col;
+            v16f acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float bf = BL ? s_b[(2 * ks + half) * NB + nt * 32 + col] : bfrag[BL ? 0 : ks][BL ? 0 : nt];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[ks], bf, acc, 0, 0, 0);
+            }
+            if (n < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[r] + bv[nt];           // (conv + bias) + residual: the order of the reference's graph
+                    if (RES) v = v + rv[nt][r];
+                    if (RELU) v = v > 0.0f ? v : 0.0f;
+                    if (row < nv) out[(v0 + row) * N + n] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                 // the slot is rewritten by the next tile
+    }
+}
+
+template <int KS, int NT, int WPB, bool BL>
+int launch(float *out, const float *x, const float *w, const float *bias, const float *res, long long V, int N, int relu, hipStream_t s)
+{
+    const long long tiles = (V + 31) / 32;
+    long long blocks = (tiles + WPB - 1) / WPB;
+    if (blocks > 2048) blocks = 2048;
+    const dim3 g((unsigned)blocks), b(64 * WPB);
+    (void)hipGetLastError();
+    if (res) {
+        if (relu) hipLaunchKernelGGL((conv1x1_fwd_mfma_kernel<KS, NT, WPB, BL, true, true>), g, b, 0, s, out, x, w, bias, res, V, N);
+        else hipLaunchKernelGGL((conv1x1_fwd_mfma_kernel<KS, NT, WPB, BL, true, false>), g, b, 0, s, out, x, w, bias, res, V, N);
+    } else {
+        if (relu) hipLaunchKernelGGL((conv1x1_fwd_mfma_kernel<KS, NT, WPB, BL, false, true>), g, b, 0, s, out, x, w, bias, res, V, N);
+        else hipLaunchKernelGGL((conv1x1_fwd_mfma_kernel<KS, NT, WPB, BL, false, false>), g, b, 0, s, out, x, w, bias, res, V, N);
+    }
+    return c1_check();
+}
+
+}  // namespace
+
+extern "C" {
+
+// the bottleneck shapes of the LIDC backbone whose maps are large: C2 (18 <-> 72) and C3's conv3 (36 -> 144)
+int mdt_conv1x1_forward_supported(int c_in, int c_out)
+{
+    return ((c_in == 18 && c_out == 72) || (c_in == 72 && c_out == 18) || (c_in == 36 && c_out == 144)) ? 1 : 0;
+}
+
+int mdt_conv1x1_forward(const float *x, const float *w, const float *bias, const float *res, float *out, long long n_voxels, int c_in, int c_out, int relu,
+                        void *stream)
+{
+    if (!x || !w || !bias || !out || n_voxels < 0) return MDT_ERR_INVALID_ARGUMENT;
+    if (!mdt_conv1x1_forward_supported(c_in, c_out)) return MDT_ERR_UNSUPPORTED;
+    if (n_voxels == 0) return MDT_OK;
+    if (((uintptr_t)x & 15) != 0 || (((uintptr_t)out | (uintptr_t)res | (uintptr_t)w | (uintptr_t)bias) & 3) != 0) return MDT_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c_in == 18) return launch<9, 3, 4, false>(out, x, w, bias, res, n_voxels, c_out, relu, s);
+    if (c_in == 36) return launch<18, 5, 4, true>(out, x, w, bias, res, n_voxels, c_out, relu, s);
+    // (144 -> 36, conv1 of the C3 blocks, measured SLOWER here than CK + the epilogue kernel: 85 us against 27 + 8 us -- 18 KB of input rows per
+    // wave tile, 290 registers; not served)
+    return launch<36, 1, 4, false>(out, x, w, bias, res, n_voxels, c_out, relu, s);
+}
+
+}  // extern "C"

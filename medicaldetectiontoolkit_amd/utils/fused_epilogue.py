@@ -975,6 +975,73 @@ def conv_unit_stride(x, w, padding):
     return (F.conv3d if nd == 3 else F.conv2d)(x, w, None, 1, padding)
 
 
+CONV1X1_FWD = True   # module switch (A/B: bench.py --conv1x1-fwd 0): the bottleneck 1x1 layers of the C2 / C3 stages with their epilogue in one pass (mdt_conv1x1_forward)
+
+
+def conv1x1_forward_applies(conv, x):
+    """the layer is one of mdt_conv1x1_forward's: 1x1(x1), unit stride, bias, channels-last fp32 on this process's GPU, a large map, a supported channel pair"""
+    if not (ENABLED and CONV1X1_FWD and x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and conv.groups == 1 and x.dim() in (4, 5)
+            and all(int(k) == 1 for k in conv.kernel_size) and _unit(conv.stride) and _unit(conv.dilation) and not isinstance(conv.padding, str)
+            and not any(int(p) for p in conv.padding) and not torch.is_autocast_enabled()):
+        return False
+    mf = torch.channels_last_3d if x.dim() == 5 else torch.channels_last
+    if not (x.is_contiguous(memory_format=mf) and not x.is_contiguous() and x.data_ptr() % 16 == 0 and _on_current_device(x)):
+        return False
+    return x.numel() >= (1 << 20) and bool(_lib.lib().mdt_conv1x1_forward_supported(int(conv.in_channels), int(conv.out_channels)))
+
+
+def _conv1x1_forward(x, w, bias, res, relu):
+    """act(conv1x1(x, w) + bias (+ res)) on channels-last rows, one launch; None when the kernel declines (alignment)"""
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    out = torch.empty((x.shape[0], cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device,
+                      memory_format=torch.channels_last_3d if x.dim() == 5 else torch.channels_last)
+    wd = w.detach()
+    rc = _lib.lib().mdt_conv1x1_forward(x.data_ptr(), wd.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
+                                        x.numel() // cin, cin, cout, 1 if relu else 0, _lib.raw_stream())
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        _lib.check(rc, "mdt_conv1x1_forward")
+    return out
+
+
+class _Conv1x1BiasAct(Function):
+    """y = act(conv1x1(x) + bias (+ residual)) in ONE pass over the operands (csrc/conv1x1_fwd.hip) -- conv3 + residual + ReLU of a ResBlock
+    (models/backbone.py:203-205).  Backward: the ReLU mask and the bias gradient as in _BiasAct, input / weight gradients as in _ConvStride1."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, relu):
+        mf = torch.channels_last_3d if x.dim() == 5 else torch.channels_last
+        if residual is not None and not residual.is_contiguous(memory_format=mf):
+            residual = residual.contiguous(memory_format=mf)
+        y = _conv1x1_forward(x, w, bias, residual, relu)
+        if y is None:
+            y = (F.conv3d if x.dim() == 5 else F.conv2d)(x, w)
+            rc = _lib.lib().mdt_bias_act_forward(y.data_ptr(), y.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                                 y.numel(), y.shape[1], 1, 1 if relu else 0, _lib.raw_stream())
+            if rc != 0:
+                _lib.check(rc, "mdt_bias_act_forward")
+        ctx.relu, ctx.mf, ctx.has_res = relu, mf, residual is not None
+        if relu:
+            ctx.save_for_backward(x, w, y)
+        else:
+            ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        y = ctx.saved_tensors[2] if ctx.relu else None
+        if not ctx.relu and not gy.is_contiguous(memory_format=ctx.mf):
+            r = bias_grad_to_channels_last(gy, ctx.mf)
+            g, gbias = r if r is not None else _bias_act_bwd(gy, None, False, ctx.mf)
+        else:
+            g, gbias = _bias_act_bwd(gy, y, ctx.relu, ctx.mf)
+        nd = w.dim() - 2
+        gx, gw = _stride1_grads(x, w, (0,) * nd, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw, (gbias if ctx.needs_input_grad[2] else None), (g if ctx.has_res and ctx.needs_input_grad[3] else None), None
+
+
 RES_TAP = True   # module switch (A/B: bench.py --res-tap 0)
 
 
@@ -1006,15 +1073,29 @@ class _Conv1x1ResTap(Function):
     (mdt_conv1x1_dgrad_add).  The alias is returned as-is (autograd wraps it as a view whose gradient arrives here)."""
 
     @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, bias=None):
         nd = w.dim() - 2
+        ctx.fused = False
+        if bias is not None:         # round 6: conv1 + bias + ReLU in one pass (mdt_conv1x1_forward); the backward masks gh with the saved output
+            h = _conv1x1_forward(x, w, bias, None, True)
+            if h is None:
+                h = (F.conv3d if nd == 3 else F.conv2d)(x, w)
+                rc = _lib.lib().mdt_bias_act_forward(h.data_ptr(), h.data_ptr(), bias.data_ptr(), None, h.numel(), h.shape[1], 1, 1, _lib.raw_stream())
+                if rc != 0:
+                    _lib.check(rc, "mdt_bias_act_forward")
+            ctx.fused = True
+            ctx.save_for_backward(x, w, h)
+            return h, x
+        ctx.save_for_backward(x, w)
         return (F.conv3d if nd == 3 else F.conv2d)(x, w), x
 
     @staticmethod
     def backward(ctx, gh, gres):
-        x, w = ctx.saved_tensors
+        x, w = ctx.saved_tensors[0], ctx.saved_tensors[1]
         nd = w.dim() - 2
+        gbias = None
+        if ctx.fused and gh is not None:
+            gh, gbias = _bias_act_bwd(gh, ctx.saved_tensors[2], True, torch.channels_last_3d if nd == 3 else torch.channels_last)
         gx = None
         if ctx.needs_input_grad[0]:
             if gres is not None and gh is not None:
@@ -1027,6 +1108,8 @@ class _Conv1x1ResTap(Function):
                 else:
                     gx = gres
         gw = _stride1_grads(x, w, (0,) * nd, gh, False, True)[1] if (ctx.needs_input_grad[1] and gh is not None) else None
+        if ctx.fused:
+            return gx, gw, gbias
         return gx, gw
 
 
@@ -1048,6 +1131,8 @@ def res_tap_applies(seq, x):
 def conv_bias_relu_with_res_tap(seq, x):
     """(relu(conv1(x) + bias), alias of x for the residual add) through _Conv1x1ResTap"""
     conv = seq[0]
+    if conv1x1_forward_applies(conv, x):
+        return _Conv1x1ResTap.apply(x, conv.weight, conv.bias)
     h, x_res = _Conv1x1ResTap.apply(x, conv.weight)
     return bias_act(h, conv.bias, None, True), x_res
 
@@ -1206,6 +1291,9 @@ class ConvBias(object):
     """mixin for the bare-conv form (relu=None in the reference's generator): forward(x, residual=None, relu=False)"""
 
     def forward(self, x, residual=None, relu=False):
+        if conv1x1_forward_applies(self, x) and (residual is None or (residual.dtype == torch.float32 and residual.is_cuda
+                and tuple(residual.shape) == (x.shape[0], self.out_channels) + tuple(x.shape[2:]))):
+            return _Conv1x1BiasAct.apply(x, self.weight, self.bias, residual, relu)
         return bias_act(_conv(self, x), self.bias, residual, relu)
 
 
