@@ -505,6 +505,18 @@ int mdt_conv1x1_forward_supported(int c_in, int c_out);
 int mdt_conv1x1_forward(const float *x, const float *w, const float *bias, const float *res, float *out, long long n_voxels, int c_in, int c_out, int relu,
                         void *stream);
 
+/*
+ * Backward of the same layer's epilogue AND its input gradient in one pass (channels-last fp32 rows):
+ *   g[v][n] = gy[v][n] * (y[v][n] > 0)  (y == NULL: no activation -- g is gy, `g` is not written and may be NULL),
+ *   gx[v][k] = sum_n g[v][n] * w[n][k],   gbias[n] = sum_v g[v][n]   (fixed summation order, deterministic).
+ * Replaces mdt_bias_act_backward + the input-gradient convolution of conv3 in a C2 ResBlock (models/backbone.py:203-205): (c_in, c_out) = (18, 72) only.
+ * gy, y, g 16-byte aligned.
+ */
+int mdt_conv1x1_backward_supported(int c_in, int c_out);
+size_t mdt_conv1x1_backward_workspace_bytes(long long n_voxels, int c_out);
+int mdt_conv1x1_backward(const float *gy, const float *y, const float *w, float *g, float *gx, float *gbias, long long n_voxels, int c_in, int c_out,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- input gradient of a 1x1(x1) convolution added to another gradient of the same tensor (csrc/epilogue.hip, round 4) ------------------
  * out[v][ci] = res[v][ci] + sum_co gy[v][co] * w[co][ci] over n_voxels channels-last rows (res may be NULL: plain input gradient).
  * What autograd does in two steps for a ResBlock input (models/backbone.py:197-205: x feeds conv1 and the residual add): the

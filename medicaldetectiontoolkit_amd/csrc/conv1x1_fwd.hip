@@ -161,6 +161,117 @@ __global__ __launch_bounds__(64 * WPB) void conv1x1_fwd_mfma_kernel(float *__res
     }
 }
 
+// ---- backward of the same layer's epilogue AND its input gradient in one pass (round 6) ------------------------------------------------------------
+//   g[v][n] = gy[v][n] * (y[v][n] > 0)   (y == null: g = gy, nothing stored),   gx[v][k] = sum_n g[v][n] * w[n][k],   gbias[n] = sum_v g[v][n]
+// conv3 of a C2 block (18 -> 72, + residual + ReLU): the ReLU-mask / bias-gradient pass (mdt_bias_act_backward: reads gy and y, writes g, 906 MB) was
+// followed by the input-gradient convolution reading g again (CK, 302 + 75 MB).  Here the masked rows of 32 voxels go to memory AND through the wave's
+// LDS slot into the matrix cores (A = g rows, B = the filter as it is stored, [c_out][c_in]); the bias gradient is the column sum of the same LDS tile,
+// kept per wave in registers and written as one partial row per wave (folded in a fixed order by the second stage: deterministic).
+// R = 2 KS output channels of the layer (the reduction of this product), C <= 32 input channels.
+template <int KS, int WPB, bool RELU>
+__global__ __launch_bounds__(64 * WPB) void conv1x1_bwd_mfma_kernel(float *__restrict__ g, float *__restrict__ gx, float *__restrict__ partial,
+                                                                    const float *__restrict__ gy, const float *__restrict__ y, const float *__restrict__ w,
+                                                                    long long V, int C)
+{
+    constexpr int R = 2 * KS;
+    constexpr int ASTR = R + 1;
+    constexpr int NA = (8 * R + 63) / 64;
+    __shared__ float s_a[WPB][32 * ASTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    float bfrag[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bfrag[ks] = col < C ? w[(long long)(2 * ks + half) * C + col] : 0.0f;
+    float bsum0 = 0.0f, bsum1 = 0.0f;                    // channels lane and lane + 64
+    const long long tiles = (V + 31) / 32;
+    float *sa = s_a[wave];
+    for (long long tile = (long long)blockIdx.x * WPB + wave; tile < tiles; tile += (long long)gridDim.x * WPB) {
+        const long long v0 = tile * 32;
+        const int nv = (int)min((long long)32, V - v0);
+        const int n4 = (nv * R) >> 2;                    // R is even; nv * R % 4 != 0 only when R % 4 == 2 and nv odd: scalar tail below
+        const v4f *sg = reinterpret_cast<const v4f *>(gy + v0 * R);
+        const v4f *sy = reinterpret_cast<const v4f *>(y + v0 * R);
+        v4f *dg = reinterpret_cast<v4f *>(g + v0 * R);
+        v4f ga[NA], ya[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e4 = lane + 64 * i;
+            ga[i] = (e4 < n4) ? sg[e4] : v4f{0.f, 0.f, 0.f, 0.f};
+            if (RELU) ya[i] = (e4 < n4) ? sy[e4] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e4 = lane + 64 * i;
+            if (RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ga[i][j] = ya[i][j] > 0.0f ? ga[i][j] : 0.0f;
+                if (e4 < n4) dg[e4] = ga[i];
+            }
+            if (e4 < 8 * R) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e4 * 4 + j, m = e / R, k = e - m * R;
+                    sa[m * ASTR + k] = ga[i][j];             // (rows past nv: zeros)
+                }
+            }
+        }
+        for (int e = n4 * 4 + lane; e < nv * R; e += 64) {   // at most a 2-float tail of the last tile
+            float v = gy[v0 * R + e];
+            if (RELU) { v = y[v0 * R + e] > 0.0f ? v : 0.0f; g[v0 * R + e] = v; }
+            const int m = e / R, k = e - m * R;
+            sa[m * ASTR + k] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float afrag[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) afrag[ks] = sa[col * ASTR + 2 * ks + half];
+        // bias gradient: column sums of the tile, rows ascending
+        {
+            float s0 = 0.0f, s1 = 0.0f;
+            const int c1 = (lane + 64 < R) ? lane + 64 : lane;
+#pragma unroll 8
+            for (int m = 0; m < 32; ++m) { s0 = s0 + sa[m * ASTR + lane]; s1 = s1 + sa[m * ASTR + c1]; }
+            bsum0 = bsum0 + s0;
+            bsum1 = bsum1 + s1;
+        }
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[ks], bfrag[ks], acc, 0, 0, 0);
+        if (col < C) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < nv) gx[(v0 + row) * C + col] = acc[r];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    float *prow = partial + ((long long)blockIdx.x * WPB + wave) * R;
+    if (lane < R) prow[lane] = bsum0;
+    if (lane + 64 < R) prow[lane + 64] = bsum1;
+}
+
+// gbias[n] = sum over the partial rows, rows ascending within a thread's strided subset, then a fixed LDS tree (one block per channel)
+__global__ __launch_bounds__(256) void conv1x1_bwd_bias_finish_kernel(float *__restrict__ gbias, const float *__restrict__ partial, int rows, int R)
+{
+    __shared__ float s_acc[256];
+    const int n = blockIdx.x;
+    float s = 0.0f;
+    for (int j = threadIdx.x; j < rows; j += 256) s = s + partial[(long long)j * R + n];
+    s_acc[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) s_acc[threadIdx.x] = s_acc[threadIdx.x] + s_acc[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gbias[n] = s_acc[0];
+}
+
 template <int KS, int NT, int WPB, bool BL>
 int launch(float *out, const float *x, const float *w, const float *bias, const float *res, long long V, int N, int relu, hipStream_t s)
 {
@@ -202,6 +313,44 @@ int mdt_conv1x1_forward(const float *x, const float *w, const float *bias, const
     // (144 -> 36, conv1 of the C3 blocks, measured SLOWER here than CK + the epilogue kernel: 85 us against 27 + 8 us -- 18 KB of input rows per
     // wave tile, 290 registers; not served)
     return launch<36, 1, 4, false>(out, x, w, bias, res, n_voxels, c_out, relu, s);
+}
+
+// conv3 of the C2 blocks (72 output channels back to 18 inputs); the C3 shape (144 -> 36) would need 18 KB of rows per wave tile (see the forward's note)
+int mdt_conv1x1_backward_supported(int c_in, int c_out) { return (c_in == 18 && c_out == 72) ? 1 : 0; }
+
+static long long c1_bwd_blocks(long long n_voxels)
+{
+    const long long tiles = (n_voxels + 31) / 32;
+    long long blocks = (tiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+size_t mdt_conv1x1_backward_workspace_bytes(long long n_voxels, int c_out)
+{
+    if (n_voxels < 0 || c_out <= 0) return 256;
+    return (size_t)c1_bwd_blocks(n_voxels) * 4 * c_out * sizeof(float) + 256;
+}
+
+int mdt_conv1x1_backward(const float *gy, const float *y, const float *w, float *g, float *gx, float *gbias, long long n_voxels, int c_in, int c_out,
+                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!gy || !w || !gx || !gbias || n_voxels < 0 || (y != nullptr && g == nullptr)) return MDT_ERR_INVALID_ARGUMENT;
+    if (!mdt_conv1x1_backward_supported(c_in, c_out)) return MDT_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < mdt_conv1x1_backward_workspace_bytes(n_voxels, c_out)) return MDT_ERR_WORKSPACE_TOO_SMALL;
+    if ((((uintptr_t)gy | (uintptr_t)y | (uintptr_t)g) & 15) != 0) return MDT_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *partial = static_cast<float *>(workspace);
+    const long long blocks = n_voxels > 0 ? c1_bwd_blocks(n_voxels) : 0;
+    (void)hipGetLastError();
+    if (blocks > 0) {
+        if (y) hipLaunchKernelGGL((conv1x1_bwd_mfma_kernel<36, 4, true>), dim3((unsigned)blocks), dim3(256), 0, s, g, gx, partial, gy, y, w, n_voxels, c_in);
+        else hipLaunchKernelGGL((conv1x1_bwd_mfma_kernel<36, 4, false>), dim3((unsigned)blocks), dim3(256), 0, s, g, gx, partial, gy, gy, w, n_voxels, c_in);
+        if (c1_check() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
+    }
+    hipLaunchKernelGGL(conv1x1_bwd_bias_finish_kernel, dim3((unsigned)c_out), dim3(256), 0, s, gbias, partial, (int)(blocks * 4), c_out);
+    return c1_check();
 }
 
 }  // extern "C"

@@ -1005,6 +1005,31 @@ def _conv1x1_forward(x, w, bias, res, relu):
     return out
 
 
+CONV1X1_BWD = True   # module switch (A/B: bench.py --conv1x1-bwd 0): ReLU mask + bias gradient + input gradient of conv3 (C2 blocks) in one pass (mdt_conv1x1_backward)
+
+
+def _conv1x1_backward(gy, y, w, mf):
+    """(g, gx, gbias) of act(conv1x1(x, w) + bias (+ res)) for the output gradient gy (y: the saved output when the activation is a ReLU, else None), one pass;
+    None when the layer is not mdt_conv1x1_backward's (shape, layout, alignment)"""
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    L = _lib.lib()
+    if not (L.mdt_conv1x1_backward_supported(cin, cout) and gy.is_cuda and gy.dtype == torch.float32 and gy.is_contiguous(memory_format=mf) and not gy.is_contiguous()
+            and gy.data_ptr() % 16 == 0 and (y is None or y.data_ptr() % 16 == 0) and _on_current_device(gy)):
+        return None
+    V = gy.numel() // cout
+    g = torch.empty_like(gy) if y is not None else None
+    gx = torch.empty((gy.shape[0], cin) + tuple(gy.shape[2:]), dtype=torch.float32, device=gy.device, memory_format=mf)
+    gbias = torch.empty(cout, dtype=torch.float32, device=gy.device)
+    ws = _workspace(L.mdt_conv1x1_backward_workspace_bytes(V, cout), gy.device)
+    rc = L.mdt_conv1x1_backward(gy.data_ptr(), y.data_ptr() if y is not None else None, w.detach().data_ptr(), g.data_ptr() if g is not None else None, gx.data_ptr(),
+                                gbias.data_ptr(), V, cin, cout, ws.data_ptr(), ws.numel(), _lib.raw_stream())
+    if rc == _lib.MDT_ERR_UNSUPPORTED:
+        return None
+    if rc != 0:
+        _lib.check(rc, "mdt_conv1x1_backward")
+    return (g if g is not None else gy), gx, gbias
+
+
 class _Conv1x1BiasAct(Function):
     """y = act(conv1x1(x) + bias (+ residual)) in ONE pass over the operands (csrc/conv1x1_fwd.hip) -- conv3 + residual + ReLU of a ResBlock
     (models/backbone.py:203-205).  Backward: the ReLU mask and the bias gradient as in _BiasAct, input / weight gradients as in _ConvStride1."""
@@ -1032,12 +1057,17 @@ class _Conv1x1BiasAct(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors[0], ctx.saved_tensors[1]
         y = ctx.saved_tensors[2] if ctx.relu else None
+        nd = w.dim() - 2
+        fused = _conv1x1_backward(gy, y, w, ctx.mf) if (CONV1X1_BWD and ctx.needs_input_grad[0]) else None
+        if fused is not None:               # ReLU mask, bias gradient and input gradient from ONE pass over gy (mdt_conv1x1_backward)
+            g, gx, gbias = fused
+            gw = _stride1_grads(x, w, (0,) * nd, g, False, True)[1] if ctx.needs_input_grad[1] else None
+            return gx, gw, (gbias if ctx.needs_input_grad[2] else None), (g if ctx.has_res and ctx.needs_input_grad[3] else None), None
         if not ctx.relu and not gy.is_contiguous(memory_format=ctx.mf):
             r = bias_grad_to_channels_last(gy, ctx.mf)
             g, gbias = r if r is not None else _bias_act_bwd(gy, None, False, ctx.mf)
         else:
             g, gbias = _bias_act_bwd(gy, y, ctx.relu, ctx.mf)
-        nd = w.dim() - 2
         gx, gw = _stride1_grads(x, w, (0,) * nd, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gx, gw, (gbias if ctx.needs_input_grad[2] else None), (g if ctx.has_res and ctx.needs_input_grad[3] else None), None
 

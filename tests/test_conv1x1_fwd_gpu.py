@@ -112,3 +112,71 @@ def test_identity_resblock_with_fused_1x1_layers_equals_plain_modules(cuda):
     a, b = run(True), run(False)
     for u, v in zip(a, b):
         assert float((u - v).abs().max()) <= 1e-3 * float(v.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("V", [32 * 64, 1000 + 7, 3])
+def test_conv1x1_backward_vs_float64(relu, V, cuda):
+    """mdt_conv1x1_backward: g exact (a mask), gx and gbias against float64 within fp32 summation-order bounds, run-to-run identical"""
+    cin, cout = 18, 72
+    g_ = torch.Generator(device=cuda).manual_seed(V + relu)
+    gy = torch.randn(V, cout, device=cuda, generator=g_)
+    y = torch.randn(V, cout, device=cuda, generator=g_) if relu else None
+    w = torch.randn(cout, cin, device=cuda, generator=g_) * 0.2
+    L = _lib.lib()
+    assert L.mdt_conv1x1_backward_supported(cin, cout) and not L.mdt_conv1x1_backward_supported(36, 144)
+    wsb = L.mdt_conv1x1_backward_workspace_bytes(V, cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+
+    def run():
+        g = torch.full((V + 1, cout), 7.0, device=cuda) if relu else None
+        gx = torch.full((V + 1, cin), 7.0, device=cuda)
+        gb = torch.empty(cout, device=cuda)
+        rc = L.mdt_conv1x1_backward(gy.data_ptr(), y.data_ptr() if relu else None, w.data_ptr(), g.data_ptr() if relu else None, gx.data_ptr(), gb.data_ptr(), V, cin, cout,
+                                    ws.data_ptr(), wsb, _lib.raw_stream())
+        assert rc == 0
+        return g, gx, gb
+
+    g, gx, gb = run()
+    gref = gy * (y > 0) if relu else gy
+    if relu:
+        assert torch.equal(g[:V], gref) and bool((g[V] == 7.0).all())
+    assert bool((gx[V] == 7.0).all())
+    ref = gref.double() @ w.double()
+    bound = 2e-6 * (gref.double().abs() @ w.double().abs()) + 1e-7
+    assert bool(((gx[:V].double() - ref).abs() <= bound).all())
+    bref = gref.double().sum(0)
+    assert float((gb.double() - bref).abs().max()) <= 2e-6 * float(gref.double().abs().sum(0).max())
+    g2, gx2, gb2 = run()
+    assert torch.equal(gx2, gx) and torch.equal(gb2, gb)
+    # too small a workspace / a ReLU without a place for g are argument errors
+    assert L.mdt_conv1x1_backward(gy.data_ptr(), None, w.data_ptr(), None, gx.data_ptr(), gb.data_ptr(), V, cin, cout, ws.data_ptr(), 16, _lib.raw_stream()) == -2
+    if relu:
+        assert L.mdt_conv1x1_backward(gy.data_ptr(), y.data_ptr(), w.data_ptr(), None, gx.data_ptr(), gb.data_ptr(), V, cin, cout, ws.data_ptr(), wsb, _lib.raw_stream()) == -1
+
+
+def test_conv_bias_module_backward_in_one_pass_equals_the_separate_passes(cuda):
+    """ConvBias3d 18 -> 72 + residual + ReLU: the backward through mdt_conv1x1_backward vs mdt_bias_act_backward + the input-gradient convolution"""
+    mf = torch.channels_last_3d
+    g = torch.Generator(device=cuda).manual_seed(8)
+    conv = fe.ConvBias3d(18, 72, 1).to(cuda).to(memory_format=mf)
+    x0 = torch.randn(2, 18, 32, 32, 32, device=cuda, generator=g).contiguous(memory_format=mf)
+    r0 = torch.randn(2, 72, 32, 32, 32, device=cuda, generator=g).contiguous(memory_format=mf)
+    gy = torch.randn(2, 72, 32, 32, 32, device=cuda, generator=g).contiguous(memory_format=mf)
+
+    def run(on, relu):
+        fe.CONV1X1_BWD = on
+        try:
+            conv.zero_grad()
+            x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            r = r0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            conv(x, residual=r * 1.0, relu=relu).backward(gy)
+            return x.grad.clone(), r.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()
+        finally:
+            fe.CONV1X1_BWD = True
+
+    for relu in (True, False):
+        a, b = run(True, relu), run(False, relu)
+        assert torch.equal(a[1], b[1])                          # the masked gradient itself
+        for u, v in zip(a, b):
+            assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max())
