@@ -625,6 +625,7 @@ def main():
     ap.add_argument("--bias-grad-in-launch", type=int, default=0, help="1: the bias gradient's second stage inside the backward epilogue's launch (measured slower, profiles/r06/r06_bias_grad_in_launch_probe.txt); 0 (default): separate finish launch")
     ap.add_argument("--conv1x1-fwd", type=int, default=1, help="1 (default): the bottleneck 1x1 layers of the C2 / C3 stages with bias / residual / ReLU in one pass (mdt_conv1x1_forward); 0: MIOpen + epilogue kernel (A/B)")
     ap.add_argument("--conv1x1-bwd", type=int, default=1, help="1 (default): ReLU mask + bias gradient + input gradient of conv3 in the C2 blocks in one pass (mdt_conv1x1_backward); 0: epilogue kernel + CK (A/B)")
+    ap.add_argument("--rpn-heads-fused", type=int, default=1, help="1 (default): the dense RPN forward runs both heads on the raw conv_shared output in one launch per level (mdt_rpn_heads_forward); 0: per-level modules + torch.cat (A/B)")
     ap.add_argument("--bias-bwd-no-copy", type=int, default=1, help="1 (default): bias-only layers' backward returns the output gradient itself; 0: stores a copy (A/B)")
     ap.add_argument("--bias-grad-transpose", type=int, default=1, help="1 (default): row-major output gradients of channels-last bias-only layers converted + reduced in one pass (A/B)")
     ap.add_argument("--lateral-upsample-fused", type=int, default=1, help="1 (default): the FPN's top-down add reads the coarser map directly; 0: materialised up-sampling (A/B)")
@@ -713,6 +714,7 @@ def main():
     mrcnn.MERGE_RPN_HEADS = bool(args.merge_rpn_heads)
     mrcnn.SPARSE_RPN_LOSS = bool(args.sparse_rpn_loss)
     mrcnn.FUSED_GLUE = bool(args.fused_glue)
+    mrcnn.RPN_HEADS_FUSED = bool(args.rpn_heads_fused)
     mrcnn.SHARED_PYRAMID_GRAD = bool(args.shared_pyramid_grad)
     fused_epilogue.BIAS_GRAD_IN_LAUNCH = bool(args.bias_grad_in_launch)
     fused_epilogue.FLIP_BATCHED = bool(args.flip_batched)

@@ -517,6 +517,18 @@ size_t mdt_conv1x1_backward_workspace_bytes(long long n_voxels, int c_out);
 int mdt_conv1x1_backward(const float *gy, const float *y, const float *w, float *g, float *gx, float *gbias, long long n_voxels, int c_in, int c_out,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The RPN's two 1x1 heads (mrcnn.py:40-86) on the RAW output of conv_shared, forward only, channels-last fp32 rows:
+ *   y[v][n] = sum_k relu(h[v][k] + bias_shared[k]) * w[n][k] + bias[n];   w = [conv_class.weight ; conv_bbox.weight] ([n_class + n_box][hidden]), bias alike.
+ * Class logits go to logits[b][anchor_offset + v * A + a][0..1], box deltas to deltas[b][anchor_offset + v * A + a][0..2 dim - 1] (A = n_class / 2 anchors per
+ * voxel; v = the voxel's index inside its batch element) -- the level's slice of the tensors the reference builds with torch.cat over the pyramid levels
+ * (mrcnn.py:1030-1033; [batch][anchors_total][2] and [batch][anchors_total][n_box / A]).  One pass over the hidden map instead of conv_shared's bias / ReLU
+ * pass, the head convolution, its bias pass, two slicing copies and the concatenations.  hidden == 128, n_class + n_box <= 32; h 16-byte aligned.
+ */
+int mdt_rpn_heads_forward_supported(int hidden, int n_class, int n_box);
+int mdt_rpn_heads_forward(const float *h, const float *bias_shared, const float *w, const float *bias, float *logits, float *deltas, int batch,
+                          long long voxels_per_element, int hidden, int n_class, int n_box, long long anchors_total, long long anchor_offset, void *stream);
+
 /* ---- input gradient of a 1x1(x1) convolution added to another gradient of the same tensor (csrc/epilogue.hip, round 4) ------------------
  * out[v][ci] = res[v][ci] + sum_co gy[v][co] * w[co][ci] over n_voxels channels-last rows (res may be NULL: plain input gradient).
  * What autograd does in two steps for a ResBlock input (models/backbone.py:197-205: x feeds conv1 and the residual add): the

@@ -272,6 +272,84 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_bias_finish_kernel(float *__r
     if (threadIdx.x == 0) gbias[n] = s_acc[0];
 }
 
+// ---- the RPN's two 1x1 heads on the raw output of conv_shared (round 6) ----------------------------------------------------------------------------
+//   y[v][n] = sum_k relu(h[v][k] + bs[k]) * w[n][k] + b[n],   n < n_class (class logits) | n >= n_class (box deltas)
+// written STRAIGHT into the level's slice of the concatenated [B][anchors of all levels][2] / [..][2 * dim] tensors (mrcnn.py:70-86 + the torch.cat of
+// :1030): the reference's conv_shared epilogue (bias + ReLU: a 537 MB read and a 537 MB write on P2 at the benchmark patch), the head convolution, its bias
+// pass, the two slicing copies and the two concatenations become ONE pass that reads the hidden map once.  Forward only (the training step differentiates
+// the RPN losses through the sampled anchors' patches, models/mrcnn.rpn_at_anchors).  K = 2 KS hidden channels, N <= 32 head channels.
+template <int KS, int WPB>
+__global__ __launch_bounds__(64 * WPB) void rpn_heads_mfma_kernel(float *__restrict__ logits, float *__restrict__ deltas, const float *__restrict__ h,
+                                                                  const float *__restrict__ bs, const float *__restrict__ w, const float *__restrict__ b,
+                                                                  unsigned V, unsigned Vl, int ncl, int nbox, long long lstride, long long loff, long long dstride,
+                                                                  long long doff)
+{
+    constexpr int K = 2 * KS;
+    constexpr int ASTR = K + 1;
+    constexpr int NA = (8 * K + 63) / 64;
+    __shared__ float s_a[WPB][32 * ASTR];
+    __shared__ float s_bs[K];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int N = ncl + nbox;
+    __shared__ float s_b[K * 32];                        // the filter, [k][n]: 64 filter registers beside the 64 row registers left one wave per SIMD
+    for (int k = threadIdx.x; k < K; k += 64 * WPB) s_bs[k] = bs[k];
+    for (int e = threadIdx.x; e < K * 32; e += 64 * WPB) {
+        const int k = e >> 5, n = e & 31;
+        s_b[e] = n < N ? w[(long long)n * K + k] : 0.0f;
+    }
+    const float bv = col < N ? b[col] : 0.0f;
+    __syncthreads();
+    const unsigned tiles = (V + 31) / 32;
+    float *sa = s_a[wave];
+    for (unsigned tile = blockIdx.x * WPB + wave; tile < tiles; tile += gridDim.x * WPB) {
+        const unsigned v0 = tile * 32;
+        const int nv = (int)min(32u, V - v0);
+        const int n4 = (nv * K) >> 2;                    // K % 4 == 0
+        const v4f *src = reinterpret_cast<const v4f *>(h + (unsigned long long)v0 * K);
+        v4f areg[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e4 = lane + 64 * i;
+            areg[i] = (e4 < n4) ? src[e4] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e4 = lane + 64 * i;
+            if (e4 < 8 * K) {
+                const int e = e4 * 4, m = e / K, k = e - m * K;          // K % 4 == 0: the four share a row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = areg[i][j] + s_bs[k + j];
+                    sa[m * ASTR + k + j] = (e4 < n4 && v > 0.0f) ? v : 0.0f;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[col * ASTR + 2 * ks + half], s_b[(2 * ks + half) * 32 + col], acc, 0, 0, 0);
+        if (col < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < nv) {
+                    const unsigned v = v0 + row, be = v / Vl, vl = v - be * Vl;
+                    const float val = acc[r] + bv;
+                    if (col < ncl) logits[be * lstride + loff + (long long)vl * ncl + col] = val;
+                    else deltas[be * dstride + doff + (long long)vl * nbox + (col - ncl)] = val;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int KS, int NT, int WPB, bool BL>
 int launch(float *out, const float *x, const float *w, const float *bias, const float *res, long long V, int N, int relu, hipStream_t s)
 {
@@ -350,6 +428,34 @@ int mdt_conv1x1_backward(const float *gy, const float *y, const float *w, float 
         if (c1_check() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
     }
     hipLaunchKernelGGL(conv1x1_bwd_bias_finish_kernel, dim3((unsigned)c_out), dim3(256), 0, s, gbias, partial, (int)(blocks * 4), c_out);
+    return c1_check();
+}
+
+int mdt_rpn_heads_forward_supported(int hidden, int n_class, int n_box)
+{
+    return (hidden == 128 && n_class >= 1 && n_box >= 1 && n_class + n_box <= 32) ? 1 : 0;
+}
+
+int mdt_rpn_heads_forward(const float *h, const float *bias_shared, const float *w, const float *bias, float *logits, float *deltas, int batch,
+                          long long voxels_per_element, int hidden, int n_class, int n_box, long long anchors_total, long long anchor_offset, void *stream)
+{
+    if (!h || !bias_shared || !w || !bias || !logits || !deltas || batch < 0 || voxels_per_element < 0 || anchors_total < 0 || anchor_offset < 0)
+        return MDT_ERR_INVALID_ARGUMENT;
+    if (!mdt_rpn_heads_forward_supported(hidden, n_class, n_box)) return MDT_ERR_UNSUPPORTED;
+    const long long V = (long long)batch * voxels_per_element;
+    if (V == 0) return MDT_OK;
+    if (V >= 0x7fffffffLL / 4 || ((uintptr_t)h & 15) != 0) return MDT_ERR_UNSUPPORTED;
+    // anchors per voxel A: n_class = 2 A, n_box = 2 dim A; the level's slice of element b starts at anchor b * anchors_total + anchor_offset
+    const int A = n_class / 2;
+    if (A < 1 || n_class != 2 * A || n_box % A != 0) return MDT_ERR_INVALID_ARGUMENT;
+    const int d2 = n_box / A;
+    if (anchor_offset + voxels_per_element * A > anchors_total) return MDT_ERR_INVALID_ARGUMENT;
+    const long long tiles = (V + 31) / 32;
+    long long blocks = (tiles + 1) / 2;
+    if (blocks > 4096) blocks = 4096;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((rpn_heads_mfma_kernel<64, 2>), dim3((unsigned)blocks), dim3(128), 0, static_cast<hipStream_t>(stream), logits, deltas, h, bias_shared, w, bias,
+                       (unsigned)V, (unsigned)voxels_per_element, n_class, n_box, anchors_total * 2, anchor_offset * 2, anchors_total * d2, anchor_offset * d2);
     return c1_check();
 }
 

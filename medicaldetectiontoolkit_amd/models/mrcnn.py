@@ -75,6 +75,56 @@ class RPN(nn.Module):
         return [rpn_class_logits, rpn_probs, rpn_bbox]
 
 
+RPN_HEADS_FUSED = True   # module switch (A/B: bench.py --rpn-heads-fused 0): the dense, gradient-free RPN forward runs both heads on the raw conv_shared output in one
+                         # launch per level that writes straight into the concatenated outputs (mdt_rpn_heads_forward)
+
+
+def rpn_levels_fused(rpn, feature_maps):
+    """[logits, probs, deltas] of the RPN over all pyramid levels, concatenated along the anchor axis as mrcnn.py:1030-1033 builds them -- without autograd
+    graph: per level conv_shared's raw output goes through ONE kernel (bias + ReLU of conv_shared, both 1x1 heads, their biases, the slicing and the
+    concatenation; csrc/conv1x1_fwd.hip rpn_heads_mfma_kernel), then one softmax over the concatenated logits.  None when the case is not the kernel's
+    (the caller runs RPN.forward per level)."""
+    from .. import _lib
+    cs = rpn.conv_shared
+    if not (isinstance(cs, fused_epilogue.ConvBiasReLU) and isinstance(rpn.conv_class, fused_epilogue.ConvBias) and isinstance(rpn.conv_bbox, fused_epilogue.ConvBias)):
+        return None
+    conv = cs[0]
+    nd = rpn.dim
+    mf = torch.channels_last_3d if nd == 3 else torch.channels_last
+    hidden, ncl, nbox = int(conv.out_channels), int(rpn.conv_class.out_channels), int(rpn.conv_bbox.out_channels)
+    L = _lib.lib()
+    if conv.bias is None or not all(int(v) == 1 for v in conv.stride) or not L.mdt_rpn_heads_forward_supported(hidden, ncl, nbox) \
+            or not all(int(k) == 1 for k in rpn.conv_class.kernel_size) or not all(int(k) == 1 for k in rpn.conv_bbox.kernel_size):
+        return None
+    if not all(m.is_cuda and m.dtype == torch.float32 and m.dim() == nd + 2 and m.is_contiguous(memory_format=mf) and not m.is_contiguous() for m in feature_maps) \
+            or torch.is_autocast_enabled():
+        return None
+    A = ncl // 2
+    B = int(feature_maps[0].shape[0])
+    with torch.no_grad():
+        vox = [int(m.shape[2:].numel()) for m in feature_maps]
+        total = sum(vox) * A
+        dev = feature_maps[0].device
+        logits = torch.empty(B, total, 2, dtype=torch.float32, device=dev)
+        deltas = torch.empty(B, total, nbox // A, dtype=torch.float32, device=dev)
+        w = torch.cat([rpn.conv_class.weight.reshape(ncl, hidden), rpn.conv_bbox.weight.reshape(nbox, hidden)], 0)
+        b = torch.cat([rpn.conv_class.bias, rpn.conv_bbox.bias], 0)
+        off = 0
+        for m, v in zip(feature_maps, vox):
+            h = fused_epilogue._conv(conv, m)
+            if not h.is_contiguous(memory_format=mf):
+                h = h.contiguous(memory_format=mf)
+            rc = L.mdt_rpn_heads_forward(h.data_ptr(), conv.bias.data_ptr(), w.data_ptr(), b.data_ptr(), logits.data_ptr(), deltas.data_ptr(), B, v, hidden, ncl, nbox,
+                                         total, off, _lib.raw_stream())
+            if rc == _lib.MDT_ERR_UNSUPPORTED:
+                return None
+            if rc != 0:
+                _lib.check(rc, "mdt_rpn_heads_forward")
+            off += v * A
+        probs = F.softmax(logits, dim=2)
+    return [logits, probs, deltas]
+
+
 def rpn_sparse_supported(rpn):
     """rpn_at_anchors restates the RPN for single voxels: 3^dim unit-stride conv_shared (+ ReLU / LeakyReLU, no norm layer) and 1^dim heads"""
     cs = rpn.conv_shared
@@ -1015,9 +1065,13 @@ class net(nn.Module):
         if keep_rpn_maps is None:
             keep_rpn_maps = is_training
         self.rpn_feature_maps = rpn_feature_maps if keep_rpn_maps else None       # read by rpn_at_anchors, released after the RPN losses
-        with torch.set_grad_enabled(rpn_graph and torch.is_grad_enabled()):
-            layer_outputs = [self.rpn(p) for p in rpn_feature_maps]
-            rpn_pred_logits, rpn_pred_probs, rpn_pred_deltas = [torch.cat(list(o), dim=1) for o in zip(*layer_outputs)]
+        fused_rpn = rpn_levels_fused(self.rpn, rpn_feature_maps) if (RPN_HEADS_FUSED and not (rpn_graph and torch.is_grad_enabled())) else None
+        if fused_rpn is not None:
+            rpn_pred_logits, rpn_pred_probs, rpn_pred_deltas = fused_rpn
+        else:
+            with torch.set_grad_enabled(rpn_graph and torch.is_grad_enabled()):
+                layer_outputs = [self.rpn(p) for p in rpn_feature_maps]
+                rpn_pred_logits, rpn_pred_probs, rpn_pred_deltas = [torch.cat(list(o), dim=1) for o in zip(*layer_outputs)]
         proposal_count = cf.post_nms_rois_training if is_training else cf.post_nms_rois_inference
         batch_rpn_rois, batch_proposal_boxes = proposal_layer(rpn_pred_probs, rpn_pred_deltas, proposal_count, self.anchors, cf)
         batch_ixs = torch.arange(B, device=img.device, dtype=torch.float32).repeat_interleave(batch_rpn_rois.shape[1])

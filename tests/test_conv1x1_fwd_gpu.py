@@ -180,3 +180,32 @@ def test_conv_bias_module_backward_in_one_pass_equals_the_separate_passes(cuda):
         assert torch.equal(a[1], b[1])                          # the masked gradient itself
         for u, v in zip(a, b):
             assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max())
+
+
+@pytest.mark.parametrize("shapes", [[(16, 16, 8), (8, 8, 4), (4, 4, 2)], [(5, 7, 3)], [(32, 32, 16), (16, 16, 8), (8, 8, 4), (4, 4, 2)]])
+def test_rpn_levels_fused_equals_the_modules_and_the_concatenation(shapes, cuda):
+    """mdt_rpn_heads_forward through models/mrcnn.rpn_levels_fused: logits / deltas within fp32 summation-order rounding of RPN.forward per level + torch.cat
+    (the reference's mrcnn.py:40-86, :1030-1033), probs the softmax of the logits it returns; ragged voxel counts (tiles straddle batch elements)"""
+    from medicaldetectiontoolkit_amd.configs import Configs
+    from medicaldetectiontoolkit_amd.models import mrcnn
+    from medicaldetectiontoolkit_amd.utils import model_utils as mutils
+    cf = Configs(dim=3, model="mrcnn", patch_size=[64, 64, 32], batch_size=2, channels_last=True)
+    torch.manual_seed(3)
+    rpn = mrcnn.RPN(cf, mutils.NDConvGenerator(3)).to(cuda).to(memory_format=torch.channels_last_3d)
+    flat = torch.zeros(129, device=cuda)                    # conv_shared's bias inside a flat buffer: 4-byte aligned only
+    flat[1:].copy_(rpn.conv_shared[0].bias.detach())
+    rpn.conv_shared[0].bias.data = flat[1:]
+    g = torch.Generator(device=cuda).manual_seed(9)
+    maps = [torch.randn((3, cf.end_filts) + s, device=cuda, generator=g).contiguous(memory_format=torch.channels_last_3d) for s in shapes]
+    with torch.no_grad():
+        fused = mrcnn.rpn_levels_fused(rpn, maps)
+        assert fused is not None
+        ref = [torch.cat(list(o), dim=1) for o in zip(*[rpn(m) for m in maps])]
+    for k in (0, 2):
+        assert fused[k].shape == ref[k].shape
+        assert float((fused[k] - ref[k]).abs().max()) <= 2e-5 * float(ref[k].abs().max())
+    assert torch.equal(fused[1], F.softmax(fused[0], dim=2))
+    assert float((fused[1] - ref[1]).abs().max()) <= 1e-5
+    with torch.no_grad():
+        again = mrcnn.rpn_levels_fused(rpn, maps)
+    assert torch.equal(again[0], fused[0]) and torch.equal(again[2], fused[2])
