@@ -160,8 +160,16 @@ class FPN(nn.Module):
             c0_out = self.C0[1](h)
         else:
             c0_out = x
-        c1_out = self.C1(c0_out)
-        c2_out = self.C2(c1_out)
+        if not self.operate_stride1 and fused_epilogue.stem_pool_fused_applies(self.C1, self.C2[0], c0_out):
+            # the stem output has ONE consumer here (the pooling in front of C2): one autograd node for stem + bias + ReLU + pooling, whose backward
+            # applies the ReLU mask / bias gradient at the pooled resolution (utils/fused_epilogue._ConvStemBiasReLUPool)
+            c1_out = None
+            c2_out = fused_epilogue.conv_stem_bias_relu_pool(self.C1, c0_out)
+            for blk in list(self.C2)[1:]:
+                c2_out = blk(c2_out)
+        else:
+            c1_out = self.C1(c0_out)
+            c2_out = self.C2(c1_out)
         c3_out, c2_out = self._stage(self.C3, c2_out)
         c4_out, c3_out = self._stage(self.C4, c3_out)
         c5_out, c4_out = self._stage(self.C5, c4_out)

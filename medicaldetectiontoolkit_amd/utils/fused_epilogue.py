@@ -938,6 +938,70 @@ class _ConvStemBiasReLU(Function):
         return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), gbias
 
 
+STEM_POOL_FUSED = True   # module switch (A/B: bench.py --stem-pool-fused 0)
+
+
+class _ConvStemBiasReLUPool(Function):
+    """maxpool_{3, (2, 2, 1), 1}(relu(stem(x) + bias)) as ONE autograd node (models/backbone.py:128-131 when the stem output has no other consumer).
+    Forward: the two kernels _ConvStemBiasReLU and _MaxPoolK3S221 run.  Backward: the ReLU mask and the bias gradient are applied at the POOLED
+    resolution BEFORE the pooling backward -- a pooled value is the stem output at its arg-max tap, so (y[tap] > 0) == (p > 0), and the bias gradient
+    sum_taps g[tap] == sum_windows gp * (p > 0).  The mask / bias pass then touches the 75 MB pooled tensors instead of the 302 MB stem output
+    (226 MB of traffic instead of 906 MB at the benchmark patch), and the stem output itself is not kept for the backward (302 MB of activations)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        y, xp = stem_forward(x, w, bias.detach(), True)
+        B, C, Y, X, Z = y.shape
+        OY, OX = (Y - 1) // 2 + 1, (X - 1) // 2 + 1
+        p = torch.empty((B, C, OY, OX, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+        arg = torch.empty((B, OY, OX, Z, C), dtype=torch.uint8, device=x.device)
+        rc = _lib.lib().mdt_maxpool3d_k3s221_cl_forward(y.data_ptr(), p.data_ptr(), arg.data_ptr(), B, Y, X, Z, C, _lib.raw_stream())
+        if rc != 0:
+            _lib.check(rc, "mdt_maxpool3d_k3s221_cl_forward")
+        ctx.save_for_backward(x, w, p, arg)
+        ctx.xp = xp
+        ctx.y_shape = (B, C, Y, X, Z)
+        return p
+
+    @staticmethod
+    def backward(ctx, gp):
+        x, w, p, arg = ctx.saved_tensors
+        gm, gbias = _bias_act_bwd(gp, p, True, torch.channels_last_3d)          # gp * (p > 0) and its per-channel sum, at the pooled size
+        B, C, Y, X, Z = ctx.y_shape
+        g = torch.empty((B, C, Y, X, Z), dtype=torch.float32, device=gp.device, memory_format=torch.channels_last_3d)
+        rc = _lib.lib().mdt_maxpool3d_k3s221_cl_backward(gm.data_ptr(), arg.data_ptr(), g.data_ptr(), B, Y, X, Z, C, _lib.raw_stream())
+        if rc != 0:
+            _lib.check(rc, "mdt_maxpool3d_k3s221_cl_backward")
+        xp, ctx.xp = ctx.xp, None
+        gw = stem_weight_grad(g, x, w, (2, 2, 1), xp=xp) if ctx.needs_input_grad[1] else None
+        need_w = bool(ctx.needs_input_grad[1]) and gw is None
+        gx = None
+        if ctx.needs_input_grad[0] or need_w:
+            gx, gw2, _ = torch.ops.aten.convolution_backward(g, x, w, None, [2, 2, 1], [3, 3, 3], [1, 1, 1], False, [0, 0, 0], 1,
+                                                             [bool(ctx.needs_input_grad[0]), need_w, False])
+            if need_w:
+                gw = gw2
+        return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), gbias
+
+
+def stem_pool_fused_applies(stem, pool, x):
+    """stem: the ConvBiasReLU Sequential of the one-channel 7x7x7 stride-(2, 2, 1) stem, pool: the MaxPool3dStem behind it, x: the stem's input"""
+    if not (ENABLED and STEM_POOL_FUSED and STEM_SPACE_TO_DEPTH and POOL_CHANNELS_LAST and isinstance(stem, ConvBiasReLU) and isinstance(pool, MaxPool3dStem)):
+        return False
+    conv = stem[0]
+    if not (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and isinstance(conv, nn.Conv3d) and conv.groups == 1 and _unit(conv.dilation)
+            and not isinstance(conv.padding, str) and _is_stem221(conv, x) and stem_forward_supported(x, conv.weight) and torch.is_grad_enabled()
+            and not torch.is_autocast_enabled() and _on_current_device(x)):
+        return False
+    return _t3(pool.kernel_size) == (3, 3, 3) and _t3(pool.stride) == (2, 2, 1) and _t3(pool.padding) == (1, 1, 1) and _t3(pool.dilation) == (1, 1, 1) \
+        and not pool.ceil_mode and not pool.return_indices and int(conv.out_channels) > 1
+
+
+def conv_stem_bias_relu_pool(stem, x):
+    conv = stem[0]
+    return _ConvStemBiasReLUPool.apply(x, conv.weight, conv.bias)
+
+
 def _unit(t):
     return all(int(v) == 1 for v in t)
 

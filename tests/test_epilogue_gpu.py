@@ -737,3 +737,29 @@ def test_bias_only_backward_returns_the_output_gradient_itself(cuda):
     ws = torch.empty(4096 * 36 + 64, device=cuda)
     rc = _lib.lib().mdt_bias_act_backward(None, gy.data_ptr(), x0.data_ptr(), b0.data_ptr(), gy.numel(), 36, 1, 1, ws.data_ptr(), ws.numel() * 4, _lib.raw_stream())
     assert rc == -1          # MDT_ERR_INVALID_ARGUMENT (include/mdt_hip.h)
+
+
+def test_stem_and_pooling_as_one_node_equals_the_two_nodes(cuda):
+    """_ConvStemBiasReLUPool: ReLU mask / bias gradient at the pooled resolution before the pooling backward.  Output and weight gradient bit-equal to
+    _ConvStemBiasReLU + _MaxPoolK3S221 (a 0/1 mask commutes with the pooling backward's sums), bias gradient to summation-order rounding; an
+    FPN built on it gives the same pyramid as with the switch off"""
+    from medicaldetectiontoolkit_amd.utils import model_utils as mutils
+    torch.manual_seed(12)
+    conv = mutils.NDConvGenerator(3)
+    stem = conv(1, 18, ks=7, stride=(2, 2, 1), pad=3, norm=None, relu="relu").to(cuda).to(memory_format=torch.channels_last_3d)
+    pool = fe.MaxPool3dStem(kernel_size=3, stride=(2, 2, 1), padding=1)
+    x = torch.randn(2, 1, 64, 64, 32, device=cuda)
+    assert fe.stem_pool_fused_applies(stem, pool, x)
+    gp = torch.randn(2, 18, 16, 16, 32, device=cuda).contiguous(memory_format=torch.channels_last_3d)
+
+    def run(fused):
+        stem.zero_grad()
+        p = fe.conv_stem_bias_relu_pool(stem, x) if fused else pool(stem(x))
+        p.backward(gp)
+        return p.detach().clone(), stem[0].weight.grad.clone(), stem[0].bias.grad.clone()
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert float((a[2] - b[2]).abs().max()) <= 1e-5 * float(gp.abs().sum(dim=(0, 2, 3, 4)).max())
+    a2 = run(True)
+    assert torch.equal(a2[2], a[2])
