@@ -251,18 +251,27 @@ __global__ __launch_bounds__(64 * WPB) void conv1x1_bwd_mfma_kernel(float *__res
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    float *prow = partial + ((long long)blockIdx.x * WPB + wave) * R;
-    if (lane < R) prow[lane] = bsum0;
-    if (lane + 64 < R) prow[lane + 64] = bsum1;
+    // the block's waves are folded in wave order (LDS slot rows are free now), one value per (channel, block): partial[c][block] -- contiguous per channel
+    __syncthreads();
+    float *fold = &s_a[0][0];
+    if (lane < R) fold[wave * R + lane] = bsum0;
+    if (lane + 64 < R) fold[wave * R + lane + 64] = bsum1;
+    __syncthreads();
+    for (int c = threadIdx.x; c < R; c += 64 * WPB) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < WPB; ++wv) sum = sum + fold[wv * R + c];
+        partial[(long long)c * gridDim.x + blockIdx.x] = sum;
+    }
 }
 
-// gbias[n] = sum over the partial rows, rows ascending within a thread's strided subset, then a fixed LDS tree (one block per channel)
+// gbias[n] = sum over the blocks' partials of channel n (contiguous), ascending within a thread's strided subset, then a fixed LDS tree (one block per channel)
 __global__ __launch_bounds__(256) void conv1x1_bwd_bias_finish_kernel(float *__restrict__ gbias, const float *__restrict__ partial, int rows, int R)
 {
     __shared__ float s_acc[256];
     const int n = blockIdx.x;
     float s = 0.0f;
-    for (int j = threadIdx.x; j < rows; j += 256) s = s + partial[(long long)j * R + n];
+    for (int j = threadIdx.x; j < rows; j += 256) s = s + partial[(long long)n * rows + j];
     s_acc[threadIdx.x] = s;
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) {
@@ -445,7 +454,7 @@ int mdt_conv1x1_backward(const float *gy, const float *y, const float *w, float 
         else hipLaunchKernelGGL((conv1x1_bwd_mfma_kernel<36, 4, false>), dim3((unsigned)blocks), dim3(256), 0, s, g, gx, partial, gy, gy, w, n_voxels, c_in);
         if (c1_check() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
     }
-    hipLaunchKernelGGL(conv1x1_bwd_bias_finish_kernel, dim3((unsigned)c_out), dim3(256), 0, s, gbias, partial, (int)(blocks * 4), c_out);
+    hipLaunchKernelGGL(conv1x1_bwd_bias_finish_kernel, dim3((unsigned)c_out), dim3(256), 0, s, gbias, partial, (int)blocks, c_out);
     return c1_check();
 }
 

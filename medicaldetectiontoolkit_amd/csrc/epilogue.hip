@@ -92,7 +92,8 @@ __device__ __forceinline__ float load_partial(const float *p) { return __hip_ato
 // ---- backward, channels-last -----------------------------------------------------------------------------------
 // Thread t of a block owns channel slots; a block walks a contiguous range of pixels.  C < 256: ppb = 256 / C pixels are
 // processed side by side (thread t -> pixel lane t / C, channel t % C) and the lanes are folded in LDS in lane order;
-// C >= 256: thread t owns channels t, t + 256, ... of every pixel.  Per-block partials go to `partial[block][C]`.
+// C >= 256: thread t owns channels t, t + 256, ... of every pixel.  Per-block partials go to `partial[C][blocks]` (one contiguous run per channel: the second
+// stage's loads coalesce -- as `[block][C]` its 256 threads read 256 different rows, ~6 us per layer, ~55 layers per step); with a ticket: `partial[block][C]`.
 // ticket != null (round 6): the second stage runs INSIDE this launch -- every block publishes its partial row with write-through (sc1) stores,
 // draws a ticket, and the block that draws the last one folds all rows into gbias with sc1 loads (per-XCD L2s are not coherent: the sc1 / sc1
 // form of cdna_hip_programming.md 6 G16 / MI355X_MICROARCH.md "inter-workgroup visibility") and resets the ticket to 0 for the next launch.
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
         if (t < C) {
             float s = 0.0f;
             for (int l = 0; l < ppb; ++l) s = s + s_acc[l * C + t];     // fixed lane order
-            store_partial(partial + (long long)blockIdx.x * C + t, s, ticket != nullptr);
+            store_partial(ticket ? partial + (long long)blockIdx.x * C + t : partial + (long long)t * gridDim.x + blockIdx.x, s, ticket != nullptr);
         }
     } else {
         for (int k = 0; k < ktiles; ++k) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(EP_THREADS) void bias_act_bwd_cl_kernel(float *__re
                     if (RELU || gx != nullptr) gx[i] = g;
                     acc = acc + g;
                 }
-                store_partial(partial + (long long)blockIdx.x * C + c, acc, ticket != nullptr);
+                store_partial(ticket ? partial + (long long)blockIdx.x * C + c : partial + (long long)c * gridDim.x + blockIdx.x, acc, ticket != nullptr);
             }
         }
     }
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(EP_THREADS) void bias_grad_to_cl_kernel(float *__re
     if (t < C) {
         float sum = 0.0f;
         for (int l = 0; l < ppb; ++l) sum = sum + s_acc[l * C + t];
-        partial[(long long)blockIdx.x * C + t] = sum;
+        partial[(long long)t * gridDim.x + blockIdx.x] = sum;
     }
 }
 
@@ -334,9 +335,21 @@ __global__ __launch_bounds__(EP_THREADS) void bias_grad_finish_kernel(float *__r
     const int c = blockIdx.x;
     const long long total = groups * count;
     float s = 0.0f;
-    for (long long j = threadIdx.x; j < total; j += EP_THREADS) {
-        const long long g = j / count, k = j - g * count;
-        s = s + partial[g * stride_g + (long long)c * stride_c + k * stride_k];
+    if (groups == 1) {
+        // one group (channels-last layers: ~55 launches per training step): no index division, four independent loads in flight per thread; the
+        // order of a thread's additions is the order of the general loop below (j ascending)
+        const float *pc = partial + (long long)c * stride_c;
+        long long j = threadIdx.x;
+        for (; j + 3 * EP_THREADS < count; j += 4 * EP_THREADS) {
+            const float v0 = pc[j * stride_k], v1 = pc[(j + EP_THREADS) * stride_k], v2 = pc[(j + 2 * EP_THREADS) * stride_k], v3 = pc[(j + 3 * EP_THREADS) * stride_k];
+            s = s + v0; s = s + v1; s = s + v2; s = s + v3;
+        }
+        for (; j < count; j += EP_THREADS) s = s + pc[j * stride_k];
+    } else {
+        for (long long j = threadIdx.x; j < total; j += EP_THREADS) {
+            const long long g = j / count, k = j - g * count;
+            s = s + partial[g * stride_g + (long long)c * stride_c + k * stride_k];
+        }
     }
     s_acc[threadIdx.x] = s;
     __syncthreads();
@@ -535,8 +548,8 @@ static int bias_act_backward_impl(float *gx, const float *gy, const float *y, fl
         else hipLaunchKernelGGL(bias_act_bwd_cl_kernel<false>, dim3((unsigned)blocks), dim3(EP_THREADS), 0, s, gx, gy, y, partial, npix, channels, ppb, ktiles, ppblock, ticket, gbias);
         if (ep_check() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
         if (ticket) return MDT_OK;            // the last block of the launch has written gbias
-        // partial[block][c]: channel stride 1, block stride C
-        hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(fin_blocks), dim3(EP_THREADS), 0, s, gbias, partial, channels, blocks, 1LL, (long long)channels, 1LL, 0LL);
+        // partial[c][block]: channel stride blocks, block stride 1
+        hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(fin_blocks), dim3(EP_THREADS), 0, s, gbias, partial, channels, blocks, blocks, 1LL, 1LL, 0LL);
         return ep_check();
     }
     const long long rows = n / inner;                       // batch * C
@@ -605,7 +618,7 @@ int mdt_bias_grad_to_channels_last(float *gx, const float *gy, float *gbias, int
                            (int)tiles);
         if (ep_check() != MDT_OK) return MDT_ERR_LAUNCH_FAILED;
     }
-    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(channels), dim3(EP_THREADS), 0, s, gbias, partial, channels, blocks, 1LL, (long long)channels, 1LL, 0LL);
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(channels), dim3(EP_THREADS), 0, s, gbias, partial, channels, blocks, blocks, 1LL, 1LL, 0LL);
     return ep_check();
 }
 

@@ -28,7 +28,7 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for (B, C, Co, Y, X, Z) in [(8, 18, 18, 32, 32, 128), (8, 18, 18, 128, 128, 128), (8, 36, 36, 32, 32, 128), (8, 36, 18, 64, 64, 128)]:
+for (B, C, Co, Y, X, Z) in [(8, 18, 18, 32, 32, 128), (8, 18, 18, 128, 128, 128), (8, 36, 36, 32, 32, 128), (8, 36, 18, 64, 64, 128), (8, 36, 32, 32, 32, 128), (8, 36, 18, 32, 32, 128), (8, 36, 32, 16, 16, 64)]:
     x = torch.randn(B, C, Y, X, Z, device=dev).contiguous(memory_format=torch.channels_last_3d)
     w = torch.randn(Co, C, 3, 3, 3, device=dev) * 0.1
     wt = w.permute(2, 3, 4, 1, 0).contiguous()
