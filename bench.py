@@ -627,6 +627,7 @@ def main():
     ap.add_argument("--conv1x1-bwd", type=int, default=1, help="1 (default): ReLU mask + bias gradient + input gradient of conv3 in the C2 blocks in one pass (mdt_conv1x1_backward); 0: epilogue kernel + CK (A/B)")
     ap.add_argument("--rpn-heads-fused", type=int, default=1, help="1 (default): the dense RPN forward runs both heads on the raw conv_shared output in one launch per level (mdt_rpn_heads_forward); 0: per-level modules + torch.cat (A/B)")
     ap.add_argument("--stem-pool-fused", type=int, default=1, help="1 (default): stem + bias + ReLU + max pooling as one autograd node, ReLU mask / bias gradient at the pooled resolution; 0: two nodes (A/B)")
+    ap.add_argument("--conv-c0", type=int, default=1, help="1 (default): the one-channel 3x3x3 first layer of the stride-1 backbone (Retina U-Net C0[0]) on this repo's kernels (csrc/conv_c0.hip); 0: MIOpen + layout conversions (A/B)")
     ap.add_argument("--bias-bwd-no-copy", type=int, default=1, help="1 (default): bias-only layers' backward returns the output gradient itself; 0: stores a copy (A/B)")
     ap.add_argument("--bias-grad-transpose", type=int, default=1, help="1 (default): row-major output gradients of channels-last bias-only layers converted + reduced in one pass (A/B)")
     ap.add_argument("--lateral-upsample-fused", type=int, default=1, help="1 (default): the FPN's top-down add reads the coarser map directly; 0: materialised up-sampling (A/B)")
@@ -721,6 +722,7 @@ def main():
     fused_epilogue.FLIP_BATCHED = bool(args.flip_batched)
     fused_epilogue.BIAS_BWD_NO_COPY = bool(args.bias_bwd_no_copy)
     fused_epilogue.CONV1X1_FWD = bool(args.conv1x1_fwd)
+    fused_epilogue.CONV_C0 = bool(args.conv_c0)
     fused_epilogue.STEM_POOL_FUSED = bool(args.stem_pool_fused)
     fused_epilogue.CONV1X1_BWD = bool(args.conv1x1_bwd)
     fused_epilogue.BIAS_GRAD_TRANSPOSE = bool(args.bias_grad_transpose)

@@ -529,6 +529,21 @@ int mdt_rpn_heads_forward_supported(int hidden, int n_class, int n_box);
 int mdt_rpn_heads_forward(const float *h, const float *bias_shared, const float *w, const float *bias, float *logits, float *deltas, int batch,
                           long long voxels_per_element, int hidden, int n_class, int n_box, long long anchors_total, long long anchor_offset, void *stream);
 
+/*
+ * The first layer of the stride-1 backbone (models/backbone.py:60-63 with operate_stride1 -- the Retina U-Net: C0[0] = conv(1 -> 18, ks 3, pad 1) + ReLU on the
+ * full-resolution one-channel volume), csrc/conv_c0.hip.  x: [batch][Y][X][Z] fp32, w: [18][27] (the module's filter, dense), y: [batch][Y][X][Z][18]
+ * (channels-last -- what the next layer reads; the library path produces it row-major and converts).
+ *   forward:  y = act(conv(x) + bias)
+ *   backward: grad_weight [18][27] and grad_bias [18] (may be NULL) from gy and the forward output y (the ReLU mask; y may be NULL when relu == 0), one pass,
+ *             fp32 MFMA, fixed summation order.  The input (the image) has no gradient.
+ * c_in == 1, c_out == 18, k == 3, Z % 32 == 0 (mdt_conv_c0_supported); everything else: the caller keeps MIOpen.
+ */
+int mdt_conv_c0_supported(int c_in, int c_out, int k, int Z);
+int mdt_conv_c0_forward(const float *x, const float *w, const float *bias, int relu, float *y, int batch, int Y, int X, int Z, int c_out, void *stream);
+size_t mdt_conv_c0_wgrad_workspace_bytes(int batch, int Y, int X, int Z);
+int mdt_conv_c0_backward(const float *gy, const float *y, const float *x, int relu, float *grad_weight, float *grad_bias, int batch, int Y, int X, int Z,
+                         int c_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- input gradient of a 1x1(x1) convolution added to another gradient of the same tensor (csrc/epilogue.hip, round 4) ------------------
  * out[v][ci] = res[v][ci] + sum_co gy[v][co] * w[co][ci] over n_voxels channels-last rows (res may be NULL: plain input gradient).
  * What autograd does in two steps for a ResBlock input (models/backbone.py:197-205: x feeds conv1 and the residual add): the

@@ -152,7 +152,7 @@ class FPN(nn.Module):
             # channels-last net -- and C0[1] (18 -> 18 on the full-resolution volume, the most expensive layer of the Retina U-Net step)
             # then misses this repo's few-channel MFMA kernel (channels-last only) and runs on MIOpen's row-major path at 7 TF/s
             # (39.6 ms forward, 57.9 + 45.8 ms backward at 8 x 128^3; profiles/r04/r04_step_launch_by_launch_retina_unet.txt)
-            h = self.C0[0](x)
+            h = fused_epilogue.conv_c0_bias_relu(self.C0[0], x) if fused_epilogue.conv_c0_applies(self.C0[0], x) else self.C0[0](x)
             w1 = self.C0[1][0].weight if isinstance(self.C0[1], nn.Sequential) else self.C0[1].weight
             mf = torch.channels_last_3d if h.dim() == 5 else torch.channels_last
             if w1.is_contiguous(memory_format=mf) and not w1.is_contiguous() and not h.is_contiguous(memory_format=mf):

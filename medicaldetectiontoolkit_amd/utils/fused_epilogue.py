@@ -938,6 +938,69 @@ class _ConvStemBiasReLU(Function):
         return (gx if ctx.needs_input_grad[0] else None), (gw if ctx.needs_input_grad[1] else None), gbias
 
 
+CONV_C0 = True   # module switch (A/B: bench.py --conv-c0 0): the one-channel 3x3x3 first layer of the stride-1 backbone on this repo's kernels (csrc/conv_c0.hip)
+
+
+class _ConvC0BiasReLU(Function):
+    """relu(conv3x3x3(x, w) + bias) for a ONE-channel volume, output in channels-last storage (models/backbone.py:60-63: C0[0] of the Retina U-Net).  The
+    library runs this layer row-major (a one-channel tensor is contiguous in both layouts) between layout transposes, and the next layer needs a
+    channels-last copy of the 2.4 GB result; the backward pays the same conversions again.  Forward: mdt_conv_c0_forward; backward: weight and bias
+    gradient from ONE pass over gy and y (mdt_conv_c0_backward).  The input has no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, relu):
+        B, _, Y, X, Z = x.shape
+        co = int(w.shape[0])
+        xc = x.detach().contiguous()
+        y = torch.empty((B, co, Y, X, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+        wd = w.detach().reshape(co, 27)
+        if not wd.is_contiguous():
+            wd = wd.contiguous()
+        rc = _lib.lib().mdt_conv_c0_forward(xc.data_ptr(), wd.data_ptr(), bias.detach().data_ptr() if bias is not None else None, 1 if relu else 0, y.data_ptr(),
+                                            B, Y, X, Z, co, _lib.raw_stream())
+        if rc != 0:
+            _lib.check(rc, "mdt_conv_c0_forward")
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        ctx.w_shape = tuple(w.shape)
+        ctx.save_for_backward(xc, y) if relu else ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc = ctx.saved_tensors[0]
+        y = ctx.saved_tensors[1] if ctx.relu else None
+        mf = torch.channels_last_3d
+        if not gy.is_contiguous(memory_format=mf):
+            gy = gy.contiguous(memory_format=mf)
+        B, co, Y, X, Z = gy.shape
+        L = _lib.lib()
+        gw = torch.empty((co, 27), dtype=torch.float32, device=gy.device)
+        gb = torch.empty(co, dtype=torch.float32, device=gy.device)
+        ws = _workspace(L.mdt_conv_c0_wgrad_workspace_bytes(B, Y, X, Z), gy.device)
+        rc = L.mdt_conv_c0_backward(gy.data_ptr(), y.data_ptr() if y is not None else None, xc.data_ptr(), 1 if ctx.relu else 0, gw.data_ptr(), gb.data_ptr(), B, Y, X, Z, co,
+                                    ws.data_ptr(), ws.numel(), _lib.raw_stream())
+        if rc != 0:
+            _lib.check(rc, "mdt_conv_c0_backward")
+        return None, gw.view(ctx.w_shape), (gb if ctx.has_bias else None), None
+
+
+def conv_c0_applies(seq, x):
+    """seq: the ConvBiasReLU Sequential of a one-channel 3x3x3 unit-stride layer; x: its fp32 GPU input [B, 1, Y, X, Z] that needs no gradient"""
+    if not (ENABLED and CONV_C0 and isinstance(seq, ConvBiasReLU) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and not x.requires_grad
+            and not torch.is_autocast_enabled() and _on_current_device(x)):
+        return False
+    conv = seq[0]
+    if not (isinstance(conv, nn.Conv3d) and conv.groups == 1 and _unit(conv.stride) and _unit(conv.dilation) and not isinstance(conv.padding, str)
+            and tuple(int(k) for k in conv.kernel_size) == (3, 3, 3) and tuple(int(v) for v in conv.padding) == (1, 1, 1) and conv.weight.dtype == torch.float32):
+        return False
+    return bool(_lib.lib().mdt_conv_c0_supported(int(conv.in_channels), int(conv.out_channels), 3, int(x.shape[4])))
+
+
+def conv_c0_bias_relu(seq, x):
+    conv = seq[0]
+    return _ConvC0BiasReLU.apply(x, conv.weight, conv.bias, True)
+
+
 STEM_POOL_FUSED = True   # module switch (A/B: bench.py --stem-pool-fused 0)
 
 
