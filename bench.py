@@ -628,6 +628,7 @@ def main():
     ap.add_argument("--rpn-heads-fused", type=int, default=1, help="1 (default): the dense RPN forward runs both heads on the raw conv_shared output in one launch per level (mdt_rpn_heads_forward); 0: per-level modules + torch.cat (A/B)")
     ap.add_argument("--stem-pool-fused", type=int, default=1, help="1 (default): stem + bias + ReLU + max pooling as one autograd node, ReLU mask / bias gradient at the pooled resolution; 0: two nodes (A/B)")
     ap.add_argument("--conv-c0", type=int, default=1, help="1 (default): the one-channel 3x3x3 first layer of the stride-1 backbone (Retina U-Net C0[0]) on this repo's kernels (csrc/conv_c0.hip); 0: MIOpen + layout conversions (A/B)")
+    ap.add_argument("--seg-head-composed", type=int, default=1, help="1 (default): the Retina U-Net's final_conv o P0_conv2 as one 36 -> 2 3x3x3 layer on csrc/conv_seg.hip; 0: the two layers as they are (A/B)")
     ap.add_argument("--bias-bwd-no-copy", type=int, default=1, help="1 (default): bias-only layers' backward returns the output gradient itself; 0: stores a copy (A/B)")
     ap.add_argument("--bias-grad-transpose", type=int, default=1, help="1 (default): row-major output gradients of channels-last bias-only layers converted + reduced in one pass (A/B)")
     ap.add_argument("--lateral-upsample-fused", type=int, default=1, help="1 (default): the FPN's top-down add reads the coarser map directly; 0: materialised up-sampling (A/B)")
@@ -722,6 +723,7 @@ def main():
     fused_epilogue.FLIP_BATCHED = bool(args.flip_batched)
     fused_epilogue.BIAS_BWD_NO_COPY = bool(args.bias_bwd_no_copy)
     fused_epilogue.CONV1X1_FWD = bool(args.conv1x1_fwd)
+    fused_epilogue.SEG_HEAD_COMPOSED = bool(args.seg_head_composed)
     fused_epilogue.CONV_C0 = bool(args.conv_c0)
     fused_epilogue.STEM_POOL_FUSED = bool(args.stem_pool_fused)
     fused_epilogue.CONV1X1_BWD = bool(args.conv1x1_bwd)

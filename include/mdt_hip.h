@@ -544,6 +544,23 @@ size_t mdt_conv_c0_wgrad_workspace_bytes(int batch, int Y, int X, int Z);
 int mdt_conv_c0_backward(const float *gy, const float *y, const float *x, int relu, float *grad_weight, float *grad_bias, int batch, int Y, int X, int Z,
                          int c_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * 3x3x3 convolution (stride 1, padding 1) between a 36-channel and a 2-channel full-resolution map, channels-last fp32 (csrc/conv_seg.hip): the Retina U-Net's
+ * segmentation branch  final_conv(P0_conv2(p0))  (models/retina_unet.py:483-486, models/backbone.py:160-176) as ONE layer -- P0_conv2 has no activation and no
+ * other reader, so the two linear layers compose: W'[s][ci][tap] = sum_co Wf[s][co] W2[co][ci][tap], b' = Wf b2 + bf (the caller composes them with
+ * differentiable tensor ops and hands W' here in the layouts below).
+ *   forward:     y[v][s] = b[s] + sum x[v + tap][ci] wt[tap][ci][s]                wt = W'.permute(2, 3, 4, 1, 0) contiguous ([27][36][2])
+ *   input grad:  gx[v][ci] = sum g[v + tap][s] wd[tap][s][ci]                      wd = flip(W', taps).permute(2, 3, 4, 0, 1) contiguous ([27][2][36])
+ *   weight grad: grad_weight[s][ci][tap], grad_bias[s] (may be NULL) from g and x; fp32 MFMA, fixed summation order
+ * c_big == 36, c_small == 2, Y % 2 == 0, X % 4 == 0, Z % 32 == 0 (mdt_conv_seg_supported).
+ */
+int mdt_conv_seg_supported(int c_big, int c_small, int Y, int X, int Z);
+int mdt_conv_seg_forward(const float *x, const float *wt, const float *bias, float *y, int batch, int Y, int X, int Z, int c_big, int c_small, void *stream);
+int mdt_conv_seg_input_grad(const float *g, const float *wd, float *gx, int batch, int Y, int X, int Z, int c_big, int c_small, void *stream);
+size_t mdt_conv_seg_wgrad_workspace_bytes(int batch, int Y, int X, int Z);
+int mdt_conv_seg_weight_grad(const float *g, const float *x, float *grad_weight, float *grad_bias, int batch, int Y, int X, int Z, int c_big, int c_small,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- input gradient of a 1x1(x1) convolution added to another gradient of the same tensor (csrc/epilogue.hip, round 4) ------------------
  * out[v][ci] = res[v][ci] + sum_co gy[v][co] * w[co][ci] over n_voxels channels-last rows (res may be NULL: plain input gradient).
  * What autograd does in two steps for a ResBlock input (models/backbone.py:197-205: x feeds conv1 and the residual add): the

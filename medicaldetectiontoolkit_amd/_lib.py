@@ -89,6 +89,11 @@ _SIGNATURES = {
     "mdt_conv_c0_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mdt_conv_c0_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mdt_conv_c0_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "mdt_conv_seg_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "mdt_conv_seg_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdt_conv_seg_input_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdt_conv_seg_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mdt_conv_seg_weight_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "mdt_rpn_heads_forward_supported": (c_int, [c_int, c_int, c_int]),
     "mdt_rpn_heads_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
     "mdt_bias_act_forward_upsampled_supported": (c_int, [c_int, c_longlong]),

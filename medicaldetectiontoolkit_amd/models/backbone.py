@@ -188,5 +188,7 @@ class FPN(nn.Module):
         if self.operate_stride1:
             p1_pre_out = _lateral(self.P1_conv1, c1_out, self.P2_upsample(p2_pre_out))
             p0_pre_out = _lateral(self.P0_conv1, c0_out, self.P1_upsample(p1_pre_out))
-            out_list = [self.P0_conv2(p0_pre_out)] + out_list
+            # defer_p0_conv2 (set per call by the Retina U-Net): the caller composes P0_conv2 with its segmentation layer (fused_epilogue.seg_head_composed)
+            # and wants P0_conv2's INPUT in the first slot
+            out_list = [p0_pre_out if getattr(self, "defer_p0_conv2", False) else self.P0_conv2(p0_pre_out)] + out_list
         return out_list

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..cuda_functions import _nms_impl
+from ..utils import fused_epilogue
 from ..utils import model_utils as mutils
 from . import backbone as backbone_module
 from .mrcnn import GtOnDevice, compute_rpn_losses
@@ -179,9 +180,22 @@ class net(nn.Module):
         """retina_unet.py:477-513."""
         if self.memory_format is not None:
             img = img.contiguous(memory_format=self.memory_format)
-        fpn_outs = self.Fpn(img)
+        # retina_unet: fpn_outs[0] (P0_conv2's output) is read by final_conv only, and neither layer has an activation: the two are composed into one
+        # 36 -> 2 3x3x3 layer where csrc/conv_seg.hip serves the shape (the 36 -> 36 layer on the full-resolution map is 58 ms of the step at 8 x 128^3)
+        compose = self.cf.model == "retina_unet" and self.cf.operate_stride1 and fused_epilogue.SEG_HEAD_COMPOSED \
+            and getattr(self.Fpn, "P0_conv2", None) is not None and self._seg_compose_ok(img)
+        self.Fpn.defer_p0_conv2 = bool(compose)
+        try:
+            fpn_outs = self.Fpn(img)
+        finally:
+            self.Fpn.defer_p0_conv2 = False
         off = 1 if self.cf.operate_stride1 else 0
-        seg_logits = self.final_conv(fpn_outs[0]) if self.cf.model == "retina_unet" else None
+        if compose and fused_epilogue.seg_head_composed_applies(self.Fpn.P0_conv2, self.final_conv, fpn_outs[0]):
+            seg_logits = fused_epilogue.seg_head_composed(self.Fpn.P0_conv2, self.final_conv, fpn_outs[0])
+        elif compose:
+            seg_logits = self.final_conv(self.Fpn.P0_conv2(fpn_outs[0]))
+        else:
+            seg_logits = self.final_conv(fpn_outs[0]) if self.cf.model == "retina_unet" else None
         selected = [fpn_outs[i + off] for i in self.cf.pyramid_levels]
         class_logits = torch.cat([self.Classifier(p)[0] for p in selected], dim=1)
         bb_outputs = torch.cat([self.BBRegressor(p)[0] for p in selected], dim=1)
@@ -190,6 +204,15 @@ class net(nn.Module):
         flat_bb_outputs = bb_outputs.detach().view(-1, bb_outputs.shape[-1])
         detections, det_valid = refine_detections(self.anchors, flat_class_softmax, flat_bb_outputs, B, self.cf)
         return detections, det_valid, class_logits, bb_outputs, seg_logits
+
+    def _seg_compose_ok(self, img):
+        """cheap pre-check (before the FPN runs) that the composed segmentation layer can apply: fp32 GPU input, supported full-resolution shape"""
+        from .. import _lib
+        if not (img.is_cuda and img.dtype == torch.float32 and img.dim() == 5 and not torch.is_autocast_enabled()):
+            return False
+        c2 = self.Fpn.P0_conv2
+        return isinstance(c2, fused_epilogue.ConvBias) and isinstance(self.final_conv, fused_epilogue.ConvBias) and bool(
+            _lib.lib().mdt_conv_seg_supported(int(c2.in_channels), int(self.final_conv.out_channels), int(img.shape[2]), int(img.shape[3]), int(img.shape[4])))
 
     # ------------------------------------------------------------------ which parameters have a gradient only under a condition of the step
     def grad_condition_spec(self):

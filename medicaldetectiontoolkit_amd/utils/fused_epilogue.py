@@ -1001,6 +1001,79 @@ def conv_c0_bias_relu(seq, x):
     return _ConvC0BiasReLU.apply(x, conv.weight, conv.bias, True)
 
 
+SEG_HEAD_COMPOSED = True   # module switch (A/B: bench.py --seg-head-composed 0): final_conv o P0_conv2 of the Retina U-Net as one 36 -> 2 3x3x3 layer (csrc/conv_seg.hip)
+
+
+class _ConvSeg(Function):
+    """y = conv3x3x3(x, w) + bias for a 36-channel channels-last map and a two-channel result (csrc/conv_seg.hip): forward, input gradient and weight / bias
+    gradient on this repo's kernels (VALU forward / input gradient, fp32-MFMA weight gradient).  w: [2, 36, 3, 3, 3] (a composed filter: a non-leaf)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        B, C, Y, X, Z = x.shape
+        S = int(w.shape[0])
+        wd = w.detach()
+        wt = wd.permute(2, 3, 4, 1, 0).contiguous()                      # [27][36][2]
+        y = torch.empty((B, S, Y, X, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
+        bd = bias.detach().contiguous()
+        rc = _lib.lib().mdt_conv_seg_forward(x.data_ptr(), wt.data_ptr(), bd.data_ptr(), y.data_ptr(), B, Y, X, Z, C, S, _lib.raw_stream())
+        if rc != 0:
+            _lib.check(rc, "mdt_conv_seg_forward")
+        ctx.save_for_backward(x, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wd = ctx.saved_tensors
+        B, C, Y, X, Z = x.shape
+        S = int(wd.shape[0])
+        mf = torch.channels_last_3d
+        if not gy.is_contiguous(memory_format=mf):
+            gy = gy.contiguous(memory_format=mf)
+        L = _lib.lib()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wflip = wd.flip(2, 3, 4).permute(2, 3, 4, 0, 1).contiguous()   # [27][2][36], taps mirrored
+            gx = torch.empty_like(x)
+            rc = L.mdt_conv_seg_input_grad(gy.data_ptr(), wflip.data_ptr(), gx.data_ptr(), B, Y, X, Z, C, S, _lib.raw_stream())
+            if rc != 0:
+                _lib.check(rc, "mdt_conv_seg_input_grad")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gw = torch.empty((S, C, 3, 3, 3), dtype=torch.float32, device=x.device)
+            gb = torch.empty(S, dtype=torch.float32, device=x.device)
+            ws = _workspace(L.mdt_conv_seg_wgrad_workspace_bytes(B, Y, X, Z), x.device)
+            rc = L.mdt_conv_seg_weight_grad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, Y, X, Z, C, S, ws.data_ptr(), ws.numel(), _lib.raw_stream())
+            if rc != 0:
+                _lib.check(rc, "mdt_conv_seg_weight_grad")
+        return gx, gw, gb
+
+
+def seg_head_composed_applies(conv2, final_conv, x):
+    """conv2: the 3x3x3 bias-only layer (P0_conv2), final_conv: the 1x1x1 bias-only layer behind it, x: conv2's input -- channels-last fp32 on this GPU, shapes
+    of csrc/conv_seg.hip"""
+    if not (ENABLED and SEG_HEAD_COMPOSED and isinstance(conv2, ConvBias) and isinstance(final_conv, ConvBias) and isinstance(conv2, nn.Conv3d)
+            and isinstance(final_conv, nn.Conv3d) and conv2.bias is not None and final_conv.bias is not None and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == 5 and not torch.is_autocast_enabled() and _on_current_device(x)):
+        return False
+    if not (tuple(int(k) for k in conv2.kernel_size) == (3, 3, 3) and tuple(int(v) for v in conv2.padding) == (1, 1, 1) and _unit(conv2.stride) and _unit(conv2.dilation)
+            and conv2.groups == 1 and all(int(k) == 1 for k in final_conv.kernel_size) and _unit(final_conv.stride) and final_conv.groups == 1
+            and not any(int(v) for v in final_conv.padding) and int(final_conv.in_channels) == int(conv2.out_channels)):
+        return False
+    if not (x.is_contiguous(memory_format=torch.channels_last_3d) and not x.is_contiguous() and x.data_ptr() % 16 == 0):
+        return False
+    return bool(_lib.lib().mdt_conv_seg_supported(int(conv2.in_channels), int(final_conv.out_channels), int(x.shape[2]), int(x.shape[3]), int(x.shape[4])))
+
+
+def seg_head_composed(conv2, final_conv, x):
+    """final_conv(conv2(x)) as ONE convolution: the two layers are linear with nothing between them, so W' = Wf . W2 and b' = Wf b2 + bf (built from the modules'
+    parameters with differentiable ops: autograd splits the composed filter's gradient between them)"""
+    S, Cm = int(final_conv.out_channels), int(conv2.out_channels)
+    wf = final_conv.weight.reshape(S, Cm)
+    w = (wf @ conv2.weight.reshape(Cm, -1)).reshape(S, int(conv2.in_channels), 3, 3, 3)
+    b = wf @ conv2.bias + final_conv.bias
+    return _ConvSeg.apply(x, w, b)
+
+
 STEM_POOL_FUSED = True   # module switch (A/B: bench.py --stem-pool-fused 0)
 
 

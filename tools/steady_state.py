@@ -14,7 +14,7 @@ def category(n):
             or "maxpool_k3" in n or "filter_flip" in n or "match_pass" in n or "upsample2x_" in n or "zero_fill_kernel" in n or "nms2to3d" in n or "adam_flat" in n or "adam_segments" in n or "s2d221_" in n \
             or "roi_levels" in n or "rpn_sample" in n or "detection_targets" in n or "refine_pre" in n or "refine_post" in n or "refine_fallback" in n or "rpn_patch" in n:
         return "mdt_hip (this repo)"
-    if "conv1x1_wgrad" in n or "conv1x1_fwd" in n or "conv_c0" in n or "conv1x1_bwd" in n or "rpn_heads" in n or "conv3x3x3_small" in n or "conv_stem_wgrad" in n or "conv_stem_fwd" in n or "conv1x1_dgrad_add" in n or "conv_s221_wgrad" in n \
+    if "conv1x1_wgrad" in n or "conv1x1_fwd" in n or "conv_c0" in n or "conv_seg" in n or "conv1x1_bwd" in n or "rpn_heads" in n or "conv3x3x3_small" in n or "conv_stem_wgrad" in n or "conv_stem_fwd" in n or "conv1x1_dgrad_add" in n or "conv_s221_wgrad" in n \
             or "conv_s221_fwd" in n or "conv_s221_dgrad" in n:
         return "mdt_hip convolution kernels (this repo, fp32 MFMA)"
     if n.startswith("_ZN2ck") or "ck::" in n or "miopen" in n.lower() or "Cijk" in n or "gemm" in n.lower() or "batched_transpose" in n \
