@@ -169,6 +169,9 @@ def test_retina_unet_large_step_matches_reference_with_mfma_conv_kernels_dispatc
     # (round 6, later: forward and input gradient of the layer run on own fp32-MFMA kernels too -- the space-to-depth plumbing is only reached outside their budgets)
     for name in (("mdt_conv_s221_forward", "mdt_conv_s221_input_grad", "mdt_conv_s221_wgrad") if case == "bench" else ()):
         assert _ncalls(calls, name) >= 1, (name, {k: v for k, v in calls.items() if "s2" in k or "conv" in k})
+    # round 6, late: the one-channel first layer and the composed segmentation layer (final_conv o P0_conv2) run on csrc/conv_c0.hip / conv_seg.hip
+    for name in ("mdt_conv_c0_forward", "mdt_conv_c0_backward", "mdt_conv_seg_forward", "mdt_conv_seg_input_grad", "mdt_conv_seg_weight_grad"):
+        assert _ncalls(calls, name) >= 1, (name, {k: v for k, v in calls.items() if "conv" in k})
     terms = {k: float(v) for k, v in res["loss_terms"].items()}
     for k in ("class", "bbox", "seg_dice", "seg_ce"):
         _close(terms[k], float(gold["retina_term_" + k]), 1e-4, "retina[%s] %s" % (case, k))
