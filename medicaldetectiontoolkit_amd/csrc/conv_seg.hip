@@ -40,7 +40,9 @@ constexpr int SF_TY = 2, SF_TX = 4, SF_TZ = 16;
 constexpr int SF_LY = SF_TY + 2, SF_LX = SF_TX + 2, SF_LZ = SF_TZ + 2;
 constexpr int SF_VOX = SF_TY * SF_TX * SF_TZ;          // 128 voxels per workgroup
 constexpr int SF_GROUPS = 3, SF_GC = SG_C / SF_GROUPS;  // three groups of 12 channels
-constexpr int SF_THREADS = SF_VOX * SF_GROUPS;          // 384
+constexpr int SF_VPT = 2;                               // voxels per thread (z and z + 8): the wave-uniform filter values are fetched once for both
+constexpr int SF_TPG = SF_VOX / SF_VPT;                 // threads per channel group: 64 = one wave
+constexpr int SF_THREADS = SF_TPG * SF_GROUPS;          // 192
 
 __global__ __launch_bounds__(SF_THREADS) void conv_seg_fwd_kernel(float *__restrict__ y, const float *__restrict__ x, const float *__restrict__ wt,
                                                                   const float *__restrict__ bias, int Y, int X, int Z, int ty_n, int tx_n, int tz_n)
@@ -66,31 +68,42 @@ __global__ __launch_bounds__(SF_THREADS) void conv_seg_fwd_kernel(float *__restr
         *reinterpret_cast<v4f *>(img + (line * SF_LZ) * SG_C + piece * 4) = v;
     }
     __syncthreads();
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / SF_VOX);      // wave-uniform: 128 voxels = two waves per group
-    const int vl = threadIdx.x - grp * SF_VOX;
-    const int lz = vl % SF_TZ, lx = (vl / SF_TZ) % SF_TX, ly = vl / (SF_TZ * SF_TX);
-    float acc0 = 0.0f, acc1 = 0.0f;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / SF_TPG);      // wave-uniform: one wave per channel group
+    const int tl = threadIdx.x - grp * SF_TPG;
+    const int lz = tl % (SF_TZ / SF_VPT), lx = (tl / (SF_TZ / SF_VPT)) % SF_TX, ly = tl / ((SF_TZ / SF_VPT) * SF_TX);
+    float acc[SF_VPT][SG_S];
+#pragma unroll
+    for (int u = 0; u < SF_VPT; ++u) { acc[u][0] = 0.0f; acc[u][1] = 0.0f; }
     const float *wg = wt + grp * SF_GC * SG_S;
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
         const int dz = tap % 3, dx = (tap / 3) % 3, dy = tap / 9;              // (offsets + 1: the image starts one voxel before the tile)
-        const float *src = img + (((ly + dy) * SF_LX + (lx + dx)) * SF_LZ + (lz + dz)) * SG_C + grp * SF_GC;
-        const v4f a0 = *reinterpret_cast<const v4f *>(src), a1 = *reinterpret_cast<const v4f *>(src + 4), a2 = *reinterpret_cast<const v4f *>(src + 8);
-        const float xs[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
         const float *wp = wg + tap * SG_C * SG_S;
 #pragma unroll
-        for (int c = 0; c < SF_GC; ++c) {
-            acc0 = acc0 + xs[c] * wp[c * SG_S];
-            acc1 = acc1 + xs[c] * wp[c * SG_S + 1];
+        for (int u = 0; u < SF_VPT; ++u) {
+            const float *src = img + (((ly + dy) * SF_LX + (lx + dx)) * SF_LZ + (lz + u * (SF_TZ / SF_VPT) + dz)) * SG_C + grp * SF_GC;
+            const v4f a0 = *reinterpret_cast<const v4f *>(src), a1 = *reinterpret_cast<const v4f *>(src + 4), a2 = *reinterpret_cast<const v4f *>(src + 8);
+            const float xs[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+            for (int c = 0; c < SF_GC; ++c) {
+                acc[u][0] = acc[u][0] + xs[c] * wp[c * SG_S];
+                acc[u][1] = acc[u][1] + xs[c] * wp[c * SG_S + 1];
+            }
         }
     }
-    red[grp][vl][0] = acc0;
-    red[grp][vl][1] = acc1;
+#pragma unroll
+    for (int u = 0; u < SF_VPT; ++u) {
+        const int vl = (ly * SF_TX + lx) * SF_TZ + lz + u * (SF_TZ / SF_VPT);
+        red[grp][vl][0] = acc[u][0];
+        red[grp][vl][1] = acc[u][1];
+    }
     __syncthreads();
     if (threadIdx.x < SF_VOX) {
+        const int vl = threadIdx.x;
+        const int vz = vl % SF_TZ, vx = (vl / SF_TZ) % SF_TX, vy = vl / (SF_TZ * SF_TX);
         const float r0 = ((red[0][vl][0] + red[1][vl][0]) + red[2][vl][0]) + (bias ? bias[0] : 0.0f);
         const float r1 = ((red[0][vl][1] + red[1][vl][1]) + red[2][vl][1]) + (bias ? bias[1] : 0.0f);
-        const long long v = (((long long)b * Y + (y0 + ly)) * X + (x0 + lx)) * Z + (z0 + lz);
+        const long long v = (((long long)b * Y + (y0 + vy)) * X + (x0 + vx)) * Z + (z0 + vz);
         *reinterpret_cast<float2 *>(y + v * SG_S) = float2{r0, r1};
     }
 }
