@@ -531,10 +531,10 @@ int mdt_rpn_heads_forward(const float *h, const float *bias_shared, const float 
 
 /*
  * The first layer of the stride-1 backbone (models/backbone.py:60-63 with operate_stride1 -- the Retina U-Net: C0[0] = conv(1 -> 18, ks 3, pad 1) + ReLU on the
- * full-resolution one-channel volume), csrc/conv_c0.hip.  x: [batch][Y][X][Z] fp32, w: [18][27] (the module's filter, dense), y: [batch][Y][X][Z][18]
+ * full-resolution one-channel volume), csrc/conv_c0.hip.  x: [batch][Y][X][Z] fp32, w: the filter as [27][18] for the forward (taps outermost: the module's [18][1][3][3][3] filter transposed), y: [batch][Y][X][Z][18]
  * (channels-last -- what the next layer reads; the library path produces it row-major and converts).
  *   forward:  y = act(conv(x) + bias)
- *   backward: grad_weight [18][27] and grad_bias [18] (may be NULL) from gy and the forward output y (the ReLU mask; y may be NULL when relu == 0), one pass,
+ *   backward: grad_weight [18][27] (the module's layout) and grad_bias [18] (may be NULL) from gy and the forward output y (the ReLU mask; y may be NULL when relu == 0), one pass,
  *             fp32 MFMA, fixed summation order.  The input (the image) has no gradient.
  * c_in == 1, c_out == 18, k == 3, Z % 32 == 0 (mdt_conv_c0_supported); everything else: the caller keeps MIOpen.
  */

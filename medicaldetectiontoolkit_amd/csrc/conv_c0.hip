@@ -35,14 +35,10 @@ constexpr int C0_CO = 18;
 constexpr int C0_THREADS = 256;
 
 // ---- forward ------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(C0_THREADS) void conv_c0_fwd_kernel(float *__restrict__ y, const float *__restrict__ x, const float *__restrict__ w,
+__global__ __launch_bounds__(C0_THREADS) void conv_c0_fwd_kernel(float *__restrict__ y, const float *__restrict__ x, const float *__restrict__ wt,
                                                                  const float *__restrict__ bias, int relu, int Y, int X, int Z, long long V)
 {
-    __shared__ float s_w[27 * C0_CO + C0_CO];                                 // [tap][co], then bias
     __shared__ __attribute__((aligned(16))) float s_t[C0_THREADS * C0_CO];      // the block's output tile
-    for (int e = threadIdx.x; e < 27 * C0_CO; e += C0_THREADS) { const int tap = e / C0_CO, co = e - tap * C0_CO; s_w[e] = w[co * 27 + tap]; }
-    if (threadIdx.x < C0_CO) s_w[27 * C0_CO + threadIdx.x] = bias ? bias[threadIdx.x] : 0.0f;
-    __syncthreads();
     const long long v0 = (long long)blockIdx.x * C0_THREADS;
     const long long v = v0 + threadIdx.x;
     if (v < V) {
@@ -54,18 +50,19 @@ __global__ __launch_bounds__(C0_THREADS) void conv_c0_fwd_kernel(float *__restri
         float acc[C0_CO];
 #pragma unroll
         for (int co = 0; co < C0_CO; ++co) acc[co] = 0.0f;
-#pragma unroll
+#pragma unroll 1                // (the filter values are wave-uniform: scalar loads of wt[tap][0 .. 17]; fully unrolled they would not fit the scalar registers)
         for (int tap = 0; tap < 27; ++tap) {
             const int dz = tap % 3 - 1, dx = (tap / 3) % 3 - 1, dy = tap / 9 - 1;
             const bool ok = (unsigned)(yy + dy) < (unsigned)Y && (unsigned)(xx + dx) < (unsigned)X && (unsigned)(z + dz) < (unsigned)Z;
             float xv = x[ok ? v + ((long long)dy * X + dx) * Z + dz : v];
             if (!ok) xv = 0.0f;
+            const float *wp = wt + tap * C0_CO;
 #pragma unroll
-            for (int co = 0; co < C0_CO; ++co) acc[co] = acc[co] + xv * s_w[tap * C0_CO + co];      // taps ascending: a fixed order
+            for (int co = 0; co < C0_CO; ++co) acc[co] = acc[co] + xv * wp[co];                  // taps ascending: a fixed order
         }
 #pragma unroll
         for (int co = 0; co < C0_CO; ++co) {
-            float r = acc[co] + s_w[27 * C0_CO + co];
+            float r = acc[co] + (bias ? bias[co] : 0.0f);
             if (relu) r = r > 0.0f ? r : 0.0f;
             s_t[threadIdx.x * C0_CO + co] = r;
         }

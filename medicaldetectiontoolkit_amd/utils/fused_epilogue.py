@@ -953,9 +953,7 @@ class _ConvC0BiasReLU(Function):
         co = int(w.shape[0])
         xc = x.detach().contiguous()
         y = torch.empty((B, co, Y, X, Z), dtype=torch.float32, device=x.device, memory_format=torch.channels_last_3d)
-        wd = w.detach().reshape(co, 27)
-        if not wd.is_contiguous():
-            wd = wd.contiguous()
+        wd = w.detach().reshape(co, 27).t().contiguous()          # [27][18]: a tap's filter values are one contiguous (wave-uniform) read
         rc = _lib.lib().mdt_conv_c0_forward(xc.data_ptr(), wd.data_ptr(), bias.detach().data_ptr() if bias is not None else None, 1 if relu else 0, y.data_ptr(),
                                             B, Y, X, Z, co, _lib.raw_stream())
         if rc != 0:

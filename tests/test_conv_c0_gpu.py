@@ -23,7 +23,8 @@ def test_conv_c0_forward_and_backward_vs_float64(shape, relu, cuda):
     L = _lib.lib()
     assert L.mdt_conv_c0_supported(1, 18, 3, Z) and not L.mdt_conv_c0_supported(2, 18, 3, Z) and not L.mdt_conv_c0_supported(1, 18, 3, 48)
     y = torch.full((B, 18, Y, X, Z), 7.0, device=cuda).contiguous(memory_format=torch.channels_last_3d)
-    assert L.mdt_conv_c0_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), relu, y.data_ptr(), B, Y, X, Z, 18, _lib.raw_stream()) == 0
+    wt = w.reshape(18, 27).t().contiguous()
+    assert L.mdt_conv_c0_forward(x.data_ptr(), wt.data_ptr(), b.data_ptr(), relu, y.data_ptr(), B, Y, X, Z, 18, _lib.raw_stream()) == 0
     ref = F.conv3d(x.double(), w.double(), b.double(), 1, 1)
     mag = F.conv3d(x.double().abs(), w.double().abs(), b.double().abs(), 1, 1)
     if relu:

@@ -40,7 +40,7 @@ print("conv_seg input gradient %.2f ms" % timed(lambda: L.mdt_conv_seg_input_gra
 print("conv_seg weight gradient %.2f ms" % timed(lambda: L.mdt_conv_seg_weight_grad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, Y, X, Z, 36, 2, ws.data_ptr(), wsb, S)))
 del x, gx
 x1 = torch.randn(B, 1, Y, X, Z, device=dev)
-w1 = torch.randn(18, 27, device=dev) * 0.1
+w1 = torch.randn(27, 18, device=dev) * 0.1
 b1 = torch.randn(18, device=dev)
 y1 = torch.empty(B, 18, Y, X, Z, device=dev).contiguous(memory_format=mf)
 g1 = torch.randn(B, 18, Y, X, Z, device=dev).contiguous(memory_format=mf)
